@@ -1,0 +1,239 @@
+/* ptamd.h -- C ABI of the MI355X (gfx950) ray-queue render path.
+ *
+ * Drop-in boundary for ONE path of mathijs727/OpenCL-Path-Tracer: the ray-queue render loop
+ *   generatePrimaryRays -> intersectWalk -> shade -> intersectShadows (+ updateKernelData, accumulate)
+ * i.e. everything the reference's RayTracer does through src/opencl + assets/cl.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions: every call returns 0 on success or a negative pt_status; the message of the last
+ * failure on a context is available from pt_last_error().  Nothing here ever exits the process
+ * (the reference's checkClErr does, src/opencl/cl_helpers.cpp:21-31).  All scene inputs use the byte
+ * layouts the reference uploads to its device buffers, so a maintainer
+ * passes the host vectors RayTracer already owns (src/raytracer.h:86-91) unchanged; the library
+ * converts them to its own SoA / packed layouts in HBM during pt_upload_*.
+ * A context is bound to one GPU and is not re-entrant; use one context per device.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1, /* bad argument / inconsistent scene */
+    PT_ERR_HIP = -2, /* a HIP runtime call failed */
+    PT_ERR_STATE = -3, /* call order (e.g. render before upload) */
+    PT_ERR_UNSUPPORTED = -4
+} pt_status;
+
+/* ---- scene arrays: byte-for-byte the reference's device structs ---------------------- */
+
+/* VertexData, assets/cl/shapes.cl:13-18 == VertexSceneData, src/vertices.h:11-16 (48 B) */
+typedef struct {
+    float vertex[4]; /* xyz, w unused */
+    float normal[4];
+    float texCoord[2];
+    float _pad[2];
+} pt_vertex;
+
+/* TriangleData, assets/cl/shapes.cl:7-11 == TriangleSceneData, src/vertices.h:6-9 (16 B) */
+typedef struct {
+    uint32_t indices[3]; /* GLOBAL vertex indices (rebased, src/raytracer.cpp:254-258) */
+    uint32_t materialIndex; /* GLOBAL material index */
+} pt_triangle;
+
+/* Material, assets/cl/material.cl:3-51 == src/model/material.h:8-61 (48 B tagged union) */
+typedef enum { PT_MAT_DIFFUSE = 0, PT_MAT_PBR = 1, PT_MAT_REFRACTIVE = 2, PT_MAT_BASIC_REFRACTIVE = 3, PT_MAT_EMISSIVE = 4 } pt_material_type;
+typedef struct {
+    union {
+        struct { float diffuseColour[4]; int32_t textureId; } diffuse; /* textureId -1: untextured */
+        struct { float baseColour[4]; float smoothness; float f0NonMetal; uint8_t metallic; } pbr;
+        struct { float absorption[4]; float smoothness; float refractiveIndex; } refractive;
+        struct { float absorption[4]; float refractiveIndex; } basicRefractive;
+        struct { float emissiveColour[4]; } emissive;
+        uint8_t _raw[32];
+    } u;
+    int32_t type; /* pt_material_type */
+    uint8_t _pad[12];
+} pt_material;
+
+/* EmissiveTriangle, assets/cl/light.cl:5-9 == src/vertices.h:18-21 (96 B), WORLD space */
+typedef struct {
+    float vertices[3][4];
+    pt_material material;
+} pt_emissive_triangle;
+
+/* SubBvhNode, assets/cl/bvh.cl:5-16 == SubBVHNode, src/bvh/bvh_nodes.h:35-49 (48 B).
+ * Leaf iff triangleCount != 0; an inner node's children are (leftChildIndex, leftChildIndex+1). */
+typedef struct {
+    float min[4];
+    float max[4];
+    uint32_t leftChildOrFirstTriangle; /* GLOBAL (rebased, src/raytracer.cpp:262-269) */
+    uint32_t triangleCount;
+    uint32_t _pad[2];
+} pt_sub_bvh_node;
+
+/* TopBvhNode, assets/cl/bvh.cl:18-34 == TopBVHNode, src/bvh/bvh_nodes.h:20-33 (112 B).
+ * Leaf: a = root of the instance's sub-BVH (global node index), invTransform = inverse(world),
+ * column-major.  Inner: a = left child, b = right child (top-node indices). */
+typedef struct {
+    float min[4];
+    float max[4];
+    float invTransform[16];
+    uint32_t a;
+    uint32_t b;
+    uint32_t isLeaf;
+    uint32_t _pad;
+} pt_top_bvh_node;
+
+/* Camera, assets/cl/camera.cl:7-26 == CameraData, src/camera.h:7-27 (128 B) */
+typedef struct {
+    float eyePoint[4];
+    float screenPoint[4]; /* top-left corner of the virtual screen */
+    float u[4];
+    float v[4];
+    float uNormalized[4];
+    float vNormalized[4];
+    float focalDistance;
+    float apertureRadius;
+    float relativeAperture; /* f-stops */
+    float shutterTime;
+    float ISO;
+    uint8_t thinLensEnabled;
+    uint8_t _pad[11];
+} pt_camera;
+
+/* ---- configuration -------------------------------------------------------------------- */
+
+typedef enum {
+    /* production: counter-based PRNG keyed by (pixel, sample, depth, dimension, seed); wave-ballot
+     * compaction in arbitrary wave order.  Images are bit-reproducible run to run. */
+    PT_RNG_COUNTER = 0,
+    /* parity: clRNG LFSR113 streams bound to queue slots exactly like the reference
+     * (kernel.cl:43,246; src/raytracer.cpp:739-751) with stable (slot-ordered) compaction, so a
+     * render follows the reference's kernels run in work-item order (oracle/_ref). */
+    PT_RNG_LFSR113_PARITY = 1
+} pt_rng_mode;
+
+typedef struct {
+    uint32_t width, height; /* full image size (all ranks) */
+    uint32_t max_active_rays; /* queue capacity; 0 = one slot per owned pixel (no refill).
+                                 Reference: MAX_ACTIVE_RAYS = 1280*720, src/raytracer.cpp:40 */
+    uint32_t max_bounces; /* 0 = 4 (MAX_ITERATIONS, assets/cl/kernel.cl:4) */
+    uint32_t rng_mode; /* pt_rng_mode */
+    uint32_t seed; /* PT_RNG_COUNTER only */
+    int32_t device; /* HIP device ordinal */
+    uint32_t flags; /* PT_FLAG_* */
+} pt_config;
+
+#define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */
+
+typedef struct { uint32_t x0, y0, x1, y1; } pt_rect; /* [x0,x1) x [y0,y1) */
+
+typedef struct {
+    uint64_t rays_extension; /* traceRay calls from intersectWalk on live entries */
+    uint64_t rays_shadow; /* traceRay calls from intersectShadows on live entries */
+    uint64_t rays_generated; /* primary rays */
+    uint64_t shade_hits; /* shade invocations on a hit */
+    uint64_t deposits; /* accumulator updates */
+    uint64_t samples; /* samples per pixel rendered since last reset */
+    double ms_last_render; /* device time of the last pt_render (hipEvent, whole call) */
+    double ms_intersect, ms_shade, ms_shadow, ms_gen; /* per-kernel-family device ms of the last pt_render
+                                                        (only when PT_PROFILE_KERNELS was requested) */
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---- lifetime -- replaces CLContext + RayTracer ctor/dtor (src/opencl/context.cpp, src/raytracer.cpp:63-86) */
+int pt_create(const pt_config* cfg, pt_ctx** out);
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(const pt_ctx* ctx); /* ctx may be NULL: error of a failed pt_create */
+/* Run everything on a caller-owned HIP stream (e.g. torch's current stream); NULL = own stream. */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+
+/* ---- uploads -- replace the enqueueWriteBuffer calls of src/raytracer.cpp:273-282 and :556-578 */
+int pt_upload_static(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, const pt_triangle* tris, uint32_t n_tris,
+    const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
+int pt_upload_dynamic(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
+    const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
+/* kind 0: material textures (CLTextureArray 1024x1024 BGRA8 in the reference, src/raytracer.cpp:284),
+ * kind 1: skydome (RGBA32F, src/raytracer.cpp:153-160).  data: layers*h*w*4 floats, RGBA, already
+ * linear / brightness-scaled (what read_imagef would return).  Sampling reproduces
+ * CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_REPEAT | CLK_FILTER_LINEAR. */
+int pt_upload_texture_array(pt_ctx* ctx, int kind, uint32_t width, uint32_t height, uint32_t layers, const float* rgba);
+
+/* ---- per-frame state -- replaces the KernelData upload, src/raytracer.cpp:294-317 */
+int pt_set_camera(pt_ctx* ctx, const pt_camera* cam); /* does NOT clear; caller decides (src/raytracer.cpp:99-105) */
+/* Restrict this context to a set of image rectangles (multi-GPU tile sharding).  n = 0: whole image. */
+int pt_set_tiles(pt_ctx* ctx, const pt_rect* rects, uint32_t n);
+/* Use caller-owned device memory (width*height float4) as the HDR accumulator, e.g. a torch tensor
+ * that is then reduced with torch.distributed / RCCL.  NULL = library-owned. */
+int pt_set_accum_buffer(pt_ctx* ctx, void* device_float4);
+int pt_clear(pt_ctx* ctx); /* clearAccumulationBuffer, src/raytracer.cpp:452-462; also resets spp */
+
+/* ---- render -- replaces RayTracer::traceRays (src/raytracer.cpp:289-430): `spp` samples per owned pixel,
+ * asynchronous on the context's stream. */
+int pt_render(pt_ctx* ctx, uint32_t spp);
+int pt_synchronize(pt_ctx* ctx);
+/* accumulate kernel, assets/cl/accumulate.cl:6-34: mean -> exposure -> Reinhard -> sRGB; width*height*4 floats out (host) */
+int pt_resolve(pt_ctx* ctx, float* rgba_out);
+int pt_read_accum(pt_ctx* ctx, float* out_float4); /* width*height*4 floats: HDR sums (host) */
+int pt_write_accum(pt_ctx* ctx, const float* in_float4, uint32_t spp); /* restore a checkpoint */
+void* pt_accum_device_ptr(pt_ctx* ctx);
+uint32_t pt_samples_per_pixel(const pt_ctx* ctx); /* RayTracer::getSamplesPerPixel */
+int pt_stats_get(pt_ctx* ctx, pt_stats* out); /* synchronises */
+int pt_stats_reset(pt_ctx* ctx);
+int pt_profile_kernels(pt_ctx* ctx, int enable); /* per-kernel hipEvent timing inside pt_render */
+/* Sum the accumulator over ranks onto `root` with RCCL (ncclReduce, float sum). comm: ncclComm_t. */
+int pt_reduce_accum(pt_ctx* ctx, void* nccl_comm, int root);
+
+/* ---- kernel-granular entry points (parity tests and micro-benchmarks) ------------------
+ * Host SoA arrays in, host SoA arrays out; the scene must have been uploaded. */
+typedef struct {
+    const float *ox, *oy, *oz, *dx, *dy, *dz; /* n each */
+    const float* tmax; /* any-hit: ray length; closest-hit: ignored (INFINITY) */
+} pt_rays_soa;
+typedef struct {
+    float *t, *u, *v; /* closest hit: t (INFINITY on miss), barycentrics */
+    int32_t* prim; /* index into the (reordered) triangle array, -1 on miss; any-hit: 1/0 occluded */
+    int32_t* inst; /* top-level LEAF node index of the hit instance, -1 on miss */
+} pt_hits_soa;
+/* traceRay (assets/cl/scene.cl:61-271) over n rays; any_hit selects intersectShadows semantics.
+ * repeat > 1 re-runs the launch for timing; ms_out (optional) receives the mean device ms per launch. */
+int pt_intersect(pt_ctx* ctx, const pt_rays_soa* rays, uint32_t n, int any_hit, pt_hits_soa* hits, uint32_t repeat, float* ms_out);
+/* generatePrimaryRays (kernel.cl:24-84) for sample index `sample`: first n owned pixels, SoA out. */
+int pt_gen_rays(pt_ctx* ctx, uint32_t sample, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel);
+
+/* One shade invocation per entry (kernel.cl:190-301, neeIsShading shading.cl:356-623), PT_RNG_COUNTER keying. */
+typedef struct {
+    uint32_t n;
+    /* in: the ray that was traced, its path state and its hit record */
+    const float *ox, *oy, *oz, *dx, *dy, *dz;
+    const float *thr_r, *thr_g, *thr_b;
+    const uint32_t* pixel;
+    const uint32_t* flags; /* bit1 = LASTSPECULAR */
+    const uint32_t* bounce;
+    const float *t, *u, *v;
+    const int32_t *prim, *inst;
+    uint32_t sample;
+    /* out */
+    float *radiance; /* 3n: deposit made by shade itself (emissive / sky) */
+    uint32_t* out_alive; /* continuation ray spawned */
+    float *nox, *noy, *noz, *ndx, *ndy, *ndz, *nthr_r, *nthr_g, *nthr_b;
+    uint32_t* nflags;
+    uint32_t* shadow_alive;
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *slen, *sc_r, *sc_g, *sc_b;
+} pt_shade_batch_io;
+int pt_shade_batch(pt_ctx* ctx, pt_shade_batch_io* io);
+
+const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

@@ -1,0 +1,61 @@
+/* ptamd_host.h -- C entry points of the host-side scene library (CPU only, no HIP):
+ * meshes + bottom-level BVH builders, scene graph with instancing, top-level BVH, flattening into
+ * the device arrays of ptamd.h, and camera parameter derivation.  These mirror, for non-C++
+ * callers, the C++ classes in opencl-path-tracer_amd/host/ which keep the reference's API
+ * (Scene::addNode src/scene.h:39, Mesh src/model/mesh.h, buildTopBVH src/bvh/top_bvh_build.h:12,
+ * Camera::get_camera_data src/camera.h:33).  Calls return 0 / a handle on success, -1 / NULL on
+ * failure with the message in pth_last_error() (thread-local). */
+#ifndef PTAMD_HOST_H
+#define PTAMD_HOST_H
+#include "ptamd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_mesh pth_mesh;
+typedef struct pth_scene pth_scene;
+
+enum { PTH_BVH_BINNED_SAH = 0, PTH_BVH_BINNED_FAST = 1, PTH_BVH_SPATIAL_SPLIT = 2 };
+
+typedef struct {
+    uint32_t num_vertices, num_input_triangles, num_triangle_refs, num_nodes, num_leaves, max_depth, max_leaf_size;
+    uint32_t children_inside_parents, triangles_inside_leaves, all_triangles_referenced; /* BvhTester invariants, src/bvh/bvh_test.cpp:117-139 */
+    uint32_t reachable_triangle_refs, reachable_nodes;
+} pth_mesh_stats;
+
+typedef struct {
+    uint32_t num_vertices, num_triangles, num_materials, num_sub_nodes, num_lights, num_top_nodes, top_root, num_instances;
+} pth_scene_counts;
+
+typedef struct {
+    float location[3];
+    float orientation_wxyz[4];
+    float horizontal_fov_deg, aspect_ratio, focal_distance;
+    float focal_length_mm, aperture_fstops, shutter_time, iso; /* <= 0: reference defaults 50, 8, 1/32, 1200 (src/camera.cpp:5-15) */
+    int thin_lens;
+} pth_camera_params;
+
+const char* pth_last_error(void);
+
+pth_mesh* pth_mesh_create(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+    const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles, const pt_material* materials,
+    size_t numMaterials, int builder);
+pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int builder);
+void pth_mesh_destroy(pth_mesh* m);
+int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out);
+int pth_mesh_copy_bvh(const pth_mesh* m, pt_sub_bvh_node* nodes, pt_triangle* triangles, uint32_t* originalTriangle);
+
+pth_scene* pth_scene_create(void);
+void pth_scene_destroy(pth_scene* s);
+/* returns the new node id (>= 0); parent = -1 for the root */
+int pth_scene_add_node(pth_scene* s, const pth_mesh* m, const float location[3], const float orientation_wxyz[4], const float scale[3], int parent);
+int pth_scene_set_transform(pth_scene* s, int node, const float location[3], const float orientation_wxyz[4], const float scale[3]);
+int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts);
+int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top);
+
+int pth_camera_data(const pth_camera_params* p, pt_camera* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,543 @@
+// Bottom-level BVH construction: binned SAH (3 axes or longest axis) and SBVH with spatial
+// splits + reference unsplitting.  See bvh_build.h for the contract and the reference citations.
+#include "bvh_build.h"
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cstring>
+#include <stdexcept>
+
+namespace raytracer {
+namespace {
+
+    constexpr uint32_t kLeafSize = 3; // MIN_PRIMS_PER_LEAF (bvh_build.cpp:15)
+    constexpr float kTraversalCost = 1.5f; // SAH_TRAVERSAL_COST (:17)
+    constexpr float kIntersectCost = 1.0f; // SAH_INTERSECTION_COST (:18)
+    constexpr float kSpatialAlpha = 1e-5f; // SPATIAL_SPLIT_ALPHA (:16)
+    constexpr int kObjectBins = 32; // bvh_object_split.cpp:10
+    constexpr int kSpatialBins = 8; // bvh_spatial_split.cpp:10
+    constexpr int kMedianFallbackDepth = 40;
+
+    struct PrimRef {
+        uint32_t prim;
+        AABB box;
+    };
+
+    struct Candidate {
+        bool valid = false;
+        int axis = 0;
+        int plane = 0; // split between bin plane-1 and bin plane
+        float cost = 0.0f; // SA_L*N_L + SA_R*N_R
+        AABB leftBox, rightBox;
+        size_t leftCount = 0, rightCount = 0;
+    };
+
+    inline vec3 position(const pt_vertex& v) { return { v.vertex[0], v.vertex[1], v.vertex[2] }; }
+
+    inline void storeBox(SubBVHNode& n, const AABB& b)
+    {
+        n.min[0] = b.min.x, n.min[1] = b.min.y, n.min[2] = b.min.z, n.min[3] = 0.0f;
+        n.max[0] = b.max.x, n.max[1] = b.max.y, n.max[2] = b.max.z, n.max[3] = 0.0f;
+    }
+    inline AABB loadBox(const SubBVHNode& n) { return { { n.min[0], n.min[1], n.min[2] }, { n.max[0], n.max[1], n.max[2] } }; }
+
+    inline int longestAxis(vec3 e)
+    {
+        int a = 0;
+        if (e.y > e[a]) a = 1;
+        if (e.z > e[a]) a = 2;
+        return a;
+    }
+
+    inline int binOf(float x, float lo, float invWidth, int numBins)
+    {
+        int b = (int)((x - lo) * invWidth);
+        return std::clamp(b, 0, numBins - 1);
+    }
+
+    // ---- object split: bin reference-box centroids, sweep 31 planes -----------------------
+    Candidate findObjectSplit(const AABB& nodeBox, const std::vector<PrimRef>& refs, const int* axes, int numAxes)
+    {
+        Candidate best;
+        vec3 ext = nodeBox.extent();
+        for (int ai = 0; ai < numAxes; ai++) {
+            const int axis = axes[ai];
+            if (!(ext[axis] > std::numeric_limits<float>::min()))
+                continue;
+            const float invWidth = (float)kObjectBins / ext[axis];
+            std::array<AABB, kObjectBins> box;
+            std::array<size_t, kObjectBins> count {};
+            for (const PrimRef& r : refs) {
+                int b = binOf(r.box.center()[axis], nodeBox.min[axis], invWidth, kObjectBins);
+                box[b].fit(r.box);
+                count[b]++;
+            }
+            // suffix boxes/counts, then a forward sweep
+            std::array<AABB, kObjectBins> rightBox;
+            std::array<size_t, kObjectBins> rightCount {};
+            AABB acc;
+            size_t n = 0;
+            for (int b = kObjectBins - 1; b >= 1; b--) {
+                acc.fit(box[b]);
+                n += count[b];
+                rightBox[b] = acc;
+                rightCount[b] = n;
+            }
+            AABB left;
+            size_t nl = 0;
+            for (int plane = 1; plane < kObjectBins; plane++) {
+                left.fit(box[plane - 1]);
+                nl += count[plane - 1];
+                if (nl == 0 || rightCount[plane] == 0)
+                    continue;
+                float cost = (float)nl * left.surfaceArea() + (float)rightCount[plane] * rightBox[plane].surfaceArea();
+                if (!best.valid || cost < best.cost) {
+                    best.valid = true;
+                    best.axis = axis;
+                    best.plane = plane;
+                    best.cost = cost;
+                    best.leftBox = left;
+                    best.rightBox = rightBox[plane];
+                    best.leftCount = nl;
+                    best.rightCount = rightCount[plane];
+                }
+            }
+        }
+        return best;
+    }
+
+    void applyObjectSplit(const AABB& nodeBox, const Candidate& c, std::vector<PrimRef>& refs, std::vector<PrimRef>& left, std::vector<PrimRef>& right)
+    {
+        const float invWidth = (float)kObjectBins / nodeBox.extent()[c.axis];
+        left.reserve(c.leftCount);
+        right.reserve(c.rightCount);
+        for (PrimRef& r : refs) {
+            int b = binOf(r.box.center()[c.axis], nodeBox.min[c.axis], invWidth, kObjectBins);
+            (b < c.plane ? left : right).push_back(r);
+        }
+    }
+
+    // ---- triangle clipping (Sutherland-Hodgman against one axis-aligned half space) ---------
+    struct Polygon {
+        vec3 p[12];
+        int n = 0;
+    };
+
+    void clipHalfSpace(Polygon& poly, int axis, float plane, bool keepGreater)
+    {
+        Polygon out;
+        for (int i = 0; i < poly.n; i++) {
+            vec3 a = poly.p[i], b = poly.p[(i + 1) % poly.n];
+            bool ina = keepGreater ? a[axis] >= plane : a[axis] <= plane;
+            bool inb = keepGreater ? b[axis] >= plane : b[axis] <= plane;
+            if (ina)
+                out.p[out.n++] = a;
+            if (ina != inb) {
+                float t = (plane - a[axis]) / (b[axis] - a[axis]);
+                vec3 x = a + (b - a) * t;
+                x[axis] = plane; // exact on the plane
+                out.p[out.n++] = x;
+            }
+        }
+        poly = out;
+    }
+
+    // Bounds of triangle (a,b,c) clipped to `clip`; false if nothing is left.
+    bool clippedBounds(vec3 a, vec3 b, vec3 c, const AABB& clip, AABB& out)
+    {
+        Polygon poly;
+        poly.p[0] = a, poly.p[1] = b, poly.p[2] = c;
+        poly.n = 3;
+        for (int axis = 0; axis < 3 && poly.n >= 3; axis++) {
+            clipHalfSpace(poly, axis, clip.min[axis], true);
+            if (poly.n < 3)
+                break;
+            clipHalfSpace(poly, axis, clip.max[axis], false);
+        }
+        if (poly.n < 3)
+            return false;
+        AABB r;
+        for (int i = 0; i < poly.n; i++)
+            r.fit(poly.p[i]);
+        // guard against round-off pushing the result outside the clip box
+        r.min = vmax(r.min, clip.min);
+        r.max = vmin(r.max, clip.max);
+        out = r;
+        return true;
+    }
+
+    struct Builder {
+        const pt_vertex* verts;
+        const pt_triangle* tris;
+        BvhBuilder kind;
+        std::vector<SubBVHNode> nodes;
+        std::vector<PrimRef> leafRefs;
+        float rootArea = 0.0f;
+        uint32_t maxDepthSeen = 0;
+
+        uint32_t allocPair()
+        {
+            uint32_t first = (uint32_t)nodes.size();
+            SubBVHNode blank;
+            std::memset(&blank, 0, sizeof(blank));
+            storeBox(blank, AABB());
+            nodes.push_back(blank);
+            nodes.push_back(blank);
+            return first;
+        }
+
+        void triangle(uint32_t prim, vec3& a, vec3& b, vec3& c) const
+        {
+            a = position(verts[tris[prim].indices[0]]);
+            b = position(verts[tris[prim].indices[1]]);
+            c = position(verts[tris[prim].indices[2]]);
+        }
+
+        // ---- spatial split search: chopped-triangle binning with enter/exit counters -------
+        Candidate findSpatialSplit(const AABB& nodeBox, const std::vector<PrimRef>& refs) const
+        {
+            Candidate best;
+            vec3 ext = nodeBox.extent();
+            for (int axis = 0; axis < 3; axis++) {
+                if (!(ext[axis] > std::numeric_limits<float>::min()))
+                    continue;
+                const float width = ext[axis] / (float)kSpatialBins;
+                const float invWidth = (float)kSpatialBins / ext[axis];
+                float planes[kSpatialBins + 1];
+                for (int i = 0; i <= kSpatialBins; i++)
+                    planes[i] = nodeBox.min[axis] + (float)i * width;
+                planes[kSpatialBins] = nodeBox.max[axis];
+
+                std::array<AABB, kSpatialBins> box;
+                std::array<size_t, kSpatialBins> enter {}, leave {};
+                for (const PrimRef& r : refs) {
+                    int lo = binOf(r.box.min[axis], nodeBox.min[axis], invWidth, kSpatialBins);
+                    int hi = binOf(r.box.max[axis], nodeBox.min[axis], invWidth, kSpatialBins);
+                    if (lo == hi) {
+                        box[lo].fit(r.box);
+                        enter[lo]++;
+                        leave[lo]++;
+                        continue;
+                    }
+                    vec3 a, b, c;
+                    triangle(r.prim, a, b, c);
+                    int first = kSpatialBins, last = -1;
+                    for (int bin = lo; bin <= hi; bin++) {
+                        AABB clip = r.box;
+                        clip.min[axis] = std::max(clip.min[axis], planes[bin]);
+                        clip.max[axis] = std::min(clip.max[axis], planes[bin + 1]);
+                        AABB piece;
+                        if (clip.min[axis] <= clip.max[axis] && clippedBounds(a, b, c, clip, piece)) {
+                            box[bin].fit(piece);
+                            first = std::min(first, bin);
+                            last = std::max(last, bin);
+                        }
+                    }
+                    if (first <= last) {
+                        enter[first]++;
+                        leave[last]++;
+                    }
+                }
+                std::array<AABB, kSpatialBins> rightBox;
+                std::array<size_t, kSpatialBins> rightCount {};
+                AABB acc;
+                size_t n = 0;
+                for (int b = kSpatialBins - 1; b >= 1; b--) {
+                    acc.fit(box[b]);
+                    n += leave[b];
+                    rightBox[b] = acc;
+                    rightCount[b] = n;
+                }
+                AABB left;
+                size_t nl = 0;
+                for (int plane = 1; plane < kSpatialBins; plane++) {
+                    left.fit(box[plane - 1]);
+                    nl += enter[plane - 1];
+                    if (nl == 0 || rightCount[plane] == 0)
+                        continue;
+                    float cost = (float)nl * left.surfaceArea() + (float)rightCount[plane] * rightBox[plane].surfaceArea();
+                    if (!best.valid || cost < best.cost) {
+                        best.valid = true;
+                        best.axis = axis;
+                        best.plane = plane;
+                        best.cost = cost;
+                        best.leftBox = left;
+                        best.rightBox = rightBox[plane];
+                        best.leftCount = nl;
+                        best.rightCount = rightCount[plane];
+                    }
+                }
+            }
+            return best;
+        }
+
+        // Distribute references around the chosen plane; straddlers are either duplicated with
+        // clipped boxes or, when cheaper, kept whole on one side (SBVH paper 4.4, "unsplitting").
+        bool applySpatialSplit(const AABB& nodeBox, const Candidate& c, const std::vector<PrimRef>& refs,
+            std::vector<PrimRef>& left, std::vector<PrimRef>& right, AABB& leftBox, AABB& rightBox) const
+        {
+            const int axis = c.axis;
+            float pos = nodeBox.min[axis] + (float)c.plane * (nodeBox.extent()[axis] / (float)kSpatialBins);
+            const float saL = c.leftBox.surfaceArea(), saR = c.rightBox.surfaceArea();
+            const float splitCost = saL * (float)c.leftCount + saR * (float)c.rightCount;
+            leftBox = AABB();
+            rightBox = AABB();
+            for (const PrimRef& r : refs) {
+                if (r.box.max[axis] <= pos) {
+                    left.push_back(r);
+                    leftBox.fit(r.box);
+                } else if (r.box.min[axis] >= pos) {
+                    right.push_back(r);
+                    rightBox.fit(r.box);
+                } else {
+                    float onlyLeft = c.leftBox.merged(r.box).surfaceArea() * (float)c.leftCount + saR * (float)(c.rightCount - 1);
+                    float onlyRight = saL * (float)(c.leftCount - 1) + c.rightBox.merged(r.box).surfaceArea() * (float)c.rightCount;
+                    if (std::min(onlyLeft, onlyRight) < splitCost) {
+                        if (onlyLeft < onlyRight) {
+                            left.push_back(r);
+                            leftBox.fit(r.box);
+                        } else {
+                            right.push_back(r);
+                            rightBox.fit(r.box);
+                        }
+                        continue;
+                    }
+                    vec3 a, b, cc;
+                    triangle(r.prim, a, b, cc);
+                    AABB clipL = r.box, clipR = r.box, piece;
+                    clipL.max[axis] = pos;
+                    clipR.min[axis] = pos;
+                    bool any = false;
+                    if (clippedBounds(a, b, cc, clipL, piece)) {
+                        left.push_back({ r.prim, piece });
+                        leftBox.fit(piece);
+                        any = true;
+                    }
+                    if (clippedBounds(a, b, cc, clipR, piece)) {
+                        right.push_back({ r.prim, piece });
+                        rightBox.fit(piece);
+                        any = true;
+                    }
+                    if (!any) { // numerically degenerate sliver: keep it whole on the left
+                        left.push_back(r);
+                        leftBox.fit(r.box);
+                    }
+                }
+            }
+            return !left.empty() && !right.empty() && left.size() < refs.size() && right.size() < refs.size();
+        }
+
+        void medianSplit(const AABB& nodeBox, std::vector<PrimRef>& refs, std::vector<PrimRef>& left, std::vector<PrimRef>& right, AABB& lb, AABB& rb)
+        {
+            int axis = longestAxis(nodeBox.extent());
+            size_t mid = refs.size() / 2;
+            std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [axis](const PrimRef& x, const PrimRef& y) {
+                return x.box.center()[axis] < y.box.center()[axis];
+            });
+            left.assign(refs.begin(), refs.begin() + mid);
+            right.assign(refs.begin() + mid, refs.end());
+            for (auto& r : left) lb.fit(r.box);
+            for (auto& r : right) rb.fit(r.box);
+        }
+
+        struct Work {
+            uint32_t node;
+            uint32_t depth;
+            std::vector<PrimRef> refs;
+        };
+
+        void makeLeaf(uint32_t node, const std::vector<PrimRef>& refs)
+        {
+            nodes[node].leftChildOrFirstTriangle = (uint32_t)leafRefs.size();
+            nodes[node].triangleCount = (uint32_t)refs.size();
+            leafRefs.insert(leafRefs.end(), refs.begin(), refs.end());
+        }
+
+        void run(std::vector<PrimRef>&& all)
+        {
+            AABB rootBox;
+            for (auto& r : all) rootBox.fit(r.box);
+            rootArea = rootBox.surfaceArea();
+            uint32_t root = allocPair();
+            storeBox(nodes[root], rootBox);
+
+            std::vector<Work> stack;
+            stack.push_back({ root, 0, std::move(all) });
+            while (!stack.empty()) {
+                Work w = std::move(stack.back());
+                stack.pop_back();
+                maxDepthSeen = std::max(maxDepthSeen, w.depth);
+                const AABB nodeBox = loadBox(nodes[w.node]);
+                const size_t n = w.refs.size();
+                if (n <= kLeafSize || w.depth >= (uint32_t)kMaxBvhDepth) {
+                    makeLeaf(w.node, w.refs);
+                    continue;
+                }
+
+                std::vector<PrimRef> left, right;
+                AABB leftBox, rightBox;
+                bool split = false;
+                if (w.depth >= (uint32_t)kMedianFallbackDepth) {
+                    medianSplit(nodeBox, w.refs, left, right, leftBox, rightBox);
+                    split = !left.empty() && !right.empty();
+                } else {
+                    const float leafCost = (float)n * kIntersectCost;
+                    const float area = nodeBox.surfaceArea();
+                    auto sah = [&](const Candidate& c) { return kTraversalCost + c.cost * kIntersectCost / area; };
+                    static const int allAxes[3] = { 0, 1, 2 };
+                    int one = longestAxis(nodeBox.extent());
+                    Candidate obj = (kind == BvhBuilder::BinnedFast) ? findObjectSplit(nodeBox, w.refs, &one, 1) : findObjectSplit(nodeBox, w.refs, allAxes, 3);
+                    bool objOk = obj.valid && area > 0.0f && sah(obj) < leafCost;
+                    bool done = false;
+                    if (kind == BvhBuilder::SpatialSplit && area > 0.0f) {
+                        bool trySpatial = !objOk;
+                        if (objOk) {
+                            float overlap = obj.leftBox.intersection(obj.rightBox).surfaceArea();
+                            trySpatial = overlap / rootArea > kSpatialAlpha;
+                        }
+                        if (trySpatial) {
+                            Candidate sp = findSpatialSplit(nodeBox, w.refs);
+                            if (sp.valid && sah(sp) < leafCost && (!objOk || sp.cost < obj.cost)) {
+                                if (applySpatialSplit(nodeBox, sp, w.refs, left, right, leftBox, rightBox)) {
+                                    split = done = true;
+                                } else {
+                                    left.clear();
+                                    right.clear();
+                                }
+                            }
+                        }
+                    }
+                    if (!done && objOk) {
+                        applyObjectSplit(nodeBox, obj, w.refs, left, right);
+                        leftBox = obj.leftBox;
+                        rightBox = obj.rightBox;
+                        split = !left.empty() && !right.empty();
+                    }
+                }
+                if (!split) {
+                    makeLeaf(w.node, w.refs);
+                    continue;
+                }
+                uint32_t pair = allocPair();
+                nodes[w.node].leftChildOrFirstTriangle = pair;
+                nodes[w.node].triangleCount = 0;
+                storeBox(nodes[pair], leftBox);
+                storeBox(nodes[pair + 1], rightBox);
+                w.refs.clear();
+                w.refs.shrink_to_fit();
+                stack.push_back({ pair, w.depth + 1, std::move(left) });
+                stack.push_back({ pair + 1, w.depth + 1, std::move(right) });
+            }
+        }
+    };
+
+} // namespace
+
+BvhBuildResult buildBVH(const VertexSceneData* vertices, size_t numVertices, const TriangleSceneData* triangles, size_t numTriangles, BvhBuilder kind)
+{
+    if (numTriangles == 0)
+        throw std::invalid_argument("buildBVH: empty mesh");
+    std::vector<PrimRef> refs(numTriangles);
+    for (size_t i = 0; i < numTriangles; i++) {
+        for (int k = 0; k < 3; k++) {
+            if (triangles[i].indices[k] >= numVertices)
+                throw std::invalid_argument("buildBVH: vertex index out of range");
+            refs[i].box.fit(position(vertices[triangles[i].indices[k]]));
+        }
+        refs[i].prim = (uint32_t)i;
+    }
+    Builder b { vertices, triangles, kind };
+    b.nodes.reserve(numTriangles);
+    b.leafRefs.reserve(numTriangles + numTriangles / 4);
+    b.run(std::move(refs));
+
+    BvhBuildResult out;
+    out.rootNode = 0;
+    out.nodes = std::move(b.nodes);
+    out.triangles.resize(b.leafRefs.size());
+    out.originalTriangle.resize(b.leafRefs.size());
+    for (size_t i = 0; i < b.leafRefs.size(); i++) {
+        out.triangles[i] = triangles[b.leafRefs[i].prim];
+        out.originalTriangle[i] = b.leafRefs[i].prim;
+    }
+    return out;
+}
+
+void refitBVH(std::vector<SubBVHNode>& nodes, uint32_t root, const std::vector<TriangleSceneData>& triangles, const std::vector<VertexSceneData>& vertices)
+{
+    // post-order without recursion: children always have larger indices than their parent
+    // (pairs are allocated after the parent), so a reverse index sweep visits children first.
+    (void)root;
+    for (size_t idx = nodes.size(); idx-- > 0;) {
+        SubBVHNode& n = nodes[idx];
+        if (idx == 1)
+            continue; // pad
+        AABB box;
+        if (n.triangleCount != 0) {
+            for (uint32_t t = 0; t < n.triangleCount; t++)
+                for (int k = 0; k < 3; k++)
+                    box.fit(position(vertices[triangles[n.leftChildOrFirstTriangle + t].indices[k]]));
+        } else {
+            if (n.leftChildOrFirstTriangle == 0)
+                continue; // blank node
+            box = loadBox(nodes[n.leftChildOrFirstTriangle]).merged(loadBox(nodes[n.leftChildOrFirstTriangle + 1]));
+        }
+        storeBox(n, box);
+    }
+}
+
+BvhStats checkBVH(const BvhBuildResult& bvh, const VertexSceneData* vertices, size_t numInputTriangles, bool exactLeafContainment)
+{
+    BvhStats s;
+    std::vector<uint8_t> seen(numInputTriangles, 0);
+    struct Item {
+        uint32_t node, depth;
+    };
+    std::vector<Item> stack { { bvh.rootNode, 0 } };
+    const float eps = 0.0f;
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        const SubBVHNode& n = bvh.nodes[it.node];
+        AABB box = loadBox(n);
+        s.numNodes++;
+        s.maxDepth = std::max(s.maxDepth, it.depth);
+        if (n.triangleCount != 0) {
+            s.numLeaves++;
+            s.numTriangleRefs += n.triangleCount;
+            s.maxLeafSize = std::max(s.maxLeafSize, n.triangleCount);
+            for (uint32_t t = 0; t < n.triangleCount; t++) {
+                uint32_t ti = n.leftChildOrFirstTriangle + t;
+                if (ti >= bvh.triangles.size()) {
+                    s.trianglesInsideLeaves = false;
+                    continue;
+                }
+                seen[bvh.originalTriangle[ti]] = 1;
+                AABB tb;
+                for (int k = 0; k < 3; k++)
+                    tb.fit(position(vertices[bvh.triangles[ti].indices[k]]));
+                if (exactLeafContainment) {
+                    if (!box.contains(tb))
+                        s.trianglesInsideLeaves = false;
+                } else { // spatial splits hold clipped references: the triangle must at least overlap the leaf
+                    AABB x = box.intersection(tb);
+                    if (x.min.x > x.max.x + eps || x.min.y > x.max.y + eps || x.min.z > x.max.z + eps)
+                        s.trianglesInsideLeaves = false;
+                }
+            }
+        } else {
+            uint32_t l = n.leftChildOrFirstTriangle;
+            for (uint32_t c = l; c <= l + 1; c++) {
+                if (!box.contains(loadBox(bvh.nodes[c])))
+                    s.childrenInsideParents = false;
+                stack.push_back({ c, it.depth + 1 });
+            }
+        }
+    }
+    for (uint8_t f : seen)
+        if (!f)
+            s.allTrianglesReferenced = false;
+    return s;
+}
+
+} // namespace raytracer

@@ -1,0 +1,193 @@
+// C entry points over the host-side scene library (meshes, BVH builders, scene graph, camera) so
+// that non-C++ callers -- the Python parity tests and bench.py -- can build the flattened scene
+// arrays that pt_upload_static / pt_upload_dynamic consume.  Declared in include/ptamd_host.h.
+#include "../../include/ptamd_host.h"
+#include "camera.h"
+#include "scene.h"
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+
+using namespace raytracer;
+
+namespace {
+thread_local std::string g_error;
+
+struct MeshHandle {
+    std::shared_ptr<Mesh> mesh;
+};
+struct SceneHandle {
+    Scene scene;
+    std::vector<SceneNode*> nodes; // by id
+    FlattenedScene flat;
+    bool flattened = false;
+};
+
+template <typename F>
+int guarded(F&& f)
+{
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+}
+
+extern "C" {
+
+const char* pth_last_error(void) { return g_error.c_str(); }
+
+pth_mesh* pth_mesh_create(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+    const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles, const pt_material* materials,
+    size_t numMaterials, int builder)
+{
+    MeshHandle* h = nullptr;
+    int rc = guarded([&] {
+        std::vector<Material> mats(numMaterials);
+        for (size_t i = 0; i < numMaterials; i++)
+            static_cast<pt_material&>(mats[i]) = materials[i];
+        auto m = std::make_shared<Mesh>(positions, normals, texCoords, numVertices, indices, materialIndex, numTriangles, mats, (BvhBuilder)builder);
+        h = new MeshHandle { m };
+    });
+    return rc == 0 ? (pth_mesh*)h : nullptr;
+}
+
+pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int builder)
+{
+    MeshHandle* h = nullptr;
+    int rc = guarded([&] {
+        Material m;
+        static_cast<pt_material&>(m) = *material;
+        h = new MeshHandle { Mesh::fromPLY(path, m, (BvhBuilder)builder) };
+    });
+    return rc == 0 ? (pth_mesh*)h : nullptr;
+}
+
+void pth_mesh_destroy(pth_mesh* m) { delete (MeshHandle*)m; }
+
+int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out)
+{
+    return guarded([&] {
+        const Mesh& mesh = *((const MeshHandle*)m)->mesh;
+        BvhStats s = checkBVH(mesh.getBvh(), mesh.getVertices().data(), mesh.numInputTriangles(), mesh.builder() != BvhBuilder::SpatialSplit);
+        out->num_vertices = (uint32_t)mesh.getVertices().size();
+        out->num_input_triangles = (uint32_t)mesh.numInputTriangles();
+        out->num_triangle_refs = (uint32_t)mesh.getTriangles().size();
+        out->num_nodes = (uint32_t)mesh.getBvhNodes().size();
+        out->num_leaves = s.numLeaves;
+        out->max_depth = s.maxDepth;
+        out->max_leaf_size = s.maxLeafSize;
+        out->children_inside_parents = s.childrenInsideParents;
+        out->triangles_inside_leaves = s.trianglesInsideLeaves;
+        out->all_triangles_referenced = s.allTrianglesReferenced;
+        out->reachable_triangle_refs = s.numTriangleRefs;
+        out->reachable_nodes = s.numNodes;
+    });
+}
+
+int pth_mesh_copy_bvh(const pth_mesh* m, pt_sub_bvh_node* nodes, pt_triangle* triangles, uint32_t* originalTriangle)
+{
+    return guarded([&] {
+        const Mesh& mesh = *((const MeshHandle*)m)->mesh;
+        if (nodes) std::memcpy(nodes, mesh.getBvhNodes().data(), mesh.getBvhNodes().size() * sizeof(pt_sub_bvh_node));
+        if (triangles) std::memcpy(triangles, mesh.getTriangles().data(), mesh.getTriangles().size() * sizeof(pt_triangle));
+        if (originalTriangle) std::memcpy(originalTriangle, mesh.getBvh().originalTriangle.data(), mesh.getBvh().originalTriangle.size() * sizeof(uint32_t));
+    });
+}
+
+pth_scene* pth_scene_create(void) { return (pth_scene*)new SceneHandle(); }
+void pth_scene_destroy(pth_scene* s) { delete (SceneHandle*)s; }
+
+int pth_scene_add_node(pth_scene* s, const pth_mesh* m, const float location[3], const float orientation_wxyz[4], const float scale[3], int parent)
+{
+    int id = -1;
+    int rc = guarded([&] {
+        SceneHandle& h = *(SceneHandle*)s;
+        Transform t;
+        if (location) t.location = vec3(location[0], location[1], location[2]);
+        if (orientation_wxyz) t.orientation = quat(orientation_wxyz[0], orientation_wxyz[1], orientation_wxyz[2], orientation_wxyz[3]);
+        if (scale) t.scale = vec3(scale[0], scale[1], scale[2]);
+        SceneNode* p = nullptr;
+        if (parent >= 0) {
+            if ((size_t)parent >= h.nodes.size())
+                throw std::invalid_argument("pth_scene_add_node: bad parent id");
+            p = h.nodes[parent];
+        }
+        SceneNode& n = h.scene.addNode(((const MeshHandle*)m)->mesh, t, p);
+        id = (int)h.nodes.size();
+        h.nodes.push_back(&n);
+        h.flattened = false;
+    });
+    return rc == 0 ? id : -1;
+}
+
+int pth_scene_set_transform(pth_scene* s, int node, const float location[3], const float orientation_wxyz[4], const float scale[3])
+{
+    return guarded([&] {
+        SceneHandle& h = *(SceneHandle*)s;
+        if (node < 0 || (size_t)node >= h.nodes.size())
+            throw std::invalid_argument("pth_scene_set_transform: bad node id");
+        Transform& t = h.nodes[node]->transform;
+        if (location) t.location = vec3(location[0], location[1], location[2]);
+        if (orientation_wxyz) t.orientation = quat(orientation_wxyz[0], orientation_wxyz[1], orientation_wxyz[2], orientation_wxyz[3]);
+        if (scale) t.scale = vec3(scale[0], scale[1], scale[2]);
+        h.flattened = false;
+    });
+}
+
+int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts)
+{
+    return guarded([&] {
+        SceneHandle& h = *(SceneHandle*)s;
+        h.flat = flattenScene(h.scene);
+        h.flattened = true;
+        counts->num_vertices = (uint32_t)h.flat.vertices.size();
+        counts->num_triangles = (uint32_t)h.flat.triangles.size();
+        counts->num_materials = (uint32_t)h.flat.materials.size();
+        counts->num_sub_nodes = (uint32_t)h.flat.subBvhNodes.size();
+        counts->num_lights = (uint32_t)h.flat.emissiveTriangles.size();
+        counts->num_top_nodes = (uint32_t)h.flat.topBvhNodes.size();
+        counts->top_root = h.flat.topBvhRoot;
+        counts->num_instances = (uint32_t)h.scene.numInstances();
+    });
+}
+
+int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top)
+{
+    return guarded([&] {
+        const SceneHandle& h = *(const SceneHandle*)s;
+        if (!h.flattened)
+            throw std::logic_error("pth_scene_copy: call pth_scene_flatten first");
+        auto cp = [](auto* dst, const auto& src) {
+            if (dst && !src.empty())
+                std::memcpy(dst, src.data(), src.size() * sizeof(src[0]));
+        };
+        cp(v, h.flat.vertices);
+        cp(t, h.flat.triangles);
+        cp(m, h.flat.materials);
+        cp(n, h.flat.subBvhNodes);
+        cp(l, h.flat.emissiveTriangles);
+        cp(top, h.flat.topBvhNodes);
+    });
+}
+
+int pth_camera_data(const pth_camera_params* p, pt_camera* out)
+{
+    return guarded([&] {
+        Transform t(vec3(p->location[0], p->location[1], p->location[2]),
+            quat(p->orientation_wxyz[0], p->orientation_wxyz[1], p->orientation_wxyz[2], p->orientation_wxyz[3]));
+        Camera cam(t, p->horizontal_fov_deg, p->aspect_ratio, p->focal_distance);
+        if (p->focal_length_mm > 0) cam.m_focalLengthMm = p->focal_length_mm;
+        if (p->aperture_fstops > 0) cam.m_aperture = p->aperture_fstops;
+        if (p->shutter_time > 0) cam.m_shutterTime = p->shutter_time;
+        if (p->iso > 0) cam.m_iso = p->iso;
+        cam.m_thinLens = p->thin_lens != 0;
+        *out = cam.get_camera_data();
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,145 @@
+#include "mesh.h"
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace raytracer {
+
+Mesh::Mesh(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+    const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles,
+    const std::vector<Material>& materials, BvhBuilder builder)
+    : m_materials(materials), m_builder(builder)
+{
+    if (materials.empty())
+        throw std::invalid_argument("Mesh: at least one material is required");
+    m_vertices.resize(numVertices);
+    std::memset(m_vertices.data(), 0, numVertices * sizeof(VertexSceneData));
+    for (size_t i = 0; i < numVertices; i++) {
+        for (int k = 0; k < 3; k++)
+            m_vertices[i].vertex[k] = positions[3 * i + k];
+        m_vertices[i].vertex[3] = 1.0f; // homogeneous w, as the reference's glm::vec4 positions (mesh.cpp:78)
+        if (normals)
+            for (int k = 0; k < 3; k++)
+                m_vertices[i].normal[k] = normals[3 * i + k];
+        if (texCoords) {
+            m_vertices[i].texCoord[0] = texCoords[2 * i];
+            m_vertices[i].texCoord[1] = texCoords[2 * i + 1];
+        }
+        m_bounds.fit(vec3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]));
+    }
+    m_inputTriangles.resize(numTriangles);
+    for (size_t t = 0; t < numTriangles; t++) {
+        for (int k = 0; k < 3; k++)
+            m_inputTriangles[t].indices[k] = indices[3 * t + k];
+        uint32_t mi = materialIndex ? materialIndex[t] : 0;
+        if (mi >= materials.size())
+            throw std::invalid_argument("Mesh: material index out of range");
+        m_inputTriangles[t].materialIndex = mi;
+    }
+    if (!normals) { // area-weighted smooth normals (cross product length = 2*area)
+        std::vector<vec3> acc(numVertices);
+        for (const auto& tri : m_inputTriangles) {
+            auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
+            vec3 n = cross(P(1) - P(0), P(2) - P(0));
+            for (int k = 0; k < 3; k++)
+                acc[tri.indices[k]] += n;
+        }
+        for (size_t i = 0; i < numVertices; i++) {
+            float len = length(acc[i]);
+            vec3 n = len > 0.0f ? acc[i] / len : vec3(0, 1, 0);
+            m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
+        }
+    }
+    m_bvh = buildBVH(m_vertices.data(), m_vertices.size(), m_inputTriangles.data(), m_inputTriangles.size(), builder);
+    // emissive triangles are listed once per INPUT triangle (spatial splits may duplicate references)
+    std::vector<uint8_t> listed(numTriangles, 0);
+    for (size_t i = 0; i < m_bvh.triangles.size(); i++) {
+        uint32_t orig = m_bvh.originalTriangle[i];
+        if (m_materials[m_bvh.triangles[i].materialIndex].type == PT_MAT_EMISSIVE && !listed[orig]) {
+            listed[orig] = 1;
+            m_emissive.push_back((uint32_t)i);
+        }
+    }
+}
+
+std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& material, BvhBuilder builder)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in)
+        throw std::runtime_error("cannot open " + path);
+    std::string line;
+    size_t nv = 0, nf = 0;
+    bool ascii = true;
+    int vertexProps = 0;
+    bool inVertex = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r')
+            line.pop_back();
+        std::istringstream ls(line);
+        std::string tok;
+        ls >> tok;
+        if (tok == "format") {
+            ls >> tok;
+            ascii = (tok == "ascii");
+            if (!ascii && tok != "binary_little_endian")
+                throw std::runtime_error("PLY: unsupported format " + tok);
+        } else if (tok == "element") {
+            std::string what;
+            ls >> what;
+            inVertex = (what == "vertex");
+            if (what == "vertex") ls >> nv;
+            if (what == "face") ls >> nf;
+        } else if (tok == "property" && inVertex) {
+            vertexProps++;
+        } else if (tok == "end_header") {
+            break;
+        }
+    }
+    if (vertexProps < 3)
+        throw std::runtime_error("PLY: vertices need x y z");
+    std::vector<float> pos(nv * 3);
+    std::vector<uint32_t> idx;
+    idx.reserve(nf * 3);
+    if (ascii) {
+        for (size_t i = 0; i < nv; i++) {
+            std::getline(in, line);
+            std::istringstream ls(line);
+            ls >> pos[3 * i] >> pos[3 * i + 1] >> pos[3 * i + 2];
+        }
+        for (size_t f = 0; f < nf; f++) {
+            std::getline(in, line);
+            std::istringstream ls(line);
+            int n;
+            ls >> n;
+            std::vector<uint32_t> poly(n);
+            for (int k = 0; k < n; k++) ls >> poly[k];
+            for (int k = 1; k + 1 < n; k++) { // fan-triangulate
+                idx.push_back(poly[0]);
+                idx.push_back(poly[k]);
+                idx.push_back(poly[k + 1]);
+            }
+        }
+    } else { // all vertex properties assumed float32, faces uchar count + int32 indices
+        std::vector<float> row(vertexProps);
+        for (size_t i = 0; i < nv; i++) {
+            in.read((char*)row.data(), vertexProps * sizeof(float));
+            pos[3 * i] = row[0], pos[3 * i + 1] = row[1], pos[3 * i + 2] = row[2];
+        }
+        for (size_t f = 0; f < nf; f++) {
+            uint8_t n;
+            in.read((char*)&n, 1);
+            std::vector<int32_t> poly(n);
+            in.read((char*)poly.data(), n * sizeof(int32_t));
+            for (int k = 1; k + 1 < n; k++) {
+                idx.push_back(poly[0]);
+                idx.push_back(poly[k]);
+                idx.push_back(poly[k + 1]);
+            }
+        }
+    }
+    return std::make_shared<Mesh>(pos.data(), nullptr, nullptr, nv, idx.data(), nullptr, idx.size() / 3, std::vector<Material> { material }, builder);
+}
+
+} // namespace raytracer

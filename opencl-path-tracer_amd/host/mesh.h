@@ -1,0 +1,71 @@
+// Mesh = triangle soup + materials + bottom-level BVH.  Interface of the reference's IMesh
+// (src/model/imesh.h:9-26) and Mesh (src/model/mesh.h); Assimp import is replaced by construction
+// from arrays and a small ASCII/binary PLY reader (asset I/O is outside the hot path).
+#pragma once
+#include "aabb.h"
+#include "bvh_build.h"
+#include "material.h"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace raytracer {
+
+class IMesh {
+public:
+    virtual ~IMesh() = default;
+    virtual const std::vector<VertexSceneData>& getVertices() const = 0;
+    virtual const std::vector<TriangleSceneData>& getTriangles() const = 0; // leaf order
+    virtual const std::vector<Material>& getMaterials() const = 0;
+    virtual const std::vector<SubBVHNode>& getBvhNodes() const = 0;
+    virtual const std::vector<uint32_t>& getEmissiveTriangles() const = 0;
+    virtual AABB getBounds() const = 0;
+    virtual bool isDynamic() const = 0;
+    virtual uint32_t maxNumVertices() const = 0;
+    virtual uint32_t maxNumTriangles() const = 0;
+    virtual uint32_t maxNumMaterials() const = 0;
+    virtual uint32_t maxNumBvhNodes() const = 0;
+    virtual void buildBvh() = 0;
+    virtual uint32_t getBvhRootNode() const = 0;
+};
+
+class Mesh : public IMesh {
+public:
+    // positions: 3*numVertices floats; normals (3*nv) and texCoords (2*nv) may be null -- missing
+    // normals are generated area-weighted per vertex; indices: 3*numTriangles; materialIndex per
+    // triangle (null = 0).
+    Mesh(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+        const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles,
+        const std::vector<Material>& materials, BvhBuilder builder = BvhBuilder::SpatialSplit);
+
+    static std::shared_ptr<Mesh> fromPLY(const std::string& path, const Material& material, BvhBuilder builder = BvhBuilder::SpatialSplit);
+
+    const std::vector<VertexSceneData>& getVertices() const override { return m_vertices; }
+    const std::vector<TriangleSceneData>& getTriangles() const override { return m_bvh.triangles; }
+    const std::vector<Material>& getMaterials() const override { return m_materials; }
+    const std::vector<SubBVHNode>& getBvhNodes() const override { return m_bvh.nodes; }
+    const std::vector<uint32_t>& getEmissiveTriangles() const override { return m_emissive; }
+    AABB getBounds() const override { return m_bounds; }
+    bool isDynamic() const override { return false; }
+    uint32_t maxNumVertices() const override { return (uint32_t)m_vertices.size(); }
+    uint32_t maxNumTriangles() const override { return (uint32_t)m_bvh.triangles.size(); }
+    uint32_t maxNumMaterials() const override { return (uint32_t)m_materials.size(); }
+    uint32_t maxNumBvhNodes() const override { return (uint32_t)m_bvh.nodes.size(); }
+    void buildBvh() override {}
+    uint32_t getBvhRootNode() const override { return m_bvh.rootNode; }
+
+    const BvhBuildResult& getBvh() const { return m_bvh; }
+    size_t numInputTriangles() const { return m_inputTriangles.size(); }
+    BvhBuilder builder() const { return m_builder; }
+
+private:
+    std::vector<VertexSceneData> m_vertices;
+    std::vector<TriangleSceneData> m_inputTriangles;
+    std::vector<Material> m_materials;
+    std::vector<uint32_t> m_emissive;
+    BvhBuildResult m_bvh;
+    AABB m_bounds;
+    BvhBuilder m_builder;
+};
+
+} // namespace raytracer

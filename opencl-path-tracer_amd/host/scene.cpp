@@ -1,0 +1,178 @@
+#include "scene.h"
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace raytracer {
+
+SceneNode& Scene::addNode(const std::shared_ptr<IMesh>& mesh, const Transform& transform, SceneNode* parent)
+{
+    if (!parent)
+        parent = &m_root;
+    uint32_t id;
+    auto it = m_meshIds.find(mesh.get());
+    if (it != m_meshIds.end()) {
+        id = it->second;
+    } else {
+        id = (uint32_t)m_meshes.size();
+        m_meshes.push_back({ mesh, 0 });
+        m_meshIds.emplace(mesh.get(), id);
+    }
+    auto node = std::make_unique<SceneNode>();
+    node->parent = parent;
+    node->bounds = mesh->getBounds();
+    node->transform = transform;
+    node->meshID = id;
+    node->subBvhRootID = mesh->getBvhRootNode();
+    parent->bounds.fit(mesh->getBounds());
+    parent->children.push_back(std::move(node));
+    m_numInstances++;
+    return *parent->children.back();
+}
+
+namespace {
+    void setBox(TopBVHNode& n, const AABB& b)
+    {
+        n.min[0] = b.min.x, n.min[1] = b.min.y, n.min[2] = b.min.z, n.min[3] = 0;
+        n.max[0] = b.max.x, n.max[1] = b.max.y, n.max[2] = b.max.z, n.max[3] = 0;
+    }
+    AABB getBox(const TopBVHNode& n) { return { { n.min[0], n.min[1], n.min[2] }, { n.max[0], n.max[1], n.max[2] } }; }
+
+    AABB transformedBounds(const AABB& b, const mat4& m)
+    {
+        AABB r;
+        for (int corner = 0; corner < 8; corner++) {
+            vec3 p(corner & 1 ? b.max.x : b.min.x, corner & 2 ? b.max.y : b.min.y, corner & 4 ? b.max.z : b.min.z);
+            r.fit((m * vec4(p, 1.0f)).xyz());
+        }
+        return r;
+    }
+
+    template <typename F>
+    void walk(const SceneNode& node, const mat4& parentWorld, F&& visit)
+    {
+        mat4 world = parentWorld * node.transform.matrix();
+        if (node.meshID)
+            visit(node, world);
+        for (const auto& c : node.children)
+            walk(*c, world, visit);
+    }
+}
+
+TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>& meshBvhOffsets)
+{
+    TopBvhBuildResult out;
+    std::vector<uint32_t> active; // cluster roots still to be merged
+    walk(root, mat4(), [&](const SceneNode& n, const mat4& world) {
+        TopBVHNode leaf;
+        std::memset(&leaf, 0, sizeof(leaf));
+        setBox(leaf, transformedBounds(n.bounds, world));
+        mat4 inv = inverse(world);
+        std::memcpy(leaf.invTransform, inv.data(), sizeof(leaf.invTransform));
+        leaf.a = *n.subBvhRootID + meshBvhOffsets[*n.meshID];
+        leaf.b = 0;
+        leaf.isLeaf = 1;
+        active.push_back((uint32_t)out.nodes.size());
+        out.nodes.push_back(leaf);
+    });
+    if (active.empty())
+        throw std::invalid_argument("buildTopBVH: scene has no mesh instances");
+
+    auto mergedArea = [&](uint32_t x, uint32_t y) { return getBox(out.nodes[x]).merged(getBox(out.nodes[y])).surfaceArea(); };
+    auto bestPartner = [&](uint32_t x) {
+        uint32_t best = x;
+        float bestArea = std::numeric_limits<float>::max();
+        for (uint32_t y : active) {
+            if (y == x)
+                continue;
+            float a = mergedArea(x, y);
+            if (a < bestArea) {
+                bestArea = a;
+                best = y;
+            }
+        }
+        return best;
+    };
+    // mutual-nearest-neighbour chain: follow best partners until A's partner's partner is A
+    uint32_t a = active.back();
+    while (active.size() > 1) {
+        uint32_t b = bestPartner(a);
+        uint32_t c = bestPartner(b);
+        if (c != a) {
+            a = b;
+            continue;
+        }
+        TopBVHNode inner;
+        std::memset(&inner, 0, sizeof(inner));
+        setBox(inner, getBox(out.nodes[a]).merged(getBox(out.nodes[b])));
+        mat4 identity;
+        std::memcpy(inner.invTransform, identity.data(), sizeof(inner.invTransform));
+        inner.a = a;
+        inner.b = b;
+        inner.isLeaf = 0;
+        active.erase(std::remove_if(active.begin(), active.end(), [&](uint32_t v) { return v == a || v == b; }), active.end());
+        a = (uint32_t)out.nodes.size();
+        out.nodes.push_back(inner);
+        active.push_back(a);
+    }
+    out.rootNode = (uint32_t)out.nodes.size() - 1;
+    return out;
+}
+
+void flattenStatic(Scene& scene, FlattenedScene& out)
+{
+    out.vertices.clear();
+    out.triangles.clear();
+    out.materials.clear();
+    out.subBvhNodes.clear();
+    for (MeshBvhPair& pair : scene.getMeshes()) {
+        const IMesh& mesh = *pair.meshPtr;
+        const uint32_t v0 = (uint32_t)out.vertices.size();
+        const uint32_t m0 = (uint32_t)out.materials.size();
+        const uint32_t t0 = (uint32_t)out.triangles.size();
+        const uint32_t n0 = (uint32_t)out.subBvhNodes.size();
+        out.vertices.insert(out.vertices.end(), mesh.getVertices().begin(), mesh.getVertices().end());
+        for (const Material& m : mesh.getMaterials())
+            out.materials.push_back(m);
+        for (TriangleSceneData t : mesh.getTriangles()) {
+            t.indices[0] += v0, t.indices[1] += v0, t.indices[2] += v0;
+            t.materialIndex += m0;
+            out.triangles.push_back(t);
+        }
+        for (SubBVHNode n : mesh.getBvhNodes()) {
+            n.leftChildOrFirstTriangle += (n.triangleCount > 0) ? t0 : n0;
+            out.subBvhNodes.push_back(n);
+        }
+        pair.bvhIndexOffset = n0;
+    }
+}
+
+void flattenDynamic(const Scene& scene, FlattenedScene& out)
+{
+    out.emissiveTriangles.clear();
+    walk(scene.getRootNode(), mat4(), [&](const SceneNode& n, const mat4& world) {
+        const IMesh& mesh = *scene.getMeshes()[*n.meshID].meshPtr;
+        for (uint32_t ti : mesh.getEmissiveTriangles()) {
+            if (out.emissiveTriangles.size() >= kMaxNumLights)
+                return;
+            const TriangleSceneData& tri = mesh.getTriangles()[ti];
+            pt_emissive_triangle e;
+            std::memset(&e, 0, sizeof(e));
+            for (int k = 0; k < 3; k++) {
+                const float* p = mesh.getVertices()[tri.indices[k]].vertex;
+                vec4 w = world * vec4(p[0], p[1], p[2], 1.0f);
+                e.vertices[k][0] = w.x, e.vertices[k][1] = w.y, e.vertices[k][2] = w.z, e.vertices[k][3] = w.w;
+            }
+            e.material = mesh.getMaterials()[tri.materialIndex];
+            out.emissiveTriangles.push_back(e);
+        }
+    });
+    std::vector<uint32_t> offsets;
+    for (const MeshBvhPair& p : scene.getMeshes())
+        offsets.push_back(p.bvhIndexOffset);
+    TopBvhBuildResult top = buildTopBVH(scene.getRootNode(), offsets);
+    out.topBvhNodes = std::move(top.nodes);
+    out.topBvhRoot = top.rootNode;
+}
+
+} // namespace raytracer

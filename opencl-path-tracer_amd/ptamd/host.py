@@ -1,0 +1,231 @@
+"""ctypes binding of the host-side scene library (include/ptamd_host.h): meshes + BVH builders,
+scene graph with instancing, flattening into the device arrays, camera derivation."""
+import ctypes as C
+import os
+import numpy as np
+from . import layout as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "..", "host", "libptamd_host.so")
+
+BVH_BINNED_SAH, BVH_BINNED_FAST, BVH_SPATIAL_SPLIT = 0, 1, 2
+
+
+class MeshStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "num_vertices", "num_input_triangles", "num_triangle_refs", "num_nodes", "num_leaves", "max_depth",
+        "max_leaf_size", "children_inside_parents", "triangles_inside_leaves", "all_triangles_referenced",
+        "reachable_triangle_refs", "reachable_nodes")]
+
+
+class SceneCounts(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "num_vertices", "num_triangles", "num_materials", "num_sub_nodes", "num_lights", "num_top_nodes",
+        "top_root", "num_instances")]
+
+
+class CameraParams(C.Structure):
+    _fields_ = [("location", C.c_float * 3), ("orientation_wxyz", C.c_float * 4), ("horizontal_fov_deg", C.c_float),
+                ("aspect_ratio", C.c_float), ("focal_distance", C.c_float), ("focal_length_mm", C.c_float),
+                ("aperture_fstops", C.c_float), ("shutter_time", C.c_float), ("iso", C.c_float), ("thin_lens", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} missing: run __graft_entry__.build() first")
+        _lib = C.CDLL(HOST_LIB_PATH)
+        _lib.pth_last_error.restype = C.c_char_p
+        _lib.pth_mesh_create.restype = C.c_void_p
+        _lib.pth_mesh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        _lib.pth_mesh_from_ply.restype = C.c_void_p
+        _lib.pth_mesh_from_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+        _lib.pth_mesh_destroy.argtypes = [C.c_void_p]
+        _lib.pth_mesh_info.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
+        _lib.pth_mesh_copy_bvh.argtypes = [C.c_void_p] * 4
+        _lib.pth_scene_create.restype = C.c_void_p
+        _lib.pth_scene_destroy.argtypes = [C.c_void_p]
+        _lib.pth_scene_add_node.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.pth_scene_set_transform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.pth_scene_flatten.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
+        _lib.pth_scene_copy.argtypes = [C.c_void_p] * 7
+        _lib.pth_camera_data.argtypes = [C.POINTER(CameraParams), C.c_void_p]
+    return _lib
+
+
+def _err(what):
+    raise RuntimeError(f"{what}: {lib().pth_last_error().decode()}")
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Mesh:
+    def __init__(self, positions, indices, materials, material_index=None, normals=None, tex_coords=None,
+                 builder=BVH_SPATIAL_SPLIT, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+        else:
+            pos = _f32(positions, (-1, 3))
+            nrm = _f32(normals, (-1, 3))
+            uv = _f32(tex_coords, (-1, 2))
+            idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+            mi = None if material_index is None else np.ascontiguousarray(material_index, dtype=np.uint32)
+            mats = np.ascontiguousarray(np.atleast_1d(np.asarray(materials, dtype=L.MATERIAL)))
+            self._h = lib().pth_mesh_create(_ptr(pos), _ptr(nrm), _ptr(uv), len(pos), _ptr(idx), _ptr(mi), len(idx),
+                                            _ptr(mats), len(mats), builder)
+            if not self._h:
+                _err("pth_mesh_create")
+        self.builder = builder
+
+    @staticmethod
+    def from_ply(path, material, builder=BVH_SPATIAL_SPLIT):
+        mat = np.ascontiguousarray(np.asarray(material, dtype=L.MATERIAL).reshape(1))
+        h = lib().pth_mesh_from_ply(str(path).encode(), _ptr(mat), builder)
+        if not h:
+            _err("pth_mesh_from_ply")
+        return Mesh(None, None, None, builder=builder, _handle=h)
+
+    def stats(self):
+        s = MeshStats()
+        if lib().pth_mesh_info(self._h, C.byref(s)):
+            _err("pth_mesh_info")
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def bvh(self):
+        s = self.stats()
+        nodes = np.zeros(s["num_nodes"], L.SUB_BVH_NODE)
+        tris = np.zeros(s["num_triangle_refs"], L.TRIANGLE)
+        orig = np.zeros(s["num_triangle_refs"], np.uint32)
+        if lib().pth_mesh_copy_bvh(self._h, _ptr(nodes), _ptr(tris), _ptr(orig)):
+            _err("pth_mesh_copy_bvh")
+        return nodes, tris, orig
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.pth_mesh_destroy(self._h)
+            self._h = None
+
+
+class FlatScene:
+    """The flattened device arrays (reference layouts) + counts."""
+
+    def __init__(self, vertices, triangles, materials, sub_nodes, lights, top_nodes, top_root, num_instances):
+        self.vertices, self.triangles, self.materials = vertices, triangles, materials
+        self.sub_nodes, self.lights, self.top_nodes = sub_nodes, lights, top_nodes
+        self.top_root, self.num_instances = int(top_root), int(num_instances)
+
+    @property
+    def instanced_triangles(self):
+        """Triangle references reachable through all instances (the '~1M-tri' figure)."""
+        total = 0
+        leaf = self.top_nodes[self.top_nodes["isLeaf"] != 0]
+        cache = {}
+        for root in leaf["a"]:
+            root = int(root)
+            if root not in cache:
+                n, stack = 0, [root]
+                while stack:
+                    nd = self.sub_nodes[stack.pop()]
+                    if nd["count"]:
+                        n += int(nd["count"])
+                    else:
+                        stack += [int(nd["left"]), int(nd["left"]) + 1]
+                cache[root] = n
+            total += cache[root]
+        return total
+
+
+class Scene:
+    def __init__(self):
+        self._h = lib().pth_scene_create()
+        self._meshes = []  # keep alive
+
+    def add_node(self, mesh, location=(0, 0, 0), orientation_wxyz=(1, 0, 0, 0), scale=(1, 1, 1), parent=-1):
+        loc, q, s = _f32(location), _f32(orientation_wxyz), _f32(scale)
+        if s.size == 1:
+            s = np.repeat(s, 3)
+        nid = lib().pth_scene_add_node(self._h, mesh._h, _ptr(loc), _ptr(q), _ptr(s), parent)
+        if nid < 0:
+            _err("pth_scene_add_node")
+        self._meshes.append(mesh)
+        return nid
+
+    def set_transform(self, node, location=None, orientation_wxyz=None, scale=None):
+        loc, q, s = _f32(location), _f32(orientation_wxyz), _f32(scale)
+        if lib().pth_scene_set_transform(self._h, node, _ptr(loc), _ptr(q), _ptr(s)):
+            _err("pth_scene_set_transform")
+
+    def flatten(self):
+        c = SceneCounts()
+        if lib().pth_scene_flatten(self._h, C.byref(c)):
+            _err("pth_scene_flatten")
+        v = np.zeros(c.num_vertices, L.VERTEX)
+        t = np.zeros(c.num_triangles, L.TRIANGLE)
+        m = np.zeros(c.num_materials, L.MATERIAL)
+        n = np.zeros(c.num_sub_nodes, L.SUB_BVH_NODE)
+        l = np.zeros(c.num_lights, L.EMISSIVE_TRIANGLE)
+        top = np.zeros(c.num_top_nodes, L.TOP_BVH_NODE)
+        if lib().pth_scene_copy(self._h, _ptr(v), _ptr(t), _ptr(m), _ptr(n), _ptr(l), _ptr(top)):
+            _err("pth_scene_copy")
+        return FlatScene(v, t, m, n, l, top, c.top_root, c.num_instances)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.pth_scene_destroy(self._h)
+            self._h = None
+
+
+def camera_data(location, orientation_wxyz, horizontal_fov_deg, aspect_ratio, focal_distance=1.0, thin_lens=False,
+                focal_length_mm=0.0, aperture_fstops=0.0, shutter_time=0.0, iso=0.0):
+    p = CameraParams()
+    p.location[:] = [float(x) for x in location]
+    p.orientation_wxyz[:] = [float(x) for x in orientation_wxyz]
+    p.horizontal_fov_deg, p.aspect_ratio, p.focal_distance = horizontal_fov_deg, aspect_ratio, focal_distance
+    p.focal_length_mm, p.aperture_fstops, p.shutter_time, p.iso = focal_length_mm, aperture_fstops, shutter_time, iso
+    p.thin_lens = int(bool(thin_lens))
+    out = np.zeros((), L.CAMERA)
+    if lib().pth_camera_data(C.byref(p), out.ctypes.data_as(C.c_void_p)):
+        _err("pth_camera_data")
+    return out
+
+
+def look_at_quat(eye, target, up=(0, 1, 0)):
+    """Orientation (w,x,y,z) whose local +z points from eye to target and local +y is 'up'-ish.
+    The reference camera looks down +z with screen v pointing down (src/camera.cpp:52-53)."""
+    eye, target, up = (np.asarray(a, np.float64) for a in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(up, f)
+    r /= np.linalg.norm(r)
+    u = np.cross(f, r)
+    m = np.stack([r, u, f], axis=1)  # columns = local x, y, z in world
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        q = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        q = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+    else:
+        s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+        q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+    return np.asarray(q, np.float32)
