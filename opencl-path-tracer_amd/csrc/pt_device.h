@@ -1,0 +1,144 @@
+// Device-side data layout of the gfx950 ray-queue path (all resident in HBM; see DESIGN.md "HBM layout").
+//
+// Queues are structure-of-arrays at float4 granularity: every field group is its own array of
+// 16-byte elements, so a wave reads/writes 64 x 16 B = 1 KiB contiguous per instruction (the widest
+// coalesced access on CDNA4) and a kernel only touches the groups it needs.  This replaces the
+// reference's 80-byte AoS RayData (assets/cl/shading.cl:16-29) and the pointer-carrying 32-byte
+// ShadingData (assets/cl/kernel_data.cl:26-33).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+// ---- geometry -------------------------------------------------------------------------------
+// One bottom-level BVH *pair node* (64 B): the boxes of BOTH children of a reference inner node
+// (SubBvhNode, assets/cl/bvh.cl:5-16) interleaved per axis + the two child references, so one
+// traversal step is one 64-byte fetch instead of the reference's two dependent 48-byte fetches
+// (scene.cl:199-200).
+struct PairNode {
+    float4 bx; // lmin.x, lmax.x, rmin.x, rmax.x
+    float4 by;
+    float4 bz;
+    uint32_t left, right; // child references (see makeRef)
+    uint32_t _pad0, _pad1;
+};
+
+// child reference: count (5 bits, 0 = inner) | index (27 bits).  inner: index of a PairNode;
+// leaf: first triangle.  Leaves larger than 31 are split at upload.
+constexpr uint32_t kRefIndexBits = 27;
+constexpr uint32_t kRefIndexMask = (1u << kRefIndexBits) - 1u;
+constexpr uint32_t kMaxLeafTris = 31;
+constexpr uint32_t kRefNone = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t makeRef(uint32_t index, uint32_t count) { return (count << kRefIndexBits) | index; }
+__host__ __device__ inline uint32_t refIndex(uint32_t r) { return r & kRefIndexMask; }
+__host__ __device__ inline uint32_t refCount(uint32_t r) { return r >> kRefIndexBits; }
+
+// Triangle for intersection (48 B): v0 and the two edges the reference recomputes per test
+// (shapes.cl:37-38) -- 36 useful bytes instead of a 16 B index record + 3 x 48 B vertices.
+struct TriIsect {
+    float4 a; // v0.xyz, e1.x
+    float4 b; // e1.yz, e2.xy
+    float4 c; // e2.z, -, -, -
+};
+
+// Triangle for shading (64 B): vertex indices + material, the same v0/e1/e2 are re-read from TriIsect.
+struct TriShade {
+    uint32_t i0, i1, i2, material;
+};
+struct VertexShade { // 32 B
+    float4 n_u; // normal.xyz, texCoord.x
+    float4 v_pad; // texCoord.y
+};
+
+// top-level node (32 B) -- TopBvhNode (bvh.cl:18-34) without the matrix
+struct TopNode {
+    float4 lo; // min.xyz, bits(a): left child | instance index for a leaf
+    float4 hi; // max.xyz, bits(b): right child | 0xFFFFFFFF for a leaf
+};
+// instance (64 B): rows of the 3x4 inverse world transform + root reference of the mesh BVH
+struct Instance {
+    float4 r0, r1, r2; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major matrix
+    uint32_t rootRef; // makeRef
+    uint32_t topNode; // index of the top-level leaf (reported as `inst` in hit records)
+    uint32_t _p0, _p1;
+};
+
+struct Material { // the reference's 48-byte record, read as 3 x float4
+    float4 colour; // diffuse / base|reflectance / absorption / emissive
+    float4 params; // bits: x = textureId | smoothness | iorBasic ; y = f0NonMetal | iorRough ; z = metallic byte
+    float4 typeAndPad; // bits x = type
+};
+
+struct Light { // EmissiveTriangle (light.cl:5-9) pre-digested: 80 B
+    float4 v0, v1, v2; // world space; v0.w = area (Heron), v1.w.. unused
+    float4 normal; // normalize(cross(v1-v0, v2-v0))
+    float4 colour;
+};
+
+struct Texture {
+    const float4* texels; // [layer][y][x]
+    int32_t width, height, layers, _pad;
+};
+
+struct SceneDev {
+    const PairNode* nodes;
+    const TriIsect* tris;
+    const TriShade* triShade;
+    const VertexShade* verts;
+    const Material* materials;
+    const TopNode* top;
+    const Instance* instances;
+    const Light* lights;
+    Texture materialTex;
+    Texture sky;
+    uint32_t numLights;
+    uint32_t topRoot;
+    uint32_t numTriangles;
+    uint32_t _pad;
+};
+
+// ---- queues ---------------------------------------------------------------------------------
+struct RayQueue { // extension rays + path state, capacity entries each
+    float4* o; // origin.xyz, bits(pixel)
+    float4* d; // direction.xyz, bits(flags | bounce << 8)
+    float4* thr; // throughput rgb
+};
+struct HitQueue {
+    float4* h; // t, u, v, bits(prim)   (t = +inf: miss)
+    int32_t* inst; // instance index, -1 on miss
+};
+struct ShadowQueue {
+    float4* o; // origin.xyz, ray length
+    float4* d; // direction.xyz, bits(pixel)
+    float4* c; // contribution rgb, bits(flags): parity mode keeps finished entries
+};
+
+enum : uint32_t { FLAG_FINISHED = 1, FLAG_LASTSPECULAR = 2 }; // shading.cl:11-14
+
+struct CameraDev { // Camera, camera.cl:7-26
+    float4 eye, screen, u, v, uN, vN;
+    float focalDistance, apertureRadius, relativeAperture, shutterTime, ISO;
+    uint32_t thinLens;
+};
+
+// per-sample control block in device memory: queue counts per pass and work cursors of the
+// persistent kernels.  Indexed by pass so that no kernel ever resets a word another kernel of the
+// same sample still reads (the reference needs a dedicated updateKernelData launch for that,
+// kernel.cl:303-317).
+constexpr int kMaxPasses = 16;
+struct Control {
+    uint32_t extCount[kMaxPasses + 1]; // rays in the extension queue at pass p
+    uint32_t shadowCount[kMaxPasses + 1];
+    uint32_t extCursor[kMaxPasses + 1]; // persistent-kernel fetch cursors
+    uint32_t shadowCursor[kMaxPasses + 1];
+    uint32_t shadeHits[kMaxPasses + 1];
+    uint32_t deposits;
+    uint32_t generated;
+    uint32_t _pad[2];
+};
+struct Totals {
+    unsigned long long raysExtension, raysShadow, raysGenerated, shadeHits, deposits;
+};
+
+} // namespace ptd

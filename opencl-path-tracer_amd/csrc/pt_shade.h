@@ -1,0 +1,642 @@
+// gen_camera_rays, shade (NEE + importance sampling + Russian roulette) and resolve kernels.
+//
+// Semantics follow the reference's generatePrimaryRays (assets/cl/kernel.cl:24-84, camera.cl:28-77),
+// shade (kernel.cl:190-301) with neeIsShading (shading.cl:356-623) and accumulate
+// (accumulate.cl:6-34); citations on each block.  CDNA4 specifics: float4-SoA queue records,
+// wave-aggregated compaction (one atomicAdd per wave per output queue, ranks from __ballot +
+// popcount) with separate live-ray and shadow-ray counters, textures sampled from plain buffers
+// (CDNA has no texture units), zero-state counter PRNG.
+#pragma once
+#include "pt_math.h"
+
+namespace ptd {
+
+constexpr float kPI = 3.14159265359f; // shapes.cl:5
+constexpr float kINVPI = 0.31830988618f; // shading_helper.cl:9
+constexpr float kEPS = 0.0001f; // shading_helper.cl:15
+constexpr float kMaxSmoothness = 0.94f; // shading.cl:9
+constexpr float kAirIor = 1.000277f; // scene.cl:46
+enum : int { MAT_DIFFUSE = 0, MAT_PBR = 1, MAT_REFRACTIVE = 2, MAT_BASIC_REFRACTIVE = 3, MAT_EMISSIVE = 4 };
+
+// ---- texture fetch: NORMALIZED_COORDS | ADDRESS_REPEAT | FILTER_LINEAR on a 2D array ----------
+// (sampler of shading_helper.cl:19-22 / skydome.cl:4-7; OpenCL 1.2 s8.2 linear filter, s8.3 repeat)
+__device__ inline float4 sampleLinearRepeat(const Texture& tex, float s, float t, float layerCoord)
+{
+    const int w = tex.width, h = tex.height;
+    const float u = (s - floorf(s)) * (float)w;
+    const float v = (t - floorf(t)) * (float)h;
+    int i0 = (int)floorf(u - 0.5f), j0 = (int)floorf(v - 0.5f);
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 += w;
+    if (i1 > w - 1) i1 -= w;
+    if (j0 < 0) j0 += h;
+    if (j1 > h - 1) j1 -= h;
+    const float a = (u - 0.5f) - floorf(u - 0.5f);
+    const float b = (v - 0.5f) - floorf(v - 0.5f);
+    int layer = (int)rintf(layerCoord);
+    layer = max(0, min(layer, tex.layers - 1));
+    const float4* base = tex.texels + (size_t)layer * w * h;
+    const float4 t00 = base[(size_t)j0 * w + i0], t10 = base[(size_t)j0 * w + i1];
+    const float4 t01 = base[(size_t)j1 * w + i0], t11 = base[(size_t)j1 * w + i1];
+    const float w00 = (1 - a) * (1 - b), w10 = a * (1 - b), w01 = (1 - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+        w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z, w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+
+__device__ inline V3 readSkydome(const SceneDev& sc, V3 dir) // skydome.cl:12-26
+{
+    if (!sc.sky.texels)
+        return mk(0.0f);
+    float u = 1 + atan2f(dir.x, -dir.z) / kPI;
+    const float v = acosf(dir.y) / kPI;
+    u /= 2;
+    return xyz(sampleLinearRepeat(sc.sky, u, 1.0f - v, 0.0f));
+}
+
+// ---- camera (camera.cl:28-77) -----------------------------------------------------------------
+__device__ inline void pinholeRay(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
+{
+    const V3 uStep = xyz(cam.u) / width;
+    const V3 vStep = xyz(cam.v) / height;
+    V3 sp = xyz(cam.screen) + uStep * (float)x + vStep * (float)y;
+    sp = sp + rng.u01() * uStep;
+    sp = sp + rng.u01() * vStep;
+    *o = xyz(cam.eye);
+    *d = normalize(sp - xyz(cam.eye));
+}
+__device__ inline void cameraRay(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
+{
+    if (!cam.thinLens) {
+        pinholeRay(cam, x, y, width, height, rng, o, d);
+        return;
+    }
+    const float r1 = rng.u01() * 2.0f - 1.0f; // square aperture (camera.cl:62-66)
+    const float r2 = rng.u01() * 2.0f - 1.0f;
+    const V3 offset = r1 * xyz(cam.uN) * cam.apertureRadius + r2 * xyz(cam.vN) * cam.apertureRadius;
+    V3 po, pd;
+    pinholeRay(cam, x, y, width, height, rng, &po, &pd);
+    const V3 focal = po + cam.focalDistance * pd;
+    const V3 lens = po + offset;
+    *o = lens;
+    *d = focal - lens; // not normalised, as the reference (camera.cl:71-75)
+}
+
+// ---- BSDF pieces (pbr_brdf.cl, refract.cl) -------------------------------------------------------
+__device__ inline V3 F_Schlick(V3 f0, float f90, float u) { return f0 + (mk(f90) - f0) * powf(1.0f - u, 5.0f); }
+__device__ inline float G_SmithBeckmannCorrelated(float VdotM, float NdotV, float alpha)
+{
+    const float a = 1.0f / (alpha * tanf(acosf(NdotV)));
+    const float chi = a > 0 ? 1.0f : 0.0f;
+    float approx = 1.0f;
+    if (a < 1.6f)
+        approx = (3.535f * a + 2.181f * a * a) / (1 + 2.276f * a + 2.577f * a * a);
+    return chi * VdotM / NdotV * approx;
+}
+__device__ inline float G_SmithGGX_IncludeFraction(float NdotL, float NdotV, float alphaG)
+{
+    const float a2 = alphaG * alphaG;
+    const float lv = NdotL * sqrtf((-NdotV * a2 + NdotV) * NdotV + a2);
+    const float ll = NdotV * sqrtf((-NdotL * a2 + NdotL) * NdotL + a2);
+    return 0.5f / (lv + ll);
+}
+__device__ inline float D_GGX(float NdotH, float alpha)
+{
+    const float a2 = alpha * alpha;
+    const float f = (NdotH * NdotH) * (a2 - 1) + 1;
+    return f > kEPS ? a2 / (kPI * f * f) : 1.0f;
+}
+__device__ inline float Fr_DisneyDiffuse(float NdotV, float NdotL, float LdotH, float linearRoughness)
+{
+    const float energyBias = 0.0f + (0.5f - 0.0f) * linearRoughness;
+    const float energyFactor = 1.0f + (1.0f / 1.51f - 1.0f) * linearRoughness;
+    const float fd90 = energyBias + 2.0f * LdotH * LdotH * linearRoughness;
+    const float lightScatter = 1.0f + (fd90 - 1.0f) * powf(1.0f - NdotL, 5.0f);
+    const float viewScatter = 1.0f + (fd90 - 1.0f) * powf(1.0f - NdotV, 5.0f);
+    return lightScatter * viewScatter * energyFactor;
+}
+
+struct MatView {
+    V3 colour;
+    float p0, p1; // smoothness | iorBasic ; f0NonMetal | iorRough
+    int texId;
+    bool metallic;
+    int type;
+};
+__device__ inline MatView loadMaterial(const SceneDev& sc, uint32_t index)
+{
+    const Material m = sc.materials[index];
+    MatView v;
+    v.colour = xyz(m.colour);
+    v.p0 = m.params.x;
+    v.p1 = m.params.y;
+    v.texId = (int)asU(m.params.x);
+    v.metallic = (asU(m.params.z) & 0xFFu) != 0u;
+    v.type = (int)asU(m.typeAndPad.x);
+    return v;
+}
+__device__ inline V3 pbrF0(const MatView& m) { return m.metallic ? m.colour : mk(m.p1); }
+
+__device__ inline V3 pbrBrdfWithDiffuse(V3 V, V3 L, V3 N, const MatView& m, bool nospecular) // pbr_brdf.cl:131-181
+{
+    const V3 f0 = pbrF0(m);
+    const float roughness = 1.0f - m.p0;
+    const float linearRoughness = sqrtf(roughness);
+    const float NdotV = fabsf(dot(N, V)) + 1e-5f;
+    const V3 H = normalize(V + L);
+    const float LdotH = saturate(dot(L, H));
+    const float NdotH = saturate(dot(N, H));
+    const float NdotL = saturate(dot(N, L));
+    const V3 F = F_Schlick(f0, 1.0f, LdotH);
+    const float G = G_SmithGGX_IncludeFraction(NdotL, NdotV, roughness);
+    const float D = D_GGX(NdotH, roughness);
+    const V3 Fr = D * G * F;
+    const float Fd = Fr_DisneyDiffuse(NdotV, NdotL, LdotH, linearRoughness) / kPI;
+    const V3 diffuseColour = m.metallic ? mk(0.0f) : m.colour;
+    const V3 diffuse = (mk(1.0f) - F) * (Fd * diffuseColour);
+    return nospecular ? diffuse : Fr + diffuse;
+}
+
+__device__ inline float calcWeight(V3 I, V3 N, V3 M, float smoothness, V3 O) // refract.cl:116-134
+{
+    const float IdotM = fabsf(dot(I, M)), MdotN = fabsf(dot(M, N)), NdotI = fabsf(dot(N, I));
+    const float MdotO = fabsf(dot(M, O)), NdotO = fabsf(dot(N, O));
+    const float roughness = 1.0f - smoothness;
+    float G = G_SmithBeckmannCorrelated(IdotM, NdotI, roughness) * G_SmithBeckmannCorrelated(MdotO, NdotO, roughness);
+    G = fmaxf(fminf(G, 4.0f), 0.f);
+    const float weight = (IdotM * G) / (NdotI * MdotN);
+    return fminf(weight, 4.0f);
+}
+
+// M^T (3x3 part of the inverse instance matrix) times v = normal transform (math.cl:22-29).
+// Instance rows r_i = (m[i], m[4+i], m[8+i], m[12+i]) so (M^T v)_j = sum_i m[4j+i] v_i.
+__device__ inline V3 normalTransform(const Instance& in, V3 v)
+{
+    const V3 c1 = v.x * mk(in.r0.x, in.r0.y, in.r0.z);
+    const V3 c2 = v.y * mk(in.r1.x, in.r1.y, in.r1.z);
+    const V3 c3 = v.z * mk(in.r2.x, in.r2.y, in.r2.z);
+    return c1 + c2 + c3;
+}
+__device__ inline V3 orient(V3 sample, V3 normal, V3 tangentSeed, const Instance& in)
+{
+    const V3 tangent = normalize(cross(normal, tangentSeed));
+    const V3 bitangent = cross(normal, tangent);
+    const V3 os = sample.x * tangent + sample.y * bitangent + sample.z * normal;
+    return normalize(normalTransform(in, os));
+}
+__device__ inline V3 cosineWeightedDiffuseReflection(V3 normal, V3 edge1, const Instance& in, Rng& rng) // shading_helper.cl:62-90
+{
+    const float r0 = rng.u01(), r1 = rng.u01();
+    const float r = sqrtf(r0);
+    const float theta = 2 * kPI * r1;
+    return normalize(orient(mk(r * cosf(theta), r * sinf(theta), sqrtf(1 - r0)), normal, edge1, in));
+}
+
+struct ShadeResult {
+    V3 radiance; // deposited by shade itself
+    uint32_t flags; // continuation ray flags
+    V3 origin, direction, throughput;
+    uint32_t shadowFlags;
+    V3 shadowOrigin, shadowDirection, shadowContribution;
+    float shadowLength;
+};
+
+// neeIsShading, shading.cl:356-623
+__device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u, float v, uint32_t prim, uint32_t instIdx,
+    V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out)
+{
+    const TriShade ts = sc.triShade[prim];
+    const TriIsect* tp = &sc.tris[prim];
+    const float4 ta = tp->a, tb = tp->b, tc = tp->c;
+    const V3 edge1 = mk(ta.w, tb.x, tb.y), edge2 = mk(tb.z, tb.w, tc.x);
+    const Instance in = sc.instances[instIdx];
+    const V3 realNormal = normalize(normalTransform(in, cross(edge1, edge2)));
+    const VertexShade a0 = sc.verts[ts.i0], a1 = sc.verts[ts.i1], a2 = sc.verts[ts.i2];
+    const V3 n0 = xyz(a0.n_u), n1 = xyz(a1.n_u), n2 = xyz(a2.n_u);
+    const V3 shadingNormal = normalize(n0 + (n1 - n0) * u + (n2 - n0) * v); // object space, not instance-transformed (shading.cl:378)
+    V3 raySideNormal = shadingNormal;
+    if (dot(raySideNormal, -D) < 0.0f)
+        raySideNormal = raySideNormal * -1.0f;
+    const MatView mat = loadMaterial(sc, ts.material);
+    out.radiance = mk(0.0f);
+    out.flags = 0;
+    out.shadowFlags = FLAG_FINISHED;
+
+    if (mat.type == MAT_EMISSIVE) { // :387-397
+        out.flags = FLAG_FINISHED;
+        if (inFlags & FLAG_LASTSPECULAR)
+            out.radiance = throughput * mat.colour;
+        return;
+    }
+
+    // diffuse albedo lookup shared by NEE and the continuation (shading_helper.cl:280-307); x=-1: alpha-0 texel
+    V3 albedo = mat.colour;
+    if (mat.type == MAT_DIFFUSE && mat.texId != -1) {
+        const float t0x = a0.n_u.w, t0y = a0.v_pad.x;
+        const float tcx = t0x + (a1.n_u.w - t0x) * u + (a2.n_u.w - t0x) * v;
+        const float tcy = t0y + (a1.v_pad.x - t0y) * u + (a2.v_pad.x - t0y) * v;
+        const float4 c = sampleLinearRepeat(sc.materialTex, tcx, tcy, (float)mat.texId);
+        albedo = (c.w == 0.0f) ? mk(-1.0f) : xyz(c);
+    }
+
+    V3 BRDF = mk(0.0f);
+    if (mat.type != MAT_REFRACTIVE && mat.type != MAT_BASIC_REFRACTIVE) { // NEE, :399-448
+        const int li = rng.randomInteger(0, (int)sc.numLights - 1);
+        const Light lt = sc.lights[li];
+        const float u1 = rng.u01(), u2 = rng.u01();
+        const V3 lightPos = (1 - sqrtf(u1)) * xyz(lt.v0) + (sqrtf(u1) * (1 - u2)) * xyz(lt.v1) + (sqrtf(u1) * u2) * xyz(lt.v2);
+        const V3 lightNormal = xyz(lt.normal);
+        V3 L = lightPos - X;
+        const float dist2 = dot(L, L);
+        const float dist = sqrtf(dist2);
+        L = L / dist;
+        if (dot(shadingNormal, L) > kEPS && dot(realNormal, L) > kEPS && dot(lightNormal, -L) > kEPS) {
+            if (mat.type == MAT_PBR)
+                BRDF = pbrBrdfWithDiffuse(-D, L, shadingNormal, mat, mat.p0 > kMaxSmoothness);
+            else if (mat.type == MAT_DIFFUSE)
+                BRDF = (albedo.x == -1.0f) ? mk(0.0f) : albedo / kPI;
+            float solidAngle = 2 * kPI;
+            if (dist2 > kEPS) {
+                solidAngle = (dot(lightNormal, -L) * lt.v0.w) / dist2;
+                solidAngle = fminf(fmaxf(solidAngle, 0.0f), 2 * kPI);
+            }
+            const V3 Ld = (float)sc.numLights * xyz(lt.colour) * BRDF * solidAngle * dot(shadingNormal, L);
+            out.shadowFlags = 0;
+            out.shadowContribution = Ld * throughput;
+            out.shadowOrigin = X + L * kEPS;
+            out.shadowDirection = L;
+            out.shadowLength = dist - 2 * kEPS;
+        }
+    }
+
+    bool dospecular = false;
+    float PDF = 1.0f, cosineTerm = 1.0f;
+    V3 reflection = mk(0.0f);
+    if (mat.type == MAT_PBR) { // :456-496
+        const V3 f0 = pbrF0(mat);
+        const V3 V = -D;
+        const float alpha = 1 - mat.p0;
+        // ggxWeightedHalfway, shading_helper.cl:92-125
+        const float r0 = rng.u01();
+        const float phi = 2.0f * kPI * r0;
+        const float r1 = rng.u01();
+        const float theta = acosf(sqrtf((1.0f - r1) / ((alpha * alpha - 1.0f) * r1 + 1.0f)));
+        const V3 halfway = orient(mk(cosf(phi) * cosf(kPI / 2 - theta), sinf(phi) * cosf(kPI / 2 - theta), sinf(kPI / 2 - theta)),
+            shadingNormal, mk(1.0f, 0.0f, 0.0f), in);
+        reflection = normalize(2 * dot(halfway, V) * halfway - V);
+        cosineTerm = dot(shadingNormal, reflection);
+        if (cosineTerm < 0.05f || dot(realNormal, reflection) < kEPS) {
+            out.flags = FLAG_FINISHED;
+            return;
+        }
+        const float LdotH = saturate(dot(reflection, halfway));
+        const V3 F = F_Schlick(f0, 1.0f, LdotH);
+        const float rand01 = rng.u01();
+        const float roughness = 1.0f - mat.p0;
+        if (!mat.metallic && rand01 > F.x) {
+            reflection = cosineWeightedDiffuseReflection(shadingNormal, edge1, in, rng);
+            PDF = kINVPI;
+            cosineTerm = 1.0f;
+            // diffuseOnly, pbr_brdf.cl:217-237
+            const float NdotV = fabsf(dot(shadingNormal, V)) + 1e-5f;
+            const float Fd = Fr_DisneyDiffuse(NdotV, saturate(dot(shadingNormal, reflection)), saturate(dot(reflection, halfway)), sqrtf(roughness));
+            BRDF = Fd * mat.colour / kPI;
+        } else {
+            PDF = 1.0f;
+            // brdfOnlyNoFresnelNoNDF, pbr_brdf.cl:194-213
+            const float NdotV = fabsf(dot(shadingNormal, V)) + 1e-5f;
+            const float G = G_SmithGGX_IncludeFraction(saturate(dot(shadingNormal, reflection)), NdotV, roughness);
+            BRDF = mk(fminf(G, 10.0f));
+            if (mat.metallic)
+                BRDF = BRDF * F;
+            if (mat.p0 > kMaxSmoothness)
+                dospecular = true;
+        }
+    } else if (mat.type == MAT_BASIC_REFRACTIVE) { // :497-538
+        V3 absorptionFactor = mk(1.0f);
+        float n1, n2;
+        if (dot(realNormal, -D) > kEPS) {
+            n1 = kAirIor;
+            n2 = mat.p0;
+        } else {
+            n1 = mat.p0;
+            n2 = kAirIor;
+            const V3 e = -mat.colour * t;
+            absorptionFactor = mk(expf(e.x), expf(e.y), expf(e.z));
+        }
+        const float cos1 = dot(raySideNormal, -D);
+        const float n1n2 = n1 / n2;
+        const float K = 1 - (n1n2 * n1n2) * (1 - cos1 * cos1);
+        if (K > kEPS) {
+            const float rand01 = rng.u01();
+            const float f0 = powf((n1 - n2) / (n1 + n2), 2.0f);
+            const V3 F = F_Schlick(mk(f0), 1.0f, dot(raySideNormal, -D));
+            if (rand01 < F.x)
+                reflection = normalize(-D - 2 * dot(-D, raySideNormal) * raySideNormal); // sic (shading.cl:522)
+            else
+                reflection = normalize(n1n2 * D + raySideNormal * (n1n2 * cos1 - sqrtf(K)));
+        } else {
+            reflection = normalize(-D - 2 * dot(-D, raySideNormal) * raySideNormal);
+        }
+        BRDF = absorptionFactor;
+    } else if (mat.type == MAT_REFRACTIVE) { // :539-586
+        // beckmannWeightedHalfway, shading_helper.cl:127-160
+        const float alpha = (1.2f - 0.2f * sqrtf(fabsf(dot(D, raySideNormal)))) * (1 - mat.p0);
+        const float r0 = rng.u01(), r1 = rng.u01();
+        const float phi = 2.0f * kPI * r0;
+        const float theta = atanf(-alpha * alpha * log1pf(-r1));
+        const V3 halfway = orient(mk(cosf(phi) * cosf(kPI / 2 - theta), sinf(phi) * cosf(kPI / 2 - theta), sinf(kPI / 2 - theta)),
+            raySideNormal, mk(1.0f, 0.0f, 0.0f), in);
+        V3 absorptionFactor = mk(1.0f);
+        float n_i, n_t;
+        if (dot(realNormal, -D) > 0.0f) {
+            n_i = kAirIor;
+            n_t = mat.p1;
+        } else {
+            n_i = mat.p1;
+            n_t = kAirIor;
+            const V3 e = -mat.colour * t;
+            absorptionFactor = mk(expf(e.x), expf(e.y), expf(e.z));
+        }
+        const float f0 = powf((n_i - n_t) / (n_i + n_t), 2.0f);
+        const V3 F = F_Schlick(mk(f0), 1.0f, dot(-D, halfway));
+        const float rand01 = rng.u01();
+        const V3 I = -D;
+        bool refract = false;
+        float n1n2 = 0.f, cos1 = 0.f, K = 0.f;
+        if (!(rand01 < F.x)) {
+            n1n2 = n_i / n_t;
+            cos1 = dot(halfway, I);
+            K = 1 - (n1n2 * n1n2) * (1 - cos1 * cos1);
+            refract = K >= 0;
+        }
+        if (refract)
+            reflection = normalize(-n1n2 * I + halfway * (n1n2 * cos1 - sqrtf(K))); // evaluateRefract, refract.cl:142-153
+        else
+            reflection = normalize(I - 2 * dot(I, halfway) * halfway); // evaluateReflect, refract.cl:136-140
+        const float w = calcWeight(I, raySideNormal, halfway, mat.p0, reflection);
+        BRDF = mk(w) * absorptionFactor;
+    } else if (mat.type == MAT_DIFFUSE) { // :587-601
+        if (albedo.x == -1.0f) {
+            reflection = D;
+            BRDF = mk(1.0f);
+        } else {
+            reflection = cosineWeightedDiffuseReflection(realNormal, edge1, in, rng);
+            BRDF = albedo;
+        }
+    }
+
+    // Russian roulette + spawn, :606-622
+    out.flags = (mat.type == MAT_REFRACTIVE || mat.type == MAT_BASIC_REFRACTIVE || dospecular) ? FLAG_LASTSPECULAR : 0u;
+    const V3 integral = BRDF * cosineTerm / PDF;
+    const float survive = saturate(fmaxf(fmaxf(integral.x, integral.y), integral.z));
+    const float choice = rng.u01();
+    if (survive < kEPS || choice > survive) {
+        out.flags = FLAG_FINISHED;
+        return;
+    }
+    out.origin = X + reflection * kEPS;
+    out.direction = reflection;
+    out.throughput = throughput * integral / survive;
+}
+
+// =================================================================================================
+// kernels
+// =================================================================================================
+struct FrameParams {
+    CameraDev cam;
+    uint32_t width, height;
+    uint32_t sample, seed;
+    uint32_t maxBounces;
+    uint32_t parity; // LFSR113 streams per slot + reference queue semantics
+};
+
+// generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th pixel to issue
+// (pixelList[first + i], or first + i when no list is set) into queue slot slotBase + i.
+__global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const uint32_t* __restrict__ pixelList, uint32_t first,
+    uint32_t n, uint32_t slotBase, uint4* __restrict__ streams, uint32_t* __restrict__ queueCount, uint32_t* __restrict__ generated)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { // the queue now holds the surviving rays [0, slotBase) plus n new ones
+        *queueCount = slotBase + n;
+        *generated += n;
+    }
+    if (i >= n)
+        return;
+    const uint32_t pixel = pixelList ? pixelList[first + i] : first + i;
+    Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample, fp.seed, 0u);
+    V3 o, d;
+    cameraRay(fp.cam, (int)(pixel % fp.width), (int)(pixel / fp.width), (float)fp.width, (float)fp.height, rng, &o, &d);
+    if (fp.parity)
+        rngLfsrStore(streams, i, rng);
+    const uint32_t slot = slotBase + i;
+    q.o[slot] = make_float4(o.x, o.y, o.z, asF(pixel));
+    q.d[slot] = make_float4(d.x, d.y, d.z, asF(FLAG_LASTSPECULAR)); // bounce 0 in bits 8..
+    q.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+}
+
+struct ShadeArgs {
+    SceneDev sc;
+    FrameParams fp;
+    RayQueue in;
+    HitQueue hits;
+    RayQueue out;
+    ShadowQueue shadow;
+    float4* accum;
+    const uint32_t* inCount;
+    uint32_t* outCount;
+    uint32_t* shadowCount;
+    uint32_t* shadeHits;
+    uint4* streams; // parity mode
+    // parity mode: un-compacted staging + active flags for the stable compaction pass
+    uint32_t* activeFlag;
+};
+
+// shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
+// output queues, finished or not (kernel.cl:292-300), at the SAME index, in slot order.
+template <bool PARITY>
+__global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t count = *a.inCount;
+    bool emitRay = false, emitShadow = false, shaded = false;
+    ShadeResult r;
+    uint32_t pixel = 0, bounce = 0;
+    if (i < count) {
+        const float4 ro = a.in.o[i];
+        const float4 rd = a.in.d[i];
+        const uint32_t fb = asU(rd.w);
+        pixel = asU(ro.w);
+        bounce = fb >> 8;
+        if (!(fb & FLAG_FINISHED)) {
+            const float4 h = a.hits.h[i];
+            const float4 thr = a.in.thr[i];
+            const V3 o = xyz(ro), d = xyz(rd), throughput = xyz(thr);
+            const int prim = (int)asU(h.w);
+            if (prim >= 0) {
+                shaded = true;
+                const V3 X = o + h.x * d;
+                Rng rng = PARITY ? rngLfsrLoad(a.streams, i) : rngCounter(pixel, a.fp.sample, a.fp.seed, 1u + bounce);
+                shadeHit(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r);
+                if (PARITY)
+                    rngLfsrStore(a.streams, i, rng);
+                if (r.radiance.x != 0.f || r.radiance.y != 0.f || r.radiance.z != 0.f) {
+                    float4 px = a.accum[pixel];
+                    px.x += r.radiance.x, px.y += r.radiance.y, px.z += r.radiance.z;
+                    a.accum[pixel] = px;
+                }
+                bounce += 1;
+                if (bounce >= a.fp.maxBounces) // kernel.cl:295-296
+                    r.flags = FLAG_FINISHED;
+                emitRay = PARITY ? true : !(r.flags & FLAG_FINISHED);
+                emitShadow = PARITY ? true : !(r.shadowFlags & FLAG_FINISHED);
+            } else { // miss: skydome (kernel.cl:285-289)
+                const V3 c = throughput * readSkydome(a.sc, normalize(d));
+                float4 px = a.accum[pixel];
+                px.x += c.x, px.y += c.y, px.z += c.z;
+                a.accum[pixel] = px;
+            }
+        }
+    }
+    if (PARITY) {
+        // stage at the input slot; k_compact_stable assigns output indices in slot order
+        if (i < count)
+            a.activeFlag[i] = shaded ? 1u : 0u;
+        if (shaded) {
+            a.out.o[i] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
+            a.out.d[i] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF((r.flags & 0xFFu) | (bounce << 8)));
+            a.out.thr[i] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+            a.shadow.o[i] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
+            a.shadow.d[i] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
+            a.shadow.c[i] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(r.shadowFlags));
+        }
+        return;
+    }
+    // wave-aggregated compaction: one atomic per wave and per queue
+    const unsigned long long mRay = __ballot(emitRay);
+    const unsigned long long mSh = __ballot(emitShadow);
+    const unsigned long long mHit = __ballot(shaded);
+    uint32_t baseRay = 0, baseSh = 0;
+    if (lane == 0) {
+        if (mRay) baseRay = atomicAdd(a.outCount, (uint32_t)__popcll(mRay));
+        if (mSh) baseSh = atomicAdd(a.shadowCount, (uint32_t)__popcll(mSh));
+        if (mHit) atomicAdd(a.shadeHits, (uint32_t)__popcll(mHit));
+    }
+    baseRay = __shfl(baseRay, 0);
+    baseSh = __shfl(baseSh, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (emitRay) {
+        const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);
+        a.out.o[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
+        a.out.d[idx] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF((r.flags & 0xFFu) | (bounce << 8)));
+        a.out.thr[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+    }
+    if (emitShadow) {
+        const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);
+        a.shadow.o[idx] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
+        a.shadow.d[idx] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
+        a.shadow.c[idx] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, 0.f);
+    }
+}
+
+// Parity mode: stable (slot-ordered) compaction of the staged shade outputs -- the order the
+// reference's atomic_inc compaction takes when work-items run in gid order (oracle/_ref).
+// One workgroup walks the queue in 1024-entry tiles with an LDS scan.
+struct CompactArgs {
+    RayQueue staged, out;
+    ShadowQueue stagedShadow, outShadow;
+    const uint32_t* activeFlag;
+    const uint32_t* inCount;
+    uint32_t* outCount; // rays and shadow rays share the index (kernel.cl:292-300)
+    uint32_t* shadowCount;
+    uint32_t* shadeHits;
+};
+__global__ void __launch_bounds__(1024) k_compact_stable(CompactArgs a)
+{
+    __shared__ uint32_t scan[1024];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t count = *a.inCount;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t tile = 0; tile < count; tile += 1024) {
+        const uint32_t i = tile + tid;
+        const uint32_t f = (i < count) ? a.activeFlag[i] : 0u;
+        scan[tid] = f;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+            uint32_t v = (tid >= off) ? scan[tid - off] : 0u;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t base = carry;
+        if (f) {
+            const uint32_t idx = base + scan[tid] - 1u;
+            a.out.o[idx] = a.staged.o[i];
+            a.out.d[idx] = a.staged.d[i];
+            a.out.thr[idx] = a.staged.thr[i];
+            a.outShadow.o[idx] = a.stagedShadow.o[i];
+            a.outShadow.d[idx] = a.stagedShadow.d[i];
+            a.outShadow.c[idx] = a.stagedShadow.c[i];
+        }
+        __syncthreads();
+        if (tid == 1023)
+            carry = base + scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *a.outCount = carry;
+        *a.shadowCount = carry;
+        *a.shadeHits = carry;
+    }
+}
+
+// accumulate, accumulate.cl:6-34: mean -> exposure (exposure.cl:7-41) -> Reinhard (tonemapping.cl:7-10)
+// -> sRGB (gamma.cl:4-13)
+__global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accum, float4* __restrict__ out, uint32_t n, float spp,
+    float relativeAperture, float shutterTime, float ISO)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float EV100 = log2f(relativeAperture * relativeAperture / shutterTime * 100 / ISO);
+    const float exposure = 1.0f / (1.2f * powf(2.0f, EV100));
+    const float4 s = accum[i];
+    float c[3] = { s.x / spp * exposure, s.y / spp * exposure, s.z / spp * exposure };
+    for (int k = 0; k < 3; k++) {
+        const float col = c[k] / (1.0f + c[k]);
+        c[k] = (col <= 0.0031308f) ? col * 12.92f : (powf(fabsf(col), 1.0f / 2.4f) * 1.055f) - 0.055f;
+    }
+    out[i] = make_float4(c[0], c[1], c[2], 1.0f);
+}
+
+__global__ void k_set_word(uint32_t* p, uint32_t v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        *p = v;
+}
+
+// end-of-sample bookkeeping: fold the per-pass counters into 64-bit totals and zero the control
+// block for the next sample (replaces updateKernelData, kernel.cl:303-317, and the per-pass
+// blocking KernelData read-back of raytracer.cpp:381-389).
+__global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    unsigned long long ext = 0, sh = 0, hits = 0;
+    for (uint32_t p = 0; p <= passes && p <= kMaxPasses; p++) {
+        ext += ctl->extCount[p];
+        sh += ctl->shadowCount[p];
+        hits += ctl->shadeHits[p];
+        ctl->extCount[p] = ctl->shadowCount[p] = ctl->extCursor[p] = ctl->shadowCursor[p] = ctl->shadeHits[p] = 0;
+    }
+    tot->raysExtension += ext;
+    tot->raysShadow += sh;
+    tot->shadeHits += hits;
+    tot->raysGenerated += ctl->generated;
+    ctl->generated = 0;
+}
+
+} // namespace ptd

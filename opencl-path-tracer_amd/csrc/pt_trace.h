@@ -1,0 +1,288 @@
+// Persistent-wave two-level BVH traversal for gfx950 (closest-hit and any-hit).
+//
+// What it computes is the reference's traceRay (assets/cl/scene.cl:61-271): top-level stack walk
+// with the child whose box centre is nearer to the ray origin visited first, instance transform
+// without renormalisation (so t is shared between spaces), the zero-component fix-up, bottom-level
+// ordered traversal with Moeller-Trumbore leaves, `t < closestT` updates and any-hit early out.
+//
+// How it runs is CDNA4-specific:
+//  * persistent waves: the grid is sized to the machine (blocks/CU x 256 CUs); each 64-lane wave
+//    pulls rays from the queue with ONE atomicAdd per refill (ballot + popcount ranks the idle
+//    lanes) and refills when enough lanes have gone idle, so long rays do not hold 63 lanes hostage;
+//  * the bottom-level stack lives in LDS, laid out [entry][lane] so a wave's push/pop touches 64
+//    consecutive dwords (conflict-free ds_read/ds_write_b32); entries beyond kLdsStack and the
+//    (rarely touched) top-level stack spill to a lane-interleaved region in global memory;
+//  * one 64-byte PairNode fetch per step (both child boxes), reciprocal direction computed once
+//    per instance entry, 48-byte pre-digested triangles.
+#pragma once
+#include "pt_math.h"
+
+namespace ptd {
+
+constexpr int kLdsStack = 24; // bottom-level entries kept in LDS per lane (6 KiB per wave)
+constexpr int kSpillStack = 48; // further bottom-level entries in global memory
+constexpr int kTopStack = 64; // top-level entries (global memory)
+constexpr int kTraceBlock = 256;
+constexpr int kRefillIdleLanes = 20; // refill the wave once this many lanes are idle
+
+struct TraceArgs {
+    SceneDev sc;
+    // closest-hit: rays from (rayO, rayD), results to (hit, inst)
+    // any-hit: rays from (shO, shD, shC); unoccluded contributions are added to accum
+    const float4* rayO;
+    const float4* rayD;
+    const float4* rayC;
+    float4* hit;
+    int32_t* inst;
+    float4* accum;
+    uint32_t* occluded; // optional (test hook): 1/0 per shadow ray
+    const uint32_t* count; // number of queue entries (device word)
+    uint32_t* cursor; // fetch cursor (device word, zero at launch)
+    uint32_t* spill; // (kSpillStack + kTopStack) * totalThreads dwords
+    uint32_t totalThreads;
+    uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
+};
+
+template <bool ANY_HIT>
+__global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
+{
+    __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    uint32_t* const spillBottom = a.spill + gtid; // entry e at spillBottom[e * totalThreads]
+    uint32_t* const spillTop = a.spill + (size_t)kSpillStack * a.totalThreads + gtid;
+    const uint32_t total = a.totalThreads;
+    const uint32_t count = *a.count;
+    const SceneDev& sc = a.sc;
+
+    bool active = false;
+    bool exhausted = false; // wave-uniform: queue has no more rays
+    uint32_t rayIdx = 0;
+    V3 o = mk(0.f), d = mk(0.f); // world-space ray
+    V3 to = mk(0.f), td = mk(0.f), itd = mk(0.f); // instance-space origin, direction, 1/direction
+    float tClosest = 0.f, tMax = 0.f, hu = 0.f, hv = 0.f;
+    int hprim = -1, hinst = -1, curInst = -1;
+    uint32_t cur = kRefNone;
+    int sp = 0, tsp = 0;
+    float4 contrib = make_float4(0, 0, 0, 0);
+    uint32_t pixel = 0;
+
+    while (true) {
+        // ---- refill idle lanes (one atomic per wave) ------------------------------------
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const int nIdle = __popcll(idle);
+            if (nIdle >= kRefillIdleLanes) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(a.cursor, (uint32_t)nIdle);
+                base = __shfl(base, 0);
+                if (!active) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t idx = base + rank;
+                    if (idx < count) {
+                        const float4 ro = a.rayO[idx];
+                        const float4 rd = a.rayD[idx];
+                        bool live = true;
+                        if (ANY_HIT) {
+                            contrib = a.rayC[idx];
+                            pixel = asU(rd.w);
+                            tMax = ro.w;
+                            if (a.parityShadow && (asU(contrib.w) & FLAG_FINISHED))
+                                live = false;
+                        } else {
+                            tMax = INFINITY;
+                            if (asU(rd.w) & FLAG_FINISHED) { // parity mode keeps finished rays in the queue
+                                live = false;
+                                a.hit[idx] = make_float4(INFINITY, 0.f, 0.f, asF(0xFFFFFFFFu));
+                                a.inst[idx] = -1;
+                            }
+                        }
+                        if (live) {
+                            rayIdx = idx;
+                            o = xyz(ro);
+                            d = xyz(rd);
+                            tClosest = tMax;
+                            hprim = -1;
+                            hinst = -1;
+                            hu = hv = 0.f;
+                            cur = kRefNone;
+                            sp = 0;
+                            tsp = 1;
+                            spillTop[0] = sc.topRoot;
+                            active = true;
+                        }
+                    }
+                }
+                if (base + (uint32_t)nIdle >= count)
+                    exhausted = true;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted)
+                break;
+            continue;
+        }
+
+        // ---- traverse until enough lanes are idle again -----------------------------------
+        while (true) {
+            if (active) {
+                if (cur == kRefNone) {
+                    // ---------------- top level (scene.cl:105-159) ----------------
+                    if (tsp == 0) {
+                        // ray finished: closestT != maxT decides hit/miss (scene.cl:257)
+                        if (ANY_HIT) {
+                            if (a.occluded)
+                                a.occluded[rayIdx] = 0u;
+                            float4 px = a.accum[pixel]; // one live path per pixel: plain RMW
+                            px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                            a.accum[pixel] = px;
+                        } else {
+                            a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+                            a.inst[rayIdx] = hinst;
+                        }
+                        active = false;
+                    } else {
+                        const uint32_t ni = spillTop[(size_t)(--tsp) * total];
+                        const TopNode tn = sc.top[ni];
+                        // slab test in world space with the per-axis d != 0 guard (bvh.cl:36-73)
+                        float tmin = -INFINITY, tmax = INFINITY;
+                        if (d.x != 0.0f) {
+                            float t1 = (tn.lo.x - o.x) / d.x, t2 = (tn.hi.x - o.x) / d.x;
+                            tmin = fmaxf(tmin, fminf(t1, t2));
+                            tmax = fminf(tmax, fmaxf(t1, t2));
+                        }
+                        if (d.y != 0.0f) {
+                            float t1 = (tn.lo.y - o.y) / d.y, t2 = (tn.hi.y - o.y) / d.y;
+                            tmin = fmaxf(tmin, fminf(t1, t2));
+                            tmax = fminf(tmax, fmaxf(t1, t2));
+                        }
+                        if (d.z != 0.0f) {
+                            float t1 = (tn.lo.z - o.z) / d.z, t2 = (tn.hi.z - o.z) / d.z;
+                            tmin = fmaxf(tmin, fminf(t1, t2));
+                            tmax = fminf(tmax, fmaxf(t1, t2));
+                        }
+                        if (tmax >= tmin && tmax >= 0.f && tmin < tClosest) {
+                            const uint32_t ca = asU(tn.lo.w), cb = asU(tn.hi.w);
+                            if (cb == 0xFFFFFFFFu) { // leaf: enter the instance
+                                const Instance in = sc.instances[ca];
+                                to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w,
+                                    in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
+                                    in.r2.x * o.x + in.r2.y * o.y + in.r2.z * o.z + in.r2.w);
+                                td = mk(in.r0.x * d.x + in.r0.y * d.y + in.r0.z * d.z,
+                                    in.r1.x * d.x + in.r1.y * d.y + in.r1.z * d.z,
+                                    in.r2.x * d.x + in.r2.y * d.y + in.r2.z * d.z);
+                                // NO_PARALLEL_RAYS fix-up (scene.cl:123-137)
+                                if (td.x == 0.0f) td.x = FLT_MIN;
+                                if (td.y == 0.0f) td.y = FLT_MIN;
+                                if (td.z == 0.0f) td.z = FLT_MIN;
+                                if (to.x == 0.0f) to.x = -FLT_MIN;
+                                if (to.y == 0.0f) to.y = -FLT_MIN;
+                                if (to.z == 0.0f) to.z = -FLT_MIN;
+                                itd = mk(1.0f / td.x, 1.0f / td.y, 1.0f / td.z);
+                                cur = in.rootRef;
+                                curInst = (int)ca; // instance index; pt_intersect reports the top-level leaf
+                                sp = 0;
+                            } else { // inner: nearer box centre is visited first (scene.cl:141-157)
+                                const TopNode l = sc.top[ca];
+                                const TopNode r = sc.top[cb];
+                                const V3 lv = (xyz(l.lo) + xyz(l.hi)) / 2.0f - o;
+                                const V3 rv = (xyz(r.lo) + xyz(r.hi)) / 2.0f - o;
+                                const bool leftFirst = dot(lv, lv) < dot(rv, rv);
+                                spillTop[(size_t)tsp * total] = leftFirst ? cb : ca;
+                                spillTop[(size_t)(tsp + 1) * total] = leftFirst ? ca : cb;
+                                tsp += 2;
+                            }
+                        }
+                    }
+                } else if (refCount(cur) == 0u) {
+                    // ---------------- bottom level, inner step (scene.cl:197-231) ----------------
+                    const PairNode* np = &sc.nodes[refIndex(cur)];
+                    const float4 bx = np->bx, by = np->by, bz = np->bz;
+                    const uint32_t lref = np->left, rref = np->right;
+                    const float lx0 = (bx.x - to.x) * itd.x, lx1 = (bx.y - to.x) * itd.x;
+                    const float rx0 = (bx.z - to.x) * itd.x, rx1 = (bx.w - to.x) * itd.x;
+                    const float ly0 = (by.x - to.y) * itd.y, ly1 = (by.y - to.y) * itd.y;
+                    const float ry0 = (by.z - to.y) * itd.y, ry1 = (by.w - to.y) * itd.y;
+                    const float lz0 = (bz.x - to.z) * itd.z, lz1 = (bz.y - to.z) * itd.z;
+                    const float rz0 = (bz.z - to.z) * itd.z, rz1 = (bz.w - to.z) * itd.z;
+                    const float ltmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+                    const float ltmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+                    const float rtmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+                    const float rtmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+                    const bool lvis = ltmax >= ltmin && ltmax >= 0.f && ltmin < tClosest;
+                    const bool rvis = rtmax >= rtmin && rtmax >= 0.f && rtmin < tClosest;
+                    if (lvis && rvis) {
+                        const bool leftFirst = ltmin < rtmin;
+                        const uint32_t farRef = leftFirst ? rref : lref;
+                        if (sp < kLdsStack)
+                            ldsStack[wave][sp][lane] = farRef;
+                        else
+                            spillBottom[(size_t)(sp - kLdsStack) * total] = farRef;
+                        sp++;
+                        cur = leftFirst ? lref : rref;
+                    } else if (lvis) {
+                        cur = lref;
+                    } else if (rvis) {
+                        cur = rref;
+                    } else if (sp > 0) {
+                        sp--;
+                        cur = (sp < kLdsStack) ? ldsStack[wave][sp][lane] : spillBottom[(size_t)(sp - kLdsStack) * total];
+                    } else {
+                        cur = kRefNone;
+                    }
+                } else {
+                    // ---------------- bottom level, leaf (scene.cl:168-195, shapes.cl:20-72) -------
+                    const uint32_t first = refIndex(cur), n = refCount(cur);
+                    bool done = false;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const TriIsect* tp = &sc.tris[first + k];
+                        const float4 ta = tp->a, tb = tp->b, tc = tp->c;
+                        const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc.x);
+                        const V3 P = cross(td, e2);
+                        const float det = dot(e1, P);
+                        if (det > -FLT_MIN && det < FLT_MIN)
+                            continue;
+                        const float inv = 1.f / det;
+                        const V3 T = to - v0;
+                        const float u = dot(T, P) * inv;
+                        if (u < 0.f || u > 1.f)
+                            continue;
+                        const V3 Q = cross(T, e1);
+                        const float v = dot(td, Q) * inv;
+                        if (v < 0.f || u + v > 1.f)
+                            continue;
+                        const float t = dot(e2, Q) * inv;
+                        if (t > 0.f && t < tClosest) {
+                            if (ANY_HIT) {
+                                done = true;
+                                break;
+                            }
+                            tClosest = t;
+                            hu = u;
+                            hv = v;
+                            hprim = (int)(first + k);
+                            hinst = curInst;
+                        }
+                    }
+                    if (ANY_HIT && done) { // occluded: nothing to deposit
+                        if (a.occluded)
+                            a.occluded[rayIdx] = 1u;
+                        active = false;
+                    } else if (sp > 0) {
+                        sp--;
+                        cur = (sp < kLdsStack) ? ldsStack[wave][sp][lane] : spillBottom[(size_t)(sp - kLdsStack) * total];
+                    } else {
+                        cur = kRefNone;
+                    }
+                }
+            }
+            const int nActive = __popcll(__ballot(active));
+            if (nActive == 0 || (!exhausted && nActive <= 64 - kRefillIdleLanes))
+                break;
+        }
+    }
+}
+
+} // namespace ptd

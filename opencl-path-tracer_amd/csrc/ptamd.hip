@@ -1,0 +1,1276 @@
+// C-ABI implementation (include/ptamd.h) of the gfx950 ray-queue render path: context, scene
+// conversion into the HBM layouts of pt_device.h, the launch schedule that replaces the reference's
+// RayTracer::traceRays (src/raytracer.cpp:289-430), and the kernel-granular test hooks.
+#include "../../include/ptamd.h"
+#include "pt_shade.h"
+#include "pt_trace.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_createError;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0)
+            return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct RayQueueBuf {
+    DevBuf<float4> o, d, thr;
+    RayQueue view() const { return { o.p, d.p, thr.p }; }
+};
+struct ShadowQueueBuf {
+    DevBuf<float4> o, d, c;
+    ShadowQueue view() const { return { o.p, d.p, c.p }; }
+};
+
+} // namespace
+
+struct pt_ctx {
+    pt_config cfg {};
+    std::string error;
+    int device = 0;
+    int numCUs = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    std::vector<hipEvent_t> profEvents;
+    bool profile = false;
+
+    // scene (HBM)
+    DevBuf<PairNode> nodes;
+    DevBuf<TriIsect> tris;
+    DevBuf<TriShade> triShade;
+    DevBuf<VertexShade> verts;
+    DevBuf<Material> materials;
+    DevBuf<TopNode> top;
+    DevBuf<Instance> instances;
+    DevBuf<Light> lights;
+    DevBuf<float4> texMaterial, texSky;
+    SceneDev scene {};
+    std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
+    std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
+    std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
+    uint32_t numRefNodes = 0, numTris = 0;
+    bool haveStatic = false, haveDynamic = false, haveCamera = false;
+
+    // frame state
+    CameraDev camera {};
+    DevBuf<uint32_t> pixelList;
+    uint32_t numOwned = 0;
+    uint32_t capacity = 0;
+    bool identityPixels = true;
+    DevBuf<float4> accumOwn;
+    float4* accum = nullptr;
+    uint32_t spp = 0;
+
+    // queues
+    RayQueueBuf rays[2], stagedRays;
+    ShadowQueueBuf shadow, stagedShadow;
+    DevBuf<float4> hitH;
+    DevBuf<int32_t> hitInst;
+    DevBuf<uint32_t> activeFlag;
+    DevBuf<uint4> streams;
+    DevBuf<Control> control;
+    DevBuf<Totals> totals;
+    DevBuf<uint32_t> spill;
+    uint32_t traceBlocks = 0;
+    bool queuesReady = false;
+
+    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0;
+};
+
+namespace {
+
+int fail(pt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->error = buf;
+    else
+        g_createError = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline uint32_t maxBounces(const pt_ctx* c) { return c->cfg.max_bounces ? c->cfg.max_bounces : 4u; }
+inline bool parityMode(const pt_ctx* c) { return c->cfg.rng_mode == PT_RNG_LFSR113_PARITY; }
+
+void refreshSceneView(pt_ctx* c)
+{
+    SceneDev& s = c->scene;
+    s.nodes = c->nodes.p;
+    s.tris = c->tris.p;
+    s.triShade = c->triShade.p;
+    s.verts = c->verts.p;
+    s.materials = c->materials.p;
+    s.top = c->top.p;
+    s.instances = c->instances.p;
+    s.lights = c->lights.p;
+    s.materialTex.texels = c->texMaterial.p;
+    s.sky.texels = c->texSky.p;
+    s.numTriangles = c->numTris;
+}
+
+template <typename T>
+int uploadVec(pt_ctx* c, DevBuf<T>& buf, const std::vector<T>& host)
+{
+    HIPCHK(c, buf.alloc(std::max<size_t>(host.size(), 1)));
+    if (!host.empty())
+        HIPCHK(c, hipMemcpy(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+// clRNG stream spacing jump (published xor/shift network of lfsr113AdvanceState, clRNG
+// src/lfsr113.c:183-240): stream k+1 starts 2^55 steps after stream k.
+void lfsrJump(uint32_t g[4])
+{
+    int z, b;
+    z = g[0] & (uint32_t)(-2);
+    b = (z << 6) ^ z;
+    z = (z) ^ (z << 2) ^ (z << 3) ^ (z << 10) ^ (z << 13) ^ (z << 16) ^ (z << 19) ^ (z << 22) ^ (z << 25) ^ (z << 27) ^ (z << 28)
+        ^ ((b >> 3) & 0x1FFFFFFF) ^ ((b >> 4) & 0x0FFFFFFF) ^ ((b >> 6) & 0x03FFFFFF) ^ ((b >> 9) & 0x007FFFFF)
+        ^ ((b >> 12) & 0x000FFFFF) ^ ((b >> 15) & 0x0001FFFF) ^ ((b >> 18) & 0x00003FFF) ^ ((b >> 21) & 0x000007FF);
+    g[0] = z;
+    z = g[1] & (uint32_t)(-8);
+    b = (z << 2) ^ z;
+    z = ((b >> 13) & 0x0007FFFF) ^ (z << 16);
+    g[1] = z;
+    z = g[2] & (uint32_t)(-16);
+    b = (z << 13) ^ z;
+    z = (z << 2) ^ (z << 4) ^ (z << 10) ^ (z << 12) ^ (z << 13) ^ (z << 17) ^ (z << 25)
+        ^ ((b >> 3) & 0x1FFFFFFF) ^ ((b >> 11) & 0x001FFFFF) ^ ((b >> 15) & 0x0001FFFF) ^ ((b >> 16) & 0x0000FFFF) ^ ((b >> 24) & 0x000000FF);
+    g[2] = z;
+    z = g[3] & (uint32_t)(-128);
+    b = (z << 3) ^ z;
+    z = (z << 9) ^ (z << 10) ^ (z << 11) ^ (z << 14) ^ (z << 16) ^ (z << 18) ^ (z << 23) ^ (z << 24)
+        ^ ((b >> 1) & 0x7FFFFFFF) ^ ((b >> 2) & 0x3FFFFFFF) ^ ((b >> 7) & 0x01FFFFFF) ^ ((b >> 9) & 0x007FFFFF)
+        ^ ((b >> 11) & 0x001FFFFF) ^ ((b >> 14) & 0x0003FFFF) ^ ((b >> 15) & 0x0001FFFF) ^ ((b >> 16) & 0x0000FFFF)
+        ^ ((b >> 23) & 0x000001FF) ^ ((b >> 24) & 0x000000FF);
+    g[3] = z;
+}
+
+int resetStreams(pt_ctx* c)
+{
+    // one stream per pixel of the full image, created in order (raytracer.cpp:739-751); only the
+    // `current` state (16 of clRNG's 48 bytes) is ever read by the kernels
+    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    std::vector<uint4> host(n);
+    uint32_t g[4] = { 987654321u, 987654321u, 987654321u, 987654321u };
+    for (size_t i = 0; i < n; i++) {
+        host[i] = make_uint4(g[0], g[1], g[2], g[3]);
+        lfsrJump(g);
+    }
+    return uploadVec(c, c->streams, host);
+}
+
+int ensureQueues(pt_ctx* c)
+{
+    if (c->queuesReady)
+        return PT_OK;
+    if (c->numOwned == 0)
+        return fail(c, PT_ERR_STATE, "no pixels owned by this context");
+    uint32_t cap = c->cfg.max_active_rays ? c->cfg.max_active_rays : c->numOwned;
+    cap = (cap + 63u) & ~63u;
+    c->capacity = cap;
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, c->rays[k].o.alloc(cap));
+        HIPCHK(c, c->rays[k].d.alloc(cap));
+        HIPCHK(c, c->rays[k].thr.alloc(cap));
+    }
+    HIPCHK(c, c->shadow.o.alloc(cap));
+    HIPCHK(c, c->shadow.d.alloc(cap));
+    HIPCHK(c, c->shadow.c.alloc(cap));
+    HIPCHK(c, c->hitH.alloc(cap));
+    HIPCHK(c, c->hitInst.alloc(cap));
+    if (parityMode(c)) {
+        HIPCHK(c, c->stagedRays.o.alloc(cap));
+        HIPCHK(c, c->stagedRays.d.alloc(cap));
+        HIPCHK(c, c->stagedRays.thr.alloc(cap));
+        HIPCHK(c, c->stagedShadow.o.alloc(cap));
+        HIPCHK(c, c->stagedShadow.d.alloc(cap));
+        HIPCHK(c, c->stagedShadow.c.alloc(cap));
+        HIPCHK(c, c->activeFlag.alloc(cap));
+        int rc = resetStreams(c);
+        if (rc)
+            return rc;
+    }
+    HIPCHK(c, c->control.alloc(1));
+    HIPCHK(c, hipMemset(c->control.p, 0, sizeof(Control)));
+    c->queuesReady = true;
+    return PT_OK;
+}
+
+int ensureSpill(pt_ctx* c)
+{
+    if (c->spill.p)
+        return PT_OK;
+    int blocksPerCU = 0;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, k_trace<false>, kTraceBlock, 0));
+    int blocksAny = 0;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksAny, k_trace<true>, kTraceBlock, 0));
+    blocksPerCU = std::max(1, std::min(std::min(blocksPerCU, blocksAny), 8));
+    c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
+    const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
+    HIPCHK(c, c->spill.alloc(threads * (kSpillStack + kTopStack)));
+    return PT_OK;
+}
+
+TraceArgs traceArgsBase(pt_ctx* c)
+{
+    TraceArgs a {};
+    a.sc = c->scene;
+    a.spill = c->spill.p;
+    a.totalThreads = c->traceBlocks * kTraceBlock;
+    a.parityShadow = parityMode(c) ? 1u : 0u;
+    return a;
+}
+
+FrameParams frameParams(const pt_ctx* c, uint32_t sample)
+{
+    FrameParams fp {};
+    fp.cam = c->camera;
+    fp.width = c->cfg.width;
+    fp.height = c->cfg.height;
+    fp.sample = sample;
+    fp.seed = c->cfg.seed;
+    fp.maxBounces = maxBounces(c);
+    fp.parity = parityMode(c) ? 1u : 0u;
+    return fp;
+}
+
+struct Prof {
+    pt_ctx* c;
+    size_t next = 0;
+    std::vector<std::pair<int, size_t>> marks; // (family, event index of start); stop = +1
+    void begin(int family)
+    {
+        if (!c->profile)
+            return;
+        if (c->profEvents.size() < next + 2) {
+            size_t old = c->profEvents.size();
+            c->profEvents.resize(next + 2);
+            for (size_t i = old; i < c->profEvents.size(); i++)
+                (void)hipEventCreate(&c->profEvents[i]);
+        }
+        (void)hipEventRecord(c->profEvents[next], c->stream);
+        marks.push_back({ family, next });
+    }
+    void end()
+    {
+        if (!c->profile)
+            return;
+        (void)hipEventRecord(c->profEvents[next + 1], c->stream);
+        next += 2;
+    }
+};
+
+void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t n, uint32_t slotBase, uint32_t pass)
+{
+    Control* ctl = c->control.p;
+    const uint32_t blocks = (std::max(n, 1u) + 255u) / 256u;
+    hipLaunchKernelGGL(k_gen, dim3(blocks), dim3(256), 0, c->stream, fp, c->rays[q].view(), c->identityPixels ? nullptr : c->pixelList.p,
+        first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
+}
+
+void launchIntersect(pt_ctx* c, int q, uint32_t pass)
+{
+    Control* ctl = c->control.p;
+    TraceArgs a = traceArgsBase(c);
+    a.rayO = c->rays[q].o.p;
+    a.rayD = c->rays[q].d.p;
+    a.hit = c->hitH.p;
+    a.inst = c->hitInst.p;
+    a.count = &ctl->extCount[pass];
+    a.cursor = &ctl->extCursor[pass];
+    hipLaunchKernelGGL(k_trace<false>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+}
+
+void launchShadow(pt_ctx* c, uint32_t pass)
+{
+    Control* ctl = c->control.p;
+    TraceArgs a = traceArgsBase(c);
+    a.rayO = c->shadow.o.p;
+    a.rayD = c->shadow.d.p;
+    a.rayC = c->shadow.c.p;
+    a.accum = c->accum;
+    a.count = &ctl->shadowCount[pass];
+    a.cursor = &ctl->shadowCursor[pass];
+    hipLaunchKernelGGL(k_trace<true>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+}
+
+// shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
+void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pass, uint32_t launchEntries)
+{
+    Control* ctl = c->control.p;
+    ShadeArgs a {};
+    a.sc = c->scene;
+    a.fp = fp;
+    a.in = c->rays[in].view();
+    a.hits = { c->hitH.p, c->hitInst.p };
+    a.accum = c->accum;
+    a.inCount = &ctl->extCount[pass];
+    a.outCount = &ctl->extCount[pass + 1];
+    a.shadowCount = &ctl->shadowCount[pass];
+    a.shadeHits = &ctl->shadeHits[pass];
+    a.streams = c->streams.p;
+    const uint32_t blocks = (std::max(launchEntries, 1u) + 255u) / 256u;
+    if (parityMode(c)) {
+        a.out = c->stagedRays.view();
+        a.shadow = c->stagedShadow.view();
+        a.activeFlag = c->activeFlag.p;
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, c->stream, a);
+        CompactArgs ca {};
+        ca.staged = c->stagedRays.view();
+        ca.out = c->rays[out].view();
+        ca.stagedShadow = c->stagedShadow.view();
+        ca.outShadow = c->shadow.view();
+        ca.activeFlag = c->activeFlag.p;
+        ca.inCount = &ctl->extCount[pass];
+        ca.outCount = &ctl->extCount[pass + 1];
+        ca.shadowCount = &ctl->shadowCount[pass];
+        ca.shadeHits = &ctl->shadeHits[pass];
+        hipLaunchKernelGGL(k_compact_stable, dim3(1), dim3(1024), 0, c->stream, ca);
+    } else {
+        a.out = c->rays[out].view();
+        a.shadow = c->shadow.view();
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(256), 0, c->stream, a);
+    }
+}
+
+// Fixed launch schedule for one sample when every owned pixel has its own queue slot: gen, then
+// maxBounces x (intersect, shade, shadow intersect), then the bookkeeping kernel.  No host
+// read-back anywhere (the reference blocks on a 176-byte read every pass, raytracer.cpp:381-389).
+int renderSampleFixed(pt_ctx* c, uint32_t sample, Prof& prof)
+{
+    const FrameParams fp = frameParams(c, sample);
+    const uint32_t bounces = maxBounces(c);
+    prof.begin(0);
+    launchGen(c, fp, 0, 0, c->numOwned, 0, 0);
+    prof.end();
+    int in = 0, out = 1;
+    for (uint32_t b = 0; b < bounces; b++) {
+        prof.begin(1);
+        launchIntersect(c, in, b);
+        prof.end();
+        prof.begin(2);
+        launchShade(c, fp, in, out, b, c->numOwned);
+        prof.end();
+        prof.begin(3);
+        launchShadow(c, b);
+        prof.end();
+        std::swap(in, out);
+    }
+    hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
+    HIPCHK(c, hipGetLastError());
+    return PT_OK;
+}
+
+// General schedule with slot refill (queue smaller than the number of owned pixels) and, in parity
+// mode, exactly the reference's queue bookkeeping (raytracer.cpp:323-427): finished entries stay in
+// the queue for one more pass, the loop ends when shade emits nothing and every pixel was issued.
+// One 4-byte count read-back per pass, as the reference does.
+int renderSampleRefill(pt_ctx* c, uint32_t sample)
+{
+    const FrameParams fp = frameParams(c, sample);
+    Control* ctl = c->control.p;
+    const uint32_t cap = c->capacity;
+    uint32_t issued = 0, surviving = 0, pass = 0;
+    int in = 0, out = 1;
+    Control zero {};
+    while (true) {
+        // every pass reuses index 0/1 of the control block
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, c->stream, &ctl->extCount[0], surviving);
+        HIPCHK(c, hipMemsetAsync(&ctl->extCount[1], 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(&ctl->shadowCount[0], 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(&ctl->extCursor[0], 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(&ctl->shadowCursor[0], 0, sizeof(uint32_t), c->stream));
+        uint32_t newRays = 0;
+        if (surviving != cap) {
+            newRays = std::min(cap - surviving, c->numOwned - issued);
+            if (newRays)
+                launchGen(c, fp, in, issued, newRays, surviving, 0);
+        }
+        const uint32_t entries = surviving + newRays;
+        launchIntersect(c, in, 0);
+        launchShade(c, fp, in, out, 0, entries);
+        uint32_t counts[2] = { 0, 0 };
+        HIPCHK(c, hipMemcpyAsync(&counts[0], &ctl->extCount[1], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&counts[1], &ctl->shadowCount[0], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        issued += newRays;
+        surviving = counts[0];
+        pass++;
+        if (counts[1] != 0)
+            launchShadow(c, 0);
+        // fold this pass into the totals (entries/ shadow counted on the host side of the loop)
+        hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, 0u);
+        if (surviving == 0 && issued >= c->numOwned)
+            break;
+        std::swap(in, out);
+        if (pass > 100000)
+            return fail(c, PT_ERR_STATE, "refill loop did not terminate");
+    }
+    (void)zero;
+    HIPCHK(c, hipGetLastError());
+    return PT_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* pt_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
+
+int pt_create(const pt_config* cfg, pt_ctx** out)
+{
+    if (!cfg || !out)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: null argument");
+    if (cfg->width == 0 || cfg->height == 0 || (uint64_t)cfg->width * cfg->height > 0x7FFFFFFFull)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: bad image size %ux%u", cfg->width, cfg->height);
+    if (cfg->max_bounces > (uint32_t)kMaxPasses - 1)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: max_bounces > %d", kMaxPasses - 1);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, PT_ERR_HIP, "pt_create: no HIP device (%s) -- this library has no CPU fallback", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= count)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: device %d out of range (%d devices)", cfg->device, count);
+    pt_ctx* c = new pt_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    auto bail = [&](hipError_t err, const char* what) {
+        int rc = fail(nullptr, PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(err));
+        delete c;
+        return rc;
+    };
+    if ((e = hipSetDevice(c->device)) != hipSuccess)
+        return bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess)
+        return bail(e, "hipGetDeviceProperties");
+    c->numCUs = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate");
+    c->ownStream = true;
+    if ((e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess)
+        return bail(e, "hipEventCreate");
+    if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemset(c->totals.p, 0, sizeof(Totals))) != hipSuccess)
+        return bail(e, "alloc totals");
+    if ((e = c->accumOwn.alloc((size_t)cfg->width * cfg->height)) != hipSuccess
+        || (e = hipMemset(c->accumOwn.p, 0, (size_t)cfg->width * cfg->height * sizeof(float4))) != hipSuccess)
+        return bail(e, "alloc accumulator");
+    c->accum = c->accumOwn.p;
+    c->numOwned = cfg->width * cfg->height;
+    c->identityPixels = true;
+    *out = c;
+    int rc = pt_set_tiles(c, nullptr, 0);
+    if (rc) {
+        g_createError = c->error;
+        pt_destroy(c);
+        *out = nullptr;
+        return rc;
+    }
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx* c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    DevBuf<float4>* f4[] = { &c->texMaterial, &c->texSky, &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
+        &c->rays[1].d, &c->rays[1].thr, &c->stagedRays.o, &c->stagedRays.d, &c->stagedRays.thr, &c->shadow.o, &c->shadow.d, &c->shadow.c,
+        &c->stagedShadow.o, &c->stagedShadow.d, &c->stagedShadow.c };
+    for (auto* b : f4)
+        b->release();
+    c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
+    c->top.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
+    for (hipEvent_t ev : c->profEvents)
+        (void)hipEventDestroy(ev);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pt_set_stream(pt_ctx* c, void* hip_stream)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ownStream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->ownStream = false;
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->ownStream = true;
+    }
+    return PT_OK;
+}
+
+int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if (!verts || !tris || !mats || !nodes || nV == 0 || nT == 0 || nM == 0 || nN == 0)
+        return fail(c, PT_ERR_INVALID, "pt_upload_static: empty or null scene array");
+    if (nT > kRefIndexMask || nN > kRefIndexMask)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_upload_static: more than 2^27 triangle references or nodes");
+    HIPCHK(c, hipSetDevice(c->device));
+    // ---- validate: every index in range, children after their parent (rules out cycles) -----
+    for (uint32_t t = 0; t < nT; t++) {
+        if (tris[t].indices[0] >= nV || tris[t].indices[1] >= nV || tris[t].indices[2] >= nV)
+            return fail(c, PT_ERR_INVALID, "triangle %u: vertex index out of range", t);
+        if (tris[t].materialIndex >= nM)
+            return fail(c, PT_ERR_INVALID, "triangle %u: material index out of range", t);
+    }
+    // An inner node whose children do not lie strictly after it is an unused pad (the reference's pair
+    // allocator leaves one next to every root); pads may not be referenced.
+    auto isPad = [&](uint32_t i) {
+        const uint32_t l = nodes[i].leftChildOrFirstTriangle;
+        return nodes[i].triangleCount == 0 && (l <= i || (uint64_t)l + 1 >= nN);
+    };
+    for (uint32_t i = 0; i < nN; i++) {
+        const pt_sub_bvh_node& n = nodes[i];
+        if (n.triangleCount != 0 && (uint64_t)n.leftChildOrFirstTriangle + n.triangleCount > nT)
+            return fail(c, PT_ERR_INVALID, "sub-BVH leaf %u: triangle range out of bounds", i);
+    }
+
+    // ---- triangles / vertices / materials ------------------------------------------------------
+    std::vector<TriIsect> hTris(nT);
+    std::vector<TriShade> hShade(nT);
+    auto P = [&](uint32_t vi) { return mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]); };
+    for (uint32_t t = 0; t < nT; t++) {
+        const V3 v0 = P(tris[t].indices[0]);
+        const V3 e1 = P(tris[t].indices[1]) - v0, e2 = P(tris[t].indices[2]) - v0; // shapes.cl:37-38
+        hTris[t].a = make_float4(v0.x, v0.y, v0.z, e1.x);
+        hTris[t].b = make_float4(e1.y, e1.z, e2.x, e2.y);
+        hTris[t].c = make_float4(e2.z, 0.f, 0.f, 0.f);
+        hShade[t] = { tris[t].indices[0], tris[t].indices[1], tris[t].indices[2], tris[t].materialIndex };
+    }
+    std::vector<VertexShade> hVerts(nV);
+    for (uint32_t v = 0; v < nV; v++) {
+        hVerts[v].n_u = make_float4(verts[v].normal[0], verts[v].normal[1], verts[v].normal[2], verts[v].texCoord[0]);
+        hVerts[v].v_pad = make_float4(verts[v].texCoord[1], 0.f, 0.f, 0.f);
+    }
+    std::vector<Material> hMats(nM);
+    static_assert(sizeof(Material) == sizeof(pt_material), "material record is copied verbatim");
+    std::memcpy(hMats.data(), mats, (size_t)nM * sizeof(pt_material));
+
+    // ---- pair nodes ----------------------------------------------------------------------------
+    std::vector<uint32_t> dense(nN, 0xFFFFFFFFu);
+    uint32_t numInner = 0;
+    for (uint32_t i = 0; i < nN; i++)
+        if (nodes[i].triangleCount == 0 && !isPad(i))
+            dense[i] = numInner++;
+    std::vector<PairNode> hNodes(numInner);
+    auto triBox = [&](uint32_t t, V3& lo, V3& hi) {
+        for (int k = 0; k < 3; k++) {
+            const V3 p = P(tris[t].indices[k]);
+            lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
+            hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+        }
+    };
+    // leaves larger than kMaxLeafTris become a small median-split subtree over their triangle range
+    struct Range {
+        uint32_t first, count;
+    };
+    std::function<uint32_t(Range, V3&, V3&)> leafRef = [&](Range r, V3& lo, V3& hi) -> uint32_t {
+        lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
+        if (r.count <= kMaxLeafTris) {
+            for (uint32_t t = 0; t < r.count; t++)
+                triBox(r.first + t, lo, hi);
+            return makeRef(r.first, r.count);
+        }
+        const uint32_t half = r.count / 2;
+        V3 llo, lhi, rlo, rhi;
+        const uint32_t l = leafRef({ r.first, half }, llo, lhi);
+        const uint32_t rr = leafRef({ r.first + half, r.count - half }, rlo, rhi);
+        PairNode pn {};
+        pn.bx = make_float4(llo.x, lhi.x, rlo.x, rhi.x);
+        pn.by = make_float4(llo.y, lhi.y, rlo.y, rhi.y);
+        pn.bz = make_float4(llo.z, lhi.z, rlo.z, rhi.z);
+        pn.left = l;
+        pn.right = rr;
+        lo = mk(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z));
+        hi = mk(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z));
+        hNodes.push_back(pn);
+        return makeRef((uint32_t)hNodes.size() - 1, 0);
+    };
+    c->nodeRef.assign(nN, kRefNone);
+    for (uint32_t i = 0; i < nN; i++) {
+        if (nodes[i].triangleCount != 0) {
+            if (nodes[i].triangleCount <= kMaxLeafTris) {
+                c->nodeRef[i] = makeRef(nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount);
+            } else {
+                V3 lo, hi;
+                c->nodeRef[i] = leafRef({ nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount }, lo, hi);
+            }
+        } else if (dense[i] != 0xFFFFFFFFu) {
+            c->nodeRef[i] = makeRef(dense[i], 0);
+        }
+    }
+    for (uint32_t i = 0; i < nN; i++) {
+        if (dense[i] == 0xFFFFFFFFu)
+            continue;
+        const uint32_t l = nodes[i].leftChildOrFirstTriangle;
+        const pt_sub_bvh_node& L = nodes[l];
+        const pt_sub_bvh_node& R = nodes[l + 1];
+        PairNode pn {};
+        pn.bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
+        pn.by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
+        pn.bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
+        pn.left = c->nodeRef[l];
+        pn.right = c->nodeRef[l + 1];
+        if (pn.left == kRefNone || pn.right == kRefNone)
+            return fail(c, PT_ERR_INVALID, "sub-BVH node %u: child is an unused pad node", i);
+        hNodes[dense[i]] = pn;
+    }
+    // depth of every subtree (children have larger indices: one reverse sweep), for the stack bound
+    c->subtreeDepth.assign(nN, 0);
+    for (uint32_t i = nN; i-- > 0;) {
+        if (dense[i] == 0xFFFFFFFFu) {
+            uint32_t extra = 0;
+            for (uint32_t cnt = nodes[i].triangleCount; cnt > kMaxLeafTris; cnt = (cnt + 1) / 2)
+                extra++;
+            c->subtreeDepth[i] = extra;
+        } else {
+            const uint32_t l = nodes[i].leftChildOrFirstTriangle;
+            c->subtreeDepth[i] = 1 + std::max(c->subtreeDepth[l], c->subtreeDepth[l + 1]);
+        }
+    }
+    if (hNodes.size() > kRefIndexMask)
+        return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
+
+    int rc;
+    if ((rc = uploadVec(c, c->tris, hTris)) || (rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
+        || (rc = uploadVec(c, c->materials, hMats)) || (rc = uploadVec(c, c->nodes, hNodes)))
+        return rc;
+    c->numRefNodes = nN;
+    c->numTris = nT;
+    c->haveStatic = true;
+    c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
+    refreshSceneView(c);
+    return PT_OK;
+}
+
+int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic)
+        return fail(c, PT_ERR_STATE, "pt_upload_dynamic: call pt_upload_static first");
+    if (!topNodes || nTop == 0 || topRoot >= nTop)
+        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: bad top-level BVH");
+    if (nL > 0 && !lights)
+        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
+    HIPCHK(c, hipSetDevice(c->device));
+
+    std::vector<TopNode> hTop(nTop);
+    std::vector<Instance> hInst;
+    c->instanceTopNode.clear();
+    for (uint32_t i = 0; i < nTop; i++) {
+        const pt_top_bvh_node& n = topNodes[i];
+        uint32_t a, b;
+        if (n.isLeaf) {
+            if (n.a >= c->numRefNodes || c->nodeRef[n.a] == kRefNone)
+                return fail(c, PT_ERR_INVALID, "top-level leaf %u: sub-BVH root %u is not a valid node", i, n.a);
+            if (c->subtreeDepth[n.a] + 1 > (uint32_t)(kLdsStack + kSpillStack))
+                return fail(c, PT_ERR_UNSUPPORTED, "top-level leaf %u: sub-BVH depth %u exceeds the traversal stack (%d)", i, c->subtreeDepth[n.a], kLdsStack + kSpillStack);
+            Instance in {};
+            const float* m = n.invTransform; // column-major
+            in.r0 = make_float4(m[0], m[4], m[8], m[12]);
+            in.r1 = make_float4(m[1], m[5], m[9], m[13]);
+            in.r2 = make_float4(m[2], m[6], m[10], m[14]);
+            in.rootRef = c->nodeRef[n.a];
+            in.topNode = i;
+            a = (uint32_t)hInst.size();
+            b = 0xFFFFFFFFu;
+            hInst.push_back(in);
+            c->instanceTopNode.push_back(i);
+        } else {
+            if (n.a >= nTop || n.b >= nTop)
+                return fail(c, PT_ERR_INVALID, "top-level node %u: child out of range", i);
+            a = n.a;
+            b = n.b;
+        }
+        uint32_t ua = a, ub = b;
+        float fa, fb;
+        std::memcpy(&fa, &ua, 4);
+        std::memcpy(&fb, &ub, 4);
+        hTop[i].lo = make_float4(n.min[0], n.min[1], n.min[2], fa);
+        hTop[i].hi = make_float4(n.max[0], n.max[1], n.max[2], fb);
+    }
+    { // depth / cycle check from the root
+        std::vector<std::pair<uint32_t, uint32_t>> st { { topRoot, 1u } };
+        size_t visited = 0;
+        while (!st.empty()) {
+            auto [ni, depth] = st.back();
+            st.pop_back();
+            if (++visited > nTop)
+                return fail(c, PT_ERR_INVALID, "top-level BVH is not a tree");
+            if (depth + 1 > (uint32_t)kTopStack)
+                return fail(c, PT_ERR_UNSUPPORTED, "top-level BVH deeper than %d", kTopStack - 1);
+            if (!topNodes[ni].isLeaf) {
+                st.push_back({ topNodes[ni].a, depth + 1 });
+                st.push_back({ topNodes[ni].b, depth + 1 });
+            }
+        }
+    }
+    std::vector<Light> hLights(nL);
+    for (uint32_t i = 0; i < nL; i++) {
+        const pt_emissive_triangle& e = lights[i];
+        const V3 v0 = mk(e.vertices[0][0], e.vertices[0][1], e.vertices[0][2]);
+        const V3 v1 = mk(e.vertices[1][0], e.vertices[1][1], e.vertices[1][2]);
+        const V3 v2 = mk(e.vertices[2][0], e.vertices[2][1], e.vertices[2][2]);
+        // Heron's formula (shading_helper.cl:204-214)
+        const V3 A = v1 - v0, B = v2 - v1, C = v0 - v2;
+        const float la = sqrtf(dot(A, A)), lb = sqrtf(dot(B, B)), lc = sqrtf(dot(C, C));
+        const float s = (la + lb + lc) / 2.0f;
+        const float area = sqrtf(s * (s - la) * (s - lb) * (s - lc));
+        const V3 nrm = normalize(cross(v1 - v0, v2 - v0));
+        hLights[i].v0 = make_float4(v0.x, v0.y, v0.z, area);
+        hLights[i].v1 = make_float4(v1.x, v1.y, v1.z, 0.f);
+        hLights[i].v2 = make_float4(v2.x, v2.y, v2.z, 0.f);
+        hLights[i].normal = make_float4(nrm.x, nrm.y, nrm.z, 0.f);
+        hLights[i].colour = make_float4(e.material.u.emissive.emissiveColour[0], e.material.u.emissive.emissiveColour[1], e.material.u.emissive.emissiveColour[2], 0.f);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = uploadVec(c, c->top, hTop)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+        return rc;
+    c->scene.numLights = nL;
+    c->scene.topRoot = topRoot;
+    c->haveDynamic = true;
+    refreshSceneView(c);
+    return PT_OK;
+}
+
+int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height, uint32_t layers, const float* rgba)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if ((kind != 0 && kind != 1) || !rgba || width == 0 || height == 0 || layers == 0)
+        return fail(c, PT_ERR_INVALID, "pt_upload_texture_array: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DevBuf<float4>& buf = kind == 0 ? c->texMaterial : c->texSky;
+    const size_t n = (size_t)width * height * layers;
+    HIPCHK(c, buf.alloc(n));
+    HIPCHK(c, hipMemcpy(buf.p, rgba, n * sizeof(float4), hipMemcpyHostToDevice));
+    Texture& t = kind == 0 ? c->scene.materialTex : c->scene.sky;
+    t.width = (int)width;
+    t.height = (int)height;
+    t.layers = (int)layers;
+    refreshSceneView(c);
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx* c, const pt_camera* cam)
+{
+    if (!c || !cam)
+        return PT_ERR_INVALID;
+    auto f4 = [](const float* p) { return make_float4(p[0], p[1], p[2], 0.f); };
+    c->camera.eye = f4(cam->eyePoint);
+    c->camera.screen = f4(cam->screenPoint);
+    c->camera.u = f4(cam->u);
+    c->camera.v = f4(cam->v);
+    c->camera.uN = f4(cam->uNormalized);
+    c->camera.vN = f4(cam->vNormalized);
+    c->camera.focalDistance = cam->focalDistance;
+    c->camera.apertureRadius = cam->apertureRadius;
+    c->camera.relativeAperture = cam->relativeAperture;
+    c->camera.shutterTime = cam->shutterTime;
+    c->camera.ISO = cam->ISO;
+    c->camera.thinLens = cam->thinLensEnabled ? 1u : 0u;
+    c->haveCamera = true;
+    return PT_OK;
+}
+
+int pt_set_tiles(pt_ctx* c, const pt_rect* rects, uint32_t n)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t W = c->cfg.width, H = c->cfg.height;
+    pt_rect whole { 0, 0, W, H };
+    if (n == 0 || !rects) {
+        rects = &whole;
+        n = 1;
+    }
+    const bool rowMajor = (c->cfg.flags & PT_FLAG_ROWMAJOR_PIXELS) || parityMode(c);
+    std::vector<uint32_t> list;
+    for (uint32_t r = 0; r < n; r++) {
+        const pt_rect& q = rects[r];
+        if (q.x0 >= q.x1 || q.y0 >= q.y1 || q.x1 > W || q.y1 > H)
+            return fail(c, PT_ERR_INVALID, "pt_set_tiles: rect %u out of bounds", r);
+        if (rowMajor) {
+            for (uint32_t y = q.y0; y < q.y1; y++)
+                for (uint32_t x = q.x0; x < q.x1; x++)
+                    list.push_back(y * W + x);
+        } else { // 8x8 pixel blocks: a 64-lane wave starts on a compact screen-space tile
+            for (uint32_t by = q.y0; by < q.y1; by += 8)
+                for (uint32_t bx = q.x0; bx < q.x1; bx += 8)
+                    for (uint32_t y = by; y < std::min(by + 8, q.y1); y++)
+                        for (uint32_t x = bx; x < std::min(bx + 8, q.x1); x++)
+                            list.push_back(y * W + x);
+        }
+    }
+    if (list.size() > (size_t)W * H)
+        return fail(c, PT_ERR_INVALID, "pt_set_tiles: rectangles overlap");
+    c->identityPixels = rowMajor && n == 1 && rects[0].x0 == 0 && rects[0].y0 == 0 && rects[0].x1 == W && rects[0].y1 == H;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = uploadVec(c, c->pixelList, list);
+    if (rc)
+        return rc;
+    if ((uint32_t)list.size() != c->numOwned || !c->queuesReady) {
+        c->numOwned = (uint32_t)list.size();
+        c->queuesReady = false; // re-size queues lazily
+    }
+    return PT_OK;
+}
+
+int pt_set_accum_buffer(pt_ctx* c, void* device_float4)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->accum = device_float4 ? (float4*)device_float4 : c->accumOwn.p;
+    return PT_OK;
+}
+
+int pt_clear(pt_ctx* c)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)c->cfg.width * c->cfg.height * sizeof(float4), c->stream));
+    c->spp = 0;
+    if (parityMode(c) && c->queuesReady) {
+        int rc = resetStreams(c);
+        if (rc)
+            return rc;
+    }
+    return PT_OK;
+}
+
+int pt_render(pt_ctx* c, uint32_t spp)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic || !c->haveDynamic || !c->haveCamera)
+        return fail(c, PT_ERR_STATE, "pt_render: scene (static + dynamic) and camera must be set first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensureQueues(c)) || (rc = ensureSpill(c)))
+        return rc;
+    Prof prof { c };
+    HIPCHK(c, hipEventRecord(c->evStart, c->stream));
+    const bool fixedSchedule = !parityMode(c) && c->capacity >= c->numOwned;
+    for (uint32_t s = 0; s < spp; s++) {
+        rc = fixedSchedule ? renderSampleFixed(c, c->spp, prof) : renderSampleRefill(c, c->spp);
+        if (rc)
+            return rc;
+        c->spp++;
+    }
+    HIPCHK(c, hipEventRecord(c->evStop, c->stream));
+    if (c->profile) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double fam[4] = { 0, 0, 0, 0 };
+        for (auto& m : prof.marks) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->profEvents[m.second], c->profEvents[m.second + 1]);
+            fam[m.first] += ms;
+        }
+        c->msGen = fam[0], c->msIntersect = fam[1], c->msShade = fam[2], c->msShadow = fam[3];
+    }
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_resolve(pt_ctx* c, float* rgba_out)
+{
+    if (!c || !rgba_out)
+        return PT_ERR_INVALID;
+    if (!c->haveCamera || c->spp == 0)
+        return fail(c, PT_ERR_STATE, "pt_resolve: nothing rendered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->cfg.width * c->cfg.height;
+    DevBuf<float4> tmp;
+    HIPCHK(c, tmp.alloc(n));
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, tmp.p, n, (float)c->spp,
+        c->camera.relativeAperture, c->camera.shutterTime, c->camera.ISO);
+    hipError_t e = hipMemcpyAsync(rgba_out, tmp.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    HIPCHK(c, e);
+    return PT_OK;
+}
+
+int pt_read_accum(pt_ctx* c, float* out)
+{
+    if (!c || !out)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->accum, (size_t)c->cfg.width * c->cfg.height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_write_accum(pt_ctx* c, const float* in, uint32_t spp)
+{
+    if (!c || !in)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->accum, in, (size_t)c->cfg.width * c->cfg.height * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->spp = spp;
+    return PT_OK;
+}
+
+void* pt_accum_device_ptr(pt_ctx* c) { return c ? (void*)c->accum : nullptr; }
+
+uint32_t pt_samples_per_pixel(const pt_ctx* c) { return c ? c->spp : 0; }
+
+int pt_stats_get(pt_ctx* c, pt_stats* out)
+{
+    if (!c || !out)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Totals t {};
+    HIPCHK(c, hipMemcpy(&t, c->totals.p, sizeof(Totals), hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof(*out));
+    out->rays_extension = t.raysExtension;
+    out->rays_shadow = t.raysShadow;
+    out->rays_generated = t.raysGenerated;
+    out->shade_hits = t.shadeHits;
+    out->deposits = t.deposits;
+    out->samples = c->spp;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess)
+        c->msLastRender = ms;
+    out->ms_last_render = c->msLastRender;
+    out->ms_intersect = c->msIntersect;
+    out->ms_shade = c->msShade;
+    out->ms_shadow = c->msShadow;
+    out->ms_gen = c->msGen;
+    return PT_OK;
+}
+
+int pt_stats_reset(pt_ctx* c)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
+    return PT_OK;
+}
+
+int pt_profile_kernels(pt_ctx* c, int enable)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    c->profile = enable != 0;
+    return PT_OK;
+}
+
+int pt_reduce_accum(pt_ctx* c, void* nccl_comm, int root)
+{
+    (void)nccl_comm;
+    (void)root;
+    // The accumulator is exposed as device memory (pt_accum_device_ptr / pt_set_accum_buffer) so that the
+    // caller's communicator reduces it: bench.py does torch.distributed.reduce (RCCL) on a tensor that
+    // aliases it.  Linking librccl into this library is deferred.
+    return fail(c, PT_ERR_UNSUPPORTED, "pt_reduce_accum: reduce the buffer of pt_accum_device_ptr() with the caller's RCCL communicator");
+}
+
+// ---- kernel-granular hooks ---------------------------------------------------------------------
+
+int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt_hits_soa* hits, uint32_t repeat, float* ms_out)
+{
+    if (!c || !rays || !hits || n == 0)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic || !c->haveDynamic)
+        return fail(c, PT_ERR_STATE, "pt_intersect: upload the scene first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensureSpill(c);
+    if (rc)
+        return rc;
+    std::vector<float4> hO(n), hD(n), hC(n);
+    for (uint32_t i = 0; i < n; i++) {
+        hO[i] = make_float4(rays->ox[i], rays->oy[i], rays->oz[i], any_hit ? rays->tmax[i] : 0.f);
+        hD[i] = make_float4(rays->dx[i], rays->dy[i], rays->dz[i], 0.f); // pixel / flags = 0
+        hC[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    DevBuf<float4> dO, dD, dC, dH, dAcc;
+    DevBuf<int32_t> dI;
+    DevBuf<uint32_t> dOcc, dCtl;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x) {
+        if (e == hipSuccess)
+            e = x;
+    };
+    chk(dO.alloc(n)), chk(dD.alloc(n)), chk(dC.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dOcc.alloc(n)), chk(dAcc.alloc(1)), chk(dCtl.alloc(2));
+    if (e == hipSuccess) {
+        chk(hipMemcpy(dO.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(dD.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(dC.p, hC.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemset(dAcc.p, 0, sizeof(float4)));
+    }
+    float msTotal = 0;
+    repeat = std::max(repeat, 1u);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    chk(hipEventCreate(&e0));
+    chk(hipEventCreate(&e1));
+    for (uint32_t r = 0; r < repeat && e == hipSuccess; r++) {
+        uint32_t ctl[2] = { n, 0 };
+        chk(hipMemcpyAsync(dCtl.p, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+        TraceArgs a = traceArgsBase(c);
+        a.parityShadow = 0;
+        a.rayO = dO.p, a.rayD = dD.p, a.rayC = dC.p;
+        a.hit = dH.p, a.inst = dI.p, a.accum = dAcc.p, a.occluded = dOcc.p;
+        a.count = dCtl.p, a.cursor = dCtl.p + 1;
+        chk(hipEventRecord(e0, c->stream));
+        if (any_hit)
+            hipLaunchKernelGGL(k_trace<true>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(k_trace<false>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+        chk(hipEventRecord(e1, c->stream));
+        chk(hipStreamSynchronize(c->stream));
+        chk(hipGetLastError());
+        float ms = 0;
+        chk(hipEventElapsedTime(&ms, e0, e1));
+        msTotal += ms;
+    }
+    if (e == hipSuccess) {
+        if (any_hit) {
+            std::vector<uint32_t> occ(n);
+            chk(hipMemcpy(occ.data(), dOcc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; i++)
+                hits->prim[i] = (int32_t)occ[i];
+        } else {
+            std::vector<float4> h(n);
+            std::vector<int32_t> in(n);
+            chk(hipMemcpy(h.data(), dH.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+            chk(hipMemcpy(in.data(), dI.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; i++) {
+                hits->t[i] = h[i].x, hits->u[i] = h[i].y, hits->v[i] = h[i].z;
+                int32_t prim;
+                std::memcpy(&prim, &h[i].w, 4);
+                hits->prim[i] = prim;
+                hits->inst[i] = (in[i] >= 0 && (size_t)in[i] < c->instanceTopNode.size()) ? (int32_t)c->instanceTopNode[in[i]] : -1;
+            }
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dO.release(), dD.release(), dC.release(), dH.release(), dI.release(), dOcc.release(), dAcc.release(), dCtl.release();
+    if (ms_out)
+        *ms_out = msTotal / (float)repeat;
+    HIPCHK(c, e);
+    return PT_OK;
+}
+
+int pt_gen_rays(pt_ctx* c, uint32_t sample, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel)
+{
+    if (!c || n == 0)
+        return PT_ERR_INVALID;
+    if (!c->haveCamera)
+        return fail(c, PT_ERR_STATE, "pt_gen_rays: set the camera first");
+    if (n > c->numOwned)
+        return fail(c, PT_ERR_INVALID, "pt_gen_rays: n exceeds the owned pixels");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensureQueues(c);
+    if (rc)
+        return rc;
+    if (n > c->capacity)
+        return fail(c, PT_ERR_INVALID, "pt_gen_rays: n exceeds the queue capacity");
+    FrameParams fp = frameParams(c, sample);
+    launchGen(c, fp, 0, 0, n, 0, 0);
+    std::vector<float4> o(n), d(n);
+    HIPCHK(c, hipMemcpyAsync(o.data(), c->rays[0].o.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.data(), c->rays[0].d.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        if (ox) ox[i] = o[i].x;
+        if (oy) oy[i] = o[i].y;
+        if (oz) oz[i] = o[i].z;
+        if (dx) dx[i] = d[i].x;
+        if (dy) dy[i] = d[i].y;
+        if (dz) dz[i] = d[i].z;
+        if (pixel)
+            std::memcpy(&pixel[i], &o[i].w, 4);
+    }
+    return PT_OK;
+}
+
+int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
+{
+    if (!c || !io || io->n == 0)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic || !c->haveDynamic)
+        return fail(c, PT_ERR_STATE, "pt_shade_batch: upload the scene first");
+    if (parityMode(c))
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_shade_batch uses the counter PRNG keying");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = io->n;
+    // instance index from the reported top-level leaf
+    std::vector<int32_t> topToInst;
+    for (size_t k = 0; k < c->instanceTopNode.size(); k++) {
+        if (c->instanceTopNode[k] >= topToInst.size())
+            topToInst.resize(c->instanceTopNode[k] + 1, -1);
+        topToInst[c->instanceTopNode[k]] = (int32_t)k;
+    }
+    std::vector<float4> hO(n), hD(n), hT(n), hH(n);
+    std::vector<int32_t> hI(n);
+    for (uint32_t i = 0; i < n; i++) {
+        float fp, ff, fprim;
+        uint32_t px = io->pixel[i], fl = (io->flags[i] & 0xFFu) | (io->bounce[i] << 8);
+        int32_t prim = io->prim[i];
+        std::memcpy(&fp, &px, 4), std::memcpy(&ff, &fl, 4), std::memcpy(&fprim, &prim, 4);
+        hO[i] = make_float4(io->ox[i], io->oy[i], io->oz[i], fp);
+        hD[i] = make_float4(io->dx[i], io->dy[i], io->dz[i], ff);
+        hT[i] = make_float4(io->thr_r[i], io->thr_g[i], io->thr_b[i], 0.f);
+        hH[i] = make_float4(prim >= 0 ? io->t[i] : INFINITY, io->u[i], io->v[i], fprim);
+        int32_t ti = io->inst[i];
+        hI[i] = (ti >= 0 && (size_t)ti < topToInst.size()) ? topToInst[ti] : -1;
+        if (prim >= 0 && (hI[i] < 0 || (uint32_t)prim >= c->numTris))
+            return fail(c, PT_ERR_INVALID, "pt_shade_batch: entry %u has an invalid prim/inst", i);
+    }
+    RayQueueBuf in, out, stagedDummy;
+    ShadowQueueBuf sh;
+    DevBuf<float4> dH, dAcc;
+    DevBuf<int32_t> dI;
+    DevBuf<uint32_t> dCtl;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x) {
+        if (e == hipSuccess)
+            e = x;
+    };
+    chk(in.o.alloc(n)), chk(in.d.alloc(n)), chk(in.thr.alloc(n)), chk(out.o.alloc(n)), chk(out.d.alloc(n)), chk(out.thr.alloc(n));
+    chk(sh.o.alloc(n)), chk(sh.d.alloc(n)), chk(sh.c.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dCtl.alloc(4));
+    const size_t npix = (size_t)c->cfg.width * c->cfg.height;
+    chk(dAcc.alloc(npix));
+    // per-entry outputs are needed, so every entry is shaded as its own 1-entry queue slice
+    (void)stagedDummy;
+    if (e == hipSuccess) {
+        chk(hipMemcpy(in.o.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(in.d.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(in.thr.p, hT.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(dH.p, hH.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        chk(hipMemcpy(dI.p, hI.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    std::vector<float4> acc(npix);
+    FrameParams fp = frameParams(c, io->sample);
+    for (uint32_t i = 0; i < n && e == hipSuccess; i++) {
+        // pixel-indexed accumulator: clear only the touched pixel
+        uint32_t ctl[4] = { 1, 0, 0, 0 }; // inCount, outCount, shadowCount, shadeHits
+        chk(hipMemcpyAsync(dCtl.p, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+        chk(hipMemsetAsync(dAcc.p + io->pixel[i], 0, sizeof(float4), c->stream));
+        ShadeArgs a {};
+        a.sc = c->scene;
+        a.fp = fp;
+        a.in = { in.o.p + i, in.d.p + i, in.thr.p + i };
+        a.hits = { dH.p + i, dI.p + i };
+        a.out = { out.o.p + i, out.d.p + i, out.thr.p + i };
+        a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
+        a.accum = dAcc.p;
+        a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3;
+        hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
+        uint32_t back[4];
+        float4 px;
+        chk(hipMemcpyAsync(back, dCtl.p, sizeof(back), hipMemcpyDeviceToHost, c->stream));
+        chk(hipMemcpyAsync(&px, dAcc.p + io->pixel[i], sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        chk(hipStreamSynchronize(c->stream));
+        io->out_alive[i] = back[1];
+        io->shadow_alive[i] = back[2];
+        io->radiance[3 * i] = px.x, io->radiance[3 * i + 1] = px.y, io->radiance[3 * i + 2] = px.z;
+    }
+    if (e == hipSuccess) {
+        std::vector<float4> o(n), d(n), t(n), so(n), sd(n), sc(n);
+        chk(hipMemcpy(o.data(), out.o.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        chk(hipMemcpy(d.data(), out.d.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        chk(hipMemcpy(t.data(), out.thr.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        chk(hipMemcpy(so.data(), sh.o.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        chk(hipMemcpy(sd.data(), sh.d.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        chk(hipMemcpy(sc.data(), sh.c.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            if (io->out_alive[i]) {
+                io->nox[i] = o[i].x, io->noy[i] = o[i].y, io->noz[i] = o[i].z;
+                io->ndx[i] = d[i].x, io->ndy[i] = d[i].y, io->ndz[i] = d[i].z;
+                io->nthr_r[i] = t[i].x, io->nthr_g[i] = t[i].y, io->nthr_b[i] = t[i].z;
+                uint32_t fl;
+                std::memcpy(&fl, &d[i].w, 4);
+                io->nflags[i] = fl & 0xFFu;
+            }
+            if (io->shadow_alive[i]) {
+                io->sox[i] = so[i].x, io->soy[i] = so[i].y, io->soz[i] = so[i].z, io->slen[i] = so[i].w;
+                io->sdx[i] = sd[i].x, io->sdy[i] = sd[i].y, io->sdz[i] = sd[i].z;
+                io->sc_r[i] = sc[i].x, io->sc_g[i] = sc[i].y, io->sc_b[i] = sc[i].z;
+            }
+        }
+    }
+    in.o.release(), in.d.release(), in.thr.release(), out.o.release(), out.d.release(), out.thr.release();
+    sh.o.release(), sh.d.release(), sh.c.release(), dH.release(), dI.release(), dCtl.release(), dAcc.release();
+    HIPCHK(c, e);
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+"""In-tree builds: libptamd_host.so (g++) and libptamd.so (hipcc, gfx950 code objects, no JIT)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(_HERE, ".."))
+HOST_DIR = os.path.join(ROOT, "host")
+CSRC_DIR = os.path.join(ROOT, "csrc")
+HOST_SOURCES = ["bvh_build.cpp", "mesh.cpp", "scene.cpp", "capi.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _all_files(d, exts):
+    return [os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)]
+
+
+def build_host(force=False):
+    out = os.path.join(HOST_DIR, "libptamd_host.so")
+    deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
+    if force or _newer(out, deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + HOST_SOURCES + ["-o", out],
+                       cwd=HOST_DIR, check=True)
+    return out
+
+
+def build_device(force=False):
+    out = os.path.join(CSRC_DIR, "libptamd.so")
+    deps = _all_files(CSRC_DIR, (".hip", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
+    if force or _newer(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "ptamd.hip", "-o", out],
+                       cwd=CSRC_DIR, check=True)
+    return out
+
+
+def build_all(force=False):
+    return build_host(force), build_device(force)
