@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the ray-queue render path on the ~1M-triangle two-level-BVH scene at
+1080p (BASELINE.json metric), one process per GPU.
+
+A *step* is one pass of the hot path over one batch: `4*N*R` samples per pixel for the pixels this rank
+owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~8.3 M path
+segments per launch on every rank.  Image tiles (32x32, interleaved) shard across ranks, every rank
+traces the same number of paths per step whatever N is (weak scaling: the image simply receives N x
+more samples per step), and there is no data-path collective: the only exchange is ONE RCCL reduce of
+the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the timed
+region.  A ray = one traceRay invocation on a live queue entry (extension or shadow), counted by the
+device queues.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live for the dominant kernel (k_trace<false>,
+closest-hit traversal) with HIP events on the render stream in a separate, profiled pass;
+`cpu_baseline` times the oracle (our CPU restatement of the reference's path -- the reference has no CPU
+traversal code) on this box's host cores over a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
+BYTES_PER_EXT_RAY = 48  # closest-hit intersect reads 28 B ray, writes 20 B hit record
+
+
+def tile_rects(width, height, rank, world, tile=32):
+    rects, t = [], 0
+    for y in range(0, height, tile):
+        for x in range(0, width, tile):
+            if t % world == rank:
+                rects.append((x, y, min(x + tile, width), min(y + tile, height)))
+            t += 1
+    return rects
+
+
+def cpu_baseline(bundle, seconds, width, height):
+    """Oracle (kind 'port') on all host cores: 1 spp over 8x8 pixel blocks spread over the frame,
+    extended block by block until `seconds` of wall time are used."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib as O  # checker / reported baseline only
+    O.build(fast=True, ref=False)  # -O3 -march=native for THIS host
+    cores = os.cpu_count() or 1
+    sc = O.BoundScene(bundle.flat, sky=bundle.sky, material_textures=bundle.material_textures)
+    bx, by = width // 8, height // 8
+    order = np.random.default_rng(0).permutation(bx * by)
+    yy, xx = np.mgrid[0:8, 0:8]
+    rays, pixels_done, t_used, chunk, pos = 0, 0, 0.0, 256, 0
+    while t_used < seconds and pos < len(order):
+        blocks = order[pos:pos + chunk]
+        pos += len(blocks)
+        px = (((blocks // bx)[:, None, None] * 8 + yy) * width + (blocks % bx)[:, None, None] * 8 + xx).reshape(-1)
+        t0 = time.perf_counter()
+        _, cnt = O.render(sc, bundle.camera, width, height, 1, seed=1, pixels=px.astype(np.uint32), threads=cores, fast=True)
+        t_used += time.perf_counter() - t0
+        rays += cnt["raysExtension"] + cnt["raysShadow"]
+        pixels_done += len(px)
+        chunk = min(chunk * 2, 4096)
+    return {"value": round(rays / t_used / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{pixels_done} pixels (random 8x8 blocks of the {width}x{height} frame) x 1 spp, "
+                      f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rounds", type=int, default=2, help="batches of 4*N samples per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    from ptamd import device as D, host as H, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, Hh = args.width, args.height
+    bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT)
+    flat = bundle.flat
+    in_flight = min(4 * world, 64)
+    ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight)
+    ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
+    ctx.set_camera(bundle.camera)
+    if world > 1:
+        ctx.set_tiles(tile_rects(W, Hh, rank, world))
+    # torch owns the accumulator and the stream: device memory + streams + collectives are its job here
+    accum = torch.zeros(W * Hh, 4, device="cuda", dtype=torch.float32)
+    ctx.set_accum_buffer(accum.data_ptr())
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    spp_step = in_flight * args.rounds
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.render(spp_step, sync=False)
+    barrier()
+    ctx.clear()
+    ctx.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render(spp_step, sync=False)
+    if world > 1:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # the one exchange step: HDR accumulator over xGMI
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = ctx.stats()
+    counts = torch.tensor([st["rays_extension"], st["rays_shadow"], st["rays_generated"], st["shade_hits"]],
+                          dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ext, shadow, gen, hits = (float(x) for x in counts.tolist())
+    elapsed = float(tmax.item())
+    total_rays = ext + shadow
+    image_mean = float(accum[:, :3].mean().item()) / max(ctx.samples_per_pixel, 1) if rank == 0 else 0.0
+
+    roofline = None
+    if not args.no_roofline:
+        # profiled pass (HIP events around every launch, on the render stream); not part of the timed steps
+        ctx.reset_stats()
+        ctx.profile_kernels(True)
+        ctx.render(spp_step, sync=True)
+        ps = ctx.stats()
+        ctx.profile_kernels(False)
+        launches = 4 * (spp_step // in_flight)  # closest-hit launches: one per bounce per batch
+        rays_per_launch = ps["rays_extension"] / launches
+        avg_ms = ps["ms_intersect"] / launches
+        achieved = BYTES_PER_EXT_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_trace<false> (closest-hit two-level BVH traversal)",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_ray": BYTES_PER_EXT_RAY, "rays_per_launch": int(rays_per_launch),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "mrays_per_s_in_kernel": round(rays_per_launch / avg_ms / 1e3, 1),
+                    "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),
+                                  "shade": round(ps["ms_shade"], 3), "shadow": round(ps["ms_shadow"], 3)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s at 1080p, 1M-tri SBVH scene; 1/2/4/8-GPU scaling + %HBM roofline",
+            "value": round(total_rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[3]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
+                            f"SBVH meshes = {flat.instanced_triangles} instanced triangles, PBR metal/dielectric, procedural HDR sky + "
+                            f"emissive quad), two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG",
+                "spp_per_step": spp_step, "samples_in_flight": in_flight,
+                "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
+                "pixels_per_rank": W * Hh // world, "paths_per_step_per_rank": W * Hh // world * spp_step,
+                "collective": "none" if world == 1 else "1 x reduce(SUM) of the HDR accumulator (RCCL) per job",
+            },
+            "rays": {"extension": int(ext), "shadow": int(shadow), "primary": int(gen), "shade_hits": int(hits)},
+            "image_mean_radiance": round(image_mean, 5),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

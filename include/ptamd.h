@@ -129,6 +129,9 @@ typedef struct {
     uint32_t seed; /* PT_RNG_COUNTER only */
     int32_t device; /* HIP device ordinal */
     uint32_t flags; /* PT_FLAG_* */
+    uint32_t samples_in_flight; /* samples of one pixel traced concurrently, each into its own accumulator
+                                   plane (folded after the batch); 0 = auto (~8M path segments per launch).
+                                   Only with max_active_rays == 0 and PT_RNG_COUNTER. */
 } pt_config;
 
 #define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */

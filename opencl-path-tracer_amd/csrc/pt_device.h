@@ -115,6 +115,19 @@ struct ShadowQueue {
 };
 
 enum : uint32_t { FLAG_FINISHED = 1, FLAG_LASTSPECULAR = 2 }; // shading.cl:11-14
+// state word of a queued ray: bits 0-7 flags, 8-15 bounce count, 16-31 accumulator plane.
+// Several samples of one pixel can be in flight at once; each one deposits into its own plane so
+// that there is still exactly one live path per accumulator entry (no atomics, deterministic sums).
+__host__ __device__ inline uint32_t packState(uint32_t flags, uint32_t bounce, uint32_t plane) { return (flags & 0xFFu) | ((bounce & 0xFFu) << 8) | (plane << 16); }
+struct AccumView {
+    float4* plane0; // the HDR accumulator proper (width*height float4)
+    float4* extra; // planes 1.. (scratch, folded into plane0 after every batch)
+    uint32_t stride; // width*height
+    __device__ inline float4* at(uint32_t plane, uint32_t pixel) const
+    {
+        return plane == 0u ? plane0 + pixel : extra + (size_t)(plane - 1u) * stride + pixel;
+    }
+};
 
 struct CameraDev { // Camera, camera.cl:7-26
     float4 eye, screen, u, v, uN, vN;

@@ -408,10 +408,13 @@ struct FrameParams {
     uint32_t sample, seed;
     uint32_t maxBounces;
     uint32_t parity; // LFSR113 streams per slot + reference queue semantics
+    uint32_t numOwned; // pixels owned by this context
+    uint32_t planes; // samples in flight (fixed schedule only; 1 otherwise)
 };
 
-// generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th pixel to issue
-// (pixelList[first + i], or first + i when no list is set) into queue slot slotBase + i.
+// generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th (pixel, sample) pair to
+// issue into queue slot slotBase + i: pixel = pixelList[first + i % numOwned] (or the index itself when
+// no list is set), sample = fp.sample + i / numOwned (that sample's accumulator plane).
 __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const uint32_t* __restrict__ pixelList, uint32_t first,
     uint32_t n, uint32_t slotBase, uint4* __restrict__ streams, uint32_t* __restrict__ queueCount, uint32_t* __restrict__ generated)
 {
@@ -422,15 +425,20 @@ __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const u
     }
     if (i >= n)
         return;
-    const uint32_t pixel = pixelList ? pixelList[first + i] : first + i;
-    Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample, fp.seed, 0u);
+    uint32_t plane = 0, k = first + i;
+    if (fp.planes > 1u) {
+        plane = k / fp.numOwned;
+        k -= plane * fp.numOwned;
+    }
+    const uint32_t pixel = pixelList ? pixelList[k] : k;
+    Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
     V3 o, d;
     cameraRay(fp.cam, (int)(pixel % fp.width), (int)(pixel / fp.width), (float)fp.width, (float)fp.height, rng, &o, &d);
     if (fp.parity)
         rngLfsrStore(streams, i, rng);
     const uint32_t slot = slotBase + i;
     q.o[slot] = make_float4(o.x, o.y, o.z, asF(pixel));
-    q.d[slot] = make_float4(d.x, d.y, d.z, asF(FLAG_LASTSPECULAR)); // bounce 0 in bits 8..
+    q.d[slot] = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, plane)));
     q.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
 }
 
@@ -441,7 +449,7 @@ struct ShadeArgs {
     HitQueue hits;
     RayQueue out;
     ShadowQueue shadow;
-    float4* accum;
+    AccumView accum;
     const uint32_t* inCount;
     uint32_t* outCount;
     uint32_t* shadowCount;
@@ -461,13 +469,14 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
     const uint32_t count = *a.inCount;
     bool emitRay = false, emitShadow = false, shaded = false;
     ShadeResult r;
-    uint32_t pixel = 0, bounce = 0;
+    uint32_t pixel = 0, bounce = 0, plane = 0;
     if (i < count) {
         const float4 ro = a.in.o[i];
         const float4 rd = a.in.d[i];
         const uint32_t fb = asU(rd.w);
         pixel = asU(ro.w);
-        bounce = fb >> 8;
+        bounce = (fb >> 8) & 0xFFu;
+        plane = fb >> 16;
         if (!(fb & FLAG_FINISHED)) {
             const float4 h = a.hits.h[i];
             const float4 thr = a.in.thr[i];
@@ -476,14 +485,15 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
             if (prim >= 0) {
                 shaded = true;
                 const V3 X = o + h.x * d;
-                Rng rng = PARITY ? rngLfsrLoad(a.streams, i) : rngCounter(pixel, a.fp.sample, a.fp.seed, 1u + bounce);
+                Rng rng = PARITY ? rngLfsrLoad(a.streams, i) : rngCounter(pixel, a.fp.sample + plane, a.fp.seed, 1u + bounce);
                 shadeHit(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r);
                 if (PARITY)
                     rngLfsrStore(a.streams, i, rng);
                 if (r.radiance.x != 0.f || r.radiance.y != 0.f || r.radiance.z != 0.f) {
-                    float4 px = a.accum[pixel];
+                    float4* ap = a.accum.at(plane, pixel);
+                    float4 px = *ap;
                     px.x += r.radiance.x, px.y += r.radiance.y, px.z += r.radiance.z;
-                    a.accum[pixel] = px;
+                    *ap = px;
                 }
                 bounce += 1;
                 if (bounce >= a.fp.maxBounces) // kernel.cl:295-296
@@ -492,9 +502,10 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
                 emitShadow = PARITY ? true : !(r.shadowFlags & FLAG_FINISHED);
             } else { // miss: skydome (kernel.cl:285-289)
                 const V3 c = throughput * readSkydome(a.sc, normalize(d));
-                float4 px = a.accum[pixel];
+                float4* ap = a.accum.at(plane, pixel);
+                float4 px = *ap;
                 px.x += c.x, px.y += c.y, px.z += c.z;
-                a.accum[pixel] = px;
+                *ap = px;
             }
         }
     }
@@ -504,11 +515,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
             a.activeFlag[i] = shaded ? 1u : 0u;
         if (shaded) {
             a.out.o[i] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
-            a.out.d[i] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF((r.flags & 0xFFu) | (bounce << 8)));
+            a.out.d[i] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane)));
             a.out.thr[i] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
             a.shadow.o[i] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
             a.shadow.d[i] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
-            a.shadow.c[i] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(r.shadowFlags));
+            a.shadow.c[i] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(r.shadowFlags, 0u, plane)));
         }
         return;
     }
@@ -528,14 +539,14 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
     if (emitRay) {
         const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);
         a.out.o[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
-        a.out.d[idx] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF((r.flags & 0xFFu) | (bounce << 8)));
+        a.out.d[idx] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane)));
         a.out.thr[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
     }
     if (emitShadow) {
         const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);
         a.shadow.o[idx] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
         a.shadow.d[idx] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
-        a.shadow.c[idx] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, 0.f);
+        a.shadow.c[idx] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(0u, 0u, plane)));
     }
 }
 
@@ -610,6 +621,22 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accu
         c[k] = (col <= 0.0031308f) ? col * 12.92f : (powf(fabsf(col), 1.0f / 2.4f) * 1.055f) - 0.055f;
     }
     out[i] = make_float4(c[0], c[1], c[2], 1.0f);
+}
+
+// fold the extra accumulator planes of a batch into the accumulator and clear them
+__global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= acc.stride)
+        return;
+    float4 s = acc.plane0[i];
+    for (uint32_t p = 1; p < planes; p++) {
+        float4* e = acc.extra + (size_t)(p - 1u) * acc.stride + i;
+        const float4 v = *e;
+        s.x += v.x, s.y += v.y, s.z += v.z;
+        *e = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    acc.plane0[i] = s;
 }
 
 __global__ void k_set_word(uint32_t* p, uint32_t v)

@@ -34,7 +34,7 @@ struct TraceArgs {
     const float4* rayC;
     float4* hit;
     int32_t* inst;
-    float4* accum;
+    AccumView accum;
     uint32_t* occluded; // optional (test hook): 1/0 per shadow ray
     const uint32_t* count; // number of queue entries (device word)
     uint32_t* cursor; // fetch cursor (device word, zero at launch)
@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                         if (ANY_HIT) {
                             if (a.occluded)
                                 a.occluded[rayIdx] = 0u;
-                            float4 px = a.accum[pixel]; // one live path per pixel: plain RMW
+                            float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                            float4 px = *ap;
                             px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
-                            a.accum[pixel] = px;
+                            *ap = px;
                         } else {
                             a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
                             a.inst[rayIdx] = hinst;

@@ -85,8 +85,9 @@ struct pt_ctx {
     uint32_t numOwned = 0;
     uint32_t capacity = 0;
     bool identityPixels = true;
-    DevBuf<float4> accumOwn;
+    DevBuf<float4> accumOwn, accumPlanes;
     float4* accum = nullptr;
+    uint32_t planes = 1; // samples in flight (fixed schedule)
     uint32_t spp = 0;
 
     // queues
@@ -128,6 +129,7 @@ int fail(pt_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->cfg.width * c->cfg.height }; }
 inline uint32_t maxBounces(const pt_ctx* c) { return c->cfg.max_bounces ? c->cfg.max_bounces : 4u; }
 inline bool parityMode(const pt_ctx* c) { return c->cfg.rng_mode == PT_RNG_LFSR113_PARITY; }
 
@@ -205,8 +207,23 @@ int ensureQueues(pt_ctx* c)
         return PT_OK;
     if (c->numOwned == 0)
         return fail(c, PT_ERR_STATE, "no pixels owned by this context");
-    uint32_t cap = c->cfg.max_active_rays ? c->cfg.max_active_rays : c->numOwned;
-    cap = (cap + 63u) & ~63u;
+    // samples in flight: only when every (pixel, sample) pair gets its own slot (fixed schedule)
+    c->planes = 1;
+    if (!parityMode(c) && c->cfg.max_active_rays == 0) {
+        uint32_t want = c->cfg.samples_in_flight;
+        if (want == 0) // auto: keep ~8M path segments per launch
+            want = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (8u << 20) / std::max(c->numOwned, 1u)));
+        c->planes = std::min(want, 64u);
+    }
+    uint64_t cap64 = c->cfg.max_active_rays ? c->cfg.max_active_rays : (uint64_t)c->numOwned * c->planes;
+    if (cap64 > 0x7FFFFFC0ull)
+        return fail(c, PT_ERR_UNSUPPORTED, "queue capacity too large");
+    uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;
+    if (c->planes > 1) {
+        const size_t n = (size_t)(c->planes - 1) * c->cfg.width * c->cfg.height;
+        HIPCHK(c, c->accumPlanes.alloc(n));
+        HIPCHK(c, hipMemset(c->accumPlanes.p, 0, n * sizeof(float4)));
+    }
     c->capacity = cap;
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, c->rays[k].o.alloc(cap));
@@ -271,6 +288,8 @@ FrameParams frameParams(const pt_ctx* c, uint32_t sample)
     fp.seed = c->cfg.seed;
     fp.maxBounces = maxBounces(c);
     fp.parity = parityMode(c) ? 1u : 0u;
+    fp.numOwned = c->numOwned;
+    fp.planes = 1;
     return fp;
 }
 
@@ -328,7 +347,7 @@ void launchShadow(pt_ctx* c, uint32_t pass)
     a.rayO = c->shadow.o.p;
     a.rayD = c->shadow.d.p;
     a.rayC = c->shadow.c.p;
-    a.accum = c->accum;
+    a.accum = accumView(c);
     a.count = &ctl->shadowCount[pass];
     a.cursor = &ctl->shadowCursor[pass];
     hipLaunchKernelGGL(k_trace<true>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
@@ -343,7 +362,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.fp = fp;
     a.in = c->rays[in].view();
     a.hits = { c->hitH.p, c->hitInst.p };
-    a.accum = c->accum;
+    a.accum = accumView(c);
     a.inCount = &ctl->extCount[pass];
     a.outCount = &ctl->extCount[pass + 1];
     a.shadowCount = &ctl->shadowCount[pass];
@@ -376,12 +395,14 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
 // Fixed launch schedule for one sample when every owned pixel has its own queue slot: gen, then
 // maxBounces x (intersect, shade, shadow intersect), then the bookkeeping kernel.  No host
 // read-back anywhere (the reference blocks on a 176-byte read every pass, raytracer.cpp:381-389).
-int renderSampleFixed(pt_ctx* c, uint32_t sample, Prof& prof)
+int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 {
-    const FrameParams fp = frameParams(c, sample);
+    FrameParams fp = frameParams(c, sample);
+    fp.planes = batch;
     const uint32_t bounces = maxBounces(c);
+    const uint32_t entries = c->numOwned * batch;
     prof.begin(0);
-    launchGen(c, fp, 0, 0, c->numOwned, 0, 0);
+    launchGen(c, fp, 0, 0, entries, 0, 0);
     prof.end();
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
@@ -389,7 +410,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, Prof& prof)
         launchIntersect(c, in, b);
         prof.end();
         prof.begin(2);
-        launchShade(c, fp, in, out, b, c->numOwned);
+        launchShade(c, fp, in, out, b, entries);
         prof.end();
         prof.begin(3);
         launchShadow(c, b);
@@ -397,6 +418,10 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, Prof& prof)
         std::swap(in, out);
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
+    if (batch > 1) {
+        const uint32_t n = c->cfg.width * c->cfg.height;
+        hipLaunchKernelGGL(k_fold_planes, dim3((n + 255) / 256), dim3(256), 0, c->stream, accumView(c), batch);
+    }
     HIPCHK(c, hipGetLastError());
     return PT_OK;
 }
@@ -526,7 +551,7 @@ void pt_destroy(pt_ctx* c)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
     c->top.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
-    c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
+    c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -913,12 +938,14 @@ int pt_render(pt_ctx* c, uint32_t spp)
         return rc;
     Prof prof { c };
     HIPCHK(c, hipEventRecord(c->evStart, c->stream));
-    const bool fixedSchedule = !parityMode(c) && c->capacity >= c->numOwned;
-    for (uint32_t s = 0; s < spp; s++) {
-        rc = fixedSchedule ? renderSampleFixed(c, c->spp, prof) : renderSampleRefill(c, c->spp);
+    const bool fixedSchedule = !parityMode(c) && c->cfg.max_active_rays == 0;
+    for (uint32_t s = 0; s < spp;) {
+        const uint32_t batch = fixedSchedule ? std::min(c->planes, spp - s) : 1u;
+        rc = fixedSchedule ? renderSampleFixed(c, c->spp, batch, prof) : renderSampleRefill(c, c->spp);
         if (rc)
             return rc;
-        c->spp++;
+        c->spp += batch;
+        s += batch;
     }
     HIPCHK(c, hipEventRecord(c->evStop, c->stream));
     if (c->profile) {
@@ -1084,7 +1111,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         TraceArgs a = traceArgsBase(c);
         a.parityShadow = 0;
         a.rayO = dO.p, a.rayD = dD.p, a.rayC = dC.p;
-        a.hit = dH.p, a.inst = dI.p, a.accum = dAcc.p, a.occluded = dOcc.p;
+        a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 1u }, a.occluded = dOcc.p;
         a.count = dCtl.p, a.cursor = dCtl.p + 1;
         chk(hipEventRecord(e0, c->stream));
         if (any_hit)
@@ -1231,7 +1258,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.hits = { dH.p + i, dI.p + i };
         a.out = { out.o.p + i, out.d.p + i, out.thr.p + i };
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
-        a.accum = dAcc.p;
+        a.accum = AccumView { dAcc.p, nullptr, (uint32_t)npix };
         a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3;
         hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
         uint32_t back[4];

@@ -15,7 +15,7 @@ FLAG_ROWMAJOR_PIXELS = 1
 class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_active_rays", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("rng_mode", C.c_uint32), ("seed", C.c_uint32), ("device", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32)]
 
 
 class Rect(C.Structure):
@@ -110,10 +110,10 @@ class Context:
     """One render context on one GPU (mirrors what RayTracer owns, reference src/raytracer.h:54-106)."""
 
     def __init__(self, width, height, max_active_rays=0, max_bounces=0, rng_mode=RNG_COUNTER, seed=1, device=0,
-                 flags=0):
+                 flags=0, samples_in_flight=0):
         self._h = C.c_void_p()
         self.width, self.height = width, height
-        cfg = Config(width, height, max_active_rays, max_bounces, rng_mode, seed, device, flags)
+        cfg = Config(width, height, max_active_rays, max_bounces, rng_mode, seed, device, flags, samples_in_flight)
         rc = lib().pt_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()

@@ -140,6 +140,9 @@ def create_streams(count, use_ref=False):
     out = np.zeros(count, L.LFSR113_STREAM)
     if use_ref:
         lib = ref_clrng()
+        # the default stream creator is process-global state that every CreateStreams call advances;
+        # rewind it so that each call starts at stream 0 like a fresh RayTracer (raytracer.cpp:739-751)
+        lib.clrngLfsr113RewindStreamCreator(None)
         size, err = C.c_size_t(0), C.c_int(0)
         ptr = lib.clrngLfsr113CreateStreams(None, count, C.byref(size), C.byref(err))
         assert err.value == 0 and size.value == count * 48

@@ -1,0 +1,46 @@
+"""BASELINE.json's full-size configuration (1080p, ~1M instanced triangles) through size-independent
+properties: ray-count conservation, determinism, sample additivity, tile-sum == frame, sampled-pixel
+agreement with the oracle."""
+import numpy as np
+import pytest
+
+import gpu_util as U
+import orclib as O
+from ptamd import scenes
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def bundle():
+    return scenes.instanced_grid(W, H, level=6)
+
+
+def test_full_size_properties(gpu, bundle):
+    assert 0.95e6 < bundle.flat.instanced_triangles < 1.3e6
+    ctx = U.make_ctx(gpu, bundle, W, H, seed=1)
+    ctx.render(4)
+    a = ctx.read_accum()[:, :3]
+    st = ctx.stats()
+    assert st["rays_generated"] == W * H * 4
+    assert st["rays_generated"] <= st["rays_extension"] <= 4 * st["rays_generated"]  # <= 4 bounces
+    assert st["shade_hits"] <= st["rays_extension"] and st["rays_shadow"] <= st["shade_hits"]
+    assert np.isfinite(a).all() and a.min() >= 0 and a.mean() > 0
+    # determinism + additivity: 4 more samples on top == 8 samples in one go (up to summation order)
+    ctx.render(4)
+    a8 = ctx.read_accum()[:, :3]
+    ctx.close()
+    ctx2 = U.make_ctx(gpu, bundle, W, H, seed=1)
+    ctx2.render(8)
+    b8 = ctx2.read_accum()[:, :3]
+    assert abs(ctx2.stats()["rays_extension"] - 2 * st["rays_extension"]) < 0.01 * st["rays_extension"]
+    assert np.allclose(a8, b8, rtol=1e-5, atol=1e-5 * b8.max())
+    ctx2.close()
+    # sampled pixels against the oracle (path by path, same random numbers)
+    px = np.random.default_rng(0).choice(W * H, 6000, replace=False).astype(np.uint32)
+    ref, _ = O.render(U.oracle_scene(bundle), bundle.camera, W, H, 8, seed=1, pixels=px, threads=8)
+    got, want = b8[px], ref[px, :3]
+    assert abs(got.mean() - want.mean()) / want.mean() < 2e-3
+    close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
+    assert close.mean() > 0.97, close.mean()

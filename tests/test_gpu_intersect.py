@@ -1,0 +1,111 @@
+"""HIP traversal kernels (through pt_intersect) against the oracle and against the golden vectors made
+by the reference's own kernels.  Integer results (hit, prim, instance, occlusion) are exact; t,u,v are
+fp32 with FMA contraction on the GPU: tolerance 2e-4 relative (stated in gpu_util.compare_hits)."""
+import numpy as np
+import pytest
+
+import golden_io
+import gpu_util as U
+import orclib as O
+from ptamd import host as H, layout as L, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["mixed", "inst"])
+def test_golden_closest_and_any_hit(gpu, golden, name):
+    flat, cam, sky, tex = golden_io.scene_inputs(golden, name)
+    ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex)
+    o, d = golden[f"isect_{name}_o"], golden[f"isect_{name}_d"]
+    got = ctx.intersect(o, d)
+    want = dict(t=golden[f"isect_{name}_t"], u=golden[f"isect_{name}_uv"][:, 0], v=golden[f"isect_{name}_uv"][:, 1],
+                prim=golden[f"isect_{name}_prim"], inst=golden[f"isect_{name}_inst"])
+    info = U.compare_hits(flat, got, want)
+    assert info["flips"] == 0
+    occ = ctx.intersect(o, d, tmax=golden[f"shadow_{name}_len"], any_hit=True)["prim"]
+    g = golden[f"shadow_{name}_occluded"]
+    # segments cut 0.1 % before / after the first hit are decided by the same fp32 t on both sides
+    assert (occ != g).sum() <= 2, f"{(occ != g).sum()} occlusion verdicts differ"
+    ctx.close()
+
+
+@pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
+def test_random_rays_two_level(gpu, builder):
+    b = scenes.instanced_grid(64, 36, level=4, builder=builder, sky_size=(16, 8))
+    ctx = U.make_ctx(gpu, b, 64, 36)
+    sc = U.oracle_scene(b)
+    o, d = U.random_rays(60000, 5, (-4, 0.05, -4), (4, 3, 4))
+    got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
+    info = U.compare_hits(b.flat, got, want)
+    assert info["n"] > 10000 and info["flips"] == 0
+    tmax = np.random.default_rng(1).uniform(0.05, 4, len(o)).astype(np.float32)
+    occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
+    ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
+    assert (occ != ref).sum() <= 3
+    ctx.close()
+
+
+def test_edge_cases(gpu):
+    """empty queue tail / ragged sizes, axis-parallel rays (zero components), origins exactly on box faces
+    and at 0, rays starting inside a box, rays that miss everything, degenerate zero-length shadow rays."""
+    b = scenes.cornell_box(32, 32)
+    ctx = U.make_ctx(gpu, b, 32, 32)
+    sc = U.oracle_scene(b)
+    for n in (1, 63, 64, 65, 1000):  # ragged wave fills
+        o, d = U.random_rays(n, n, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
+        U.compare_hits(b.flat, ctx.intersect(o, d), O.intersect_batch(sc, o, d))
+    o = np.zeros((12, 3), np.float32)
+    o[:, 1] = 1.0
+    d = np.zeros((12, 3), np.float32)
+    for k in range(6):
+        d[k, k % 3] = 1.0 if k < 3 else -1.0
+        d[6 + k, k % 3] = 1.0 if k < 3 else -1.0
+    o[6:, 0], o[6:, 2] = -1.0, 1.0  # on the left wall plane and the back wall plane
+    got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d)
+    assert np.array_equal(got["prim"] >= 0, want["prim"] >= 0)
+    hit = want["prim"] >= 0
+    assert np.allclose(got["t"][hit], want["t"][hit], rtol=1e-5)
+    far = np.array([[0, 50, 0]], np.float32)
+    up = np.array([[0, 1, 0]], np.float32)
+    r = ctx.intersect(far, up)
+    assert r["prim"][0] == -1 and np.isinf(r["t"][0]) and r["inst"][0] == -1
+    z = ctx.intersect(o[:4], d[:4], tmax=np.zeros(4, np.float32), any_hit=True)["prim"]
+    assert not z.any()
+    ctx.close()
+
+
+def test_invalid_scenes_are_rejected_not_traversed(gpu):
+    b = scenes.cornell_box(16, 16)
+    f = b.flat
+    ctx = gpu.Context(16, 16)
+    bad = f.triangles.copy()
+    bad["indices"][3, 1] = len(f.vertices) + 5
+    with pytest.raises(gpu.PtError, match="vertex index"):
+        ctx._chk(gpu.lib().pt_upload_static(ctx._h, f.vertices.ctypes.data, len(f.vertices), bad.ctypes.data, len(bad),
+                                            f.materials.ctypes.data, len(f.materials), f.sub_nodes.ctypes.data, len(f.sub_nodes)), "upload")
+    nodes = f.sub_nodes.copy()
+    leaf = np.flatnonzero(nodes["count"] != 0)[0]
+    nodes["count"][leaf] = 10 ** 6
+    with pytest.raises(gpu.PtError, match="out of bounds"):
+        ctx._chk(gpu.lib().pt_upload_static(ctx._h, f.vertices.ctypes.data, len(f.vertices), f.triangles.ctypes.data, len(f.triangles),
+                                            f.materials.ctypes.data, len(f.materials), nodes.ctypes.data, len(nodes)), "upload")
+    with pytest.raises(gpu.PtError, match="scene"):
+        ctx.render(1)
+    ctx.close()
+
+
+def test_large_leaves_are_split_at_upload(gpu):
+    """100 coincident triangles make one 100-triangle leaf (no SAH gain); device leaves hold <= 31."""
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (100, 1))
+    pos[:, 2] = np.repeat(np.arange(100) * 1e-4, 3)
+    mesh = H.Mesh(pos, np.arange(300, dtype=np.uint32).reshape(100, 3), [L.material_diffuse((1, 1, 1))], builder=H.BVH_BINNED_SAH)
+    sc = H.Scene()
+    sc.add_node(mesh)
+    flat = sc.flatten()
+    ctx = gpu.Context(8, 8)
+    ctx.upload_scene(flat)
+    o = np.array([[0.2, 0.2, -1.0], [0.2, 0.2, 1.0], [2, 2, -1]], np.float32)
+    d = np.array([[0, 0, 1], [0, 0, -1], [0, 0, 1]], np.float32)
+    got, want = ctx.intersect(o, d), O.intersect_batch(O.BoundScene(flat), o, d)
+    assert np.array_equal(got["prim"], want["prim"]) and np.allclose(got["t"][:2], want["t"][:2])
+    ctx.close()

@@ -1,0 +1,110 @@
+"""Host-side scene library: BVH builder invariants (the reference's BvhTester checks,
+src/bvh/bvh_test.cpp:117-139, as real tests), top-level BVH, flattening with index rebasing
+(src/raytracer.cpp:244-270) and camera derivation (src/camera.cpp:18-58)."""
+import numpy as np
+import pytest
+
+from ptamd import host as H, layout as L, scenes
+
+
+@pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
+@pytest.mark.parametrize("level", [0, 3, 5])
+def test_bvh_invariants_on_blob(builder, level):
+    m = scenes.blob_mesh(L.material_diffuse((0.8, 0.8, 0.8)), level=level, builder=builder)
+    s = m.stats()
+    assert s["children_inside_parents"] and s["triangles_inside_leaves"] and s["all_triangles_referenced"]
+    assert s["num_input_triangles"] == 20 * 4 ** level
+    assert s["reachable_triangle_refs"] == s["num_triangle_refs"] >= s["num_input_triangles"]
+    if builder != H.BVH_SPATIAL_SPLIT:
+        assert s["num_triangle_refs"] == s["num_input_triangles"]  # object splits never duplicate
+    assert s["max_depth"] <= 60
+    assert s["reachable_nodes"] == s["num_nodes"] - 1  # node 1 is the pad next to the root
+    nodes, tris, orig = m.bvh()
+    inner = nodes[nodes["count"] == 0]
+    inner = inner[inner["left"] != 0]
+    assert np.all(inner["left"] % 2 == 0), "sibling pairs are 2-aligned"
+    assert sorted(set(orig.tolist())) == list(range(s["num_input_triangles"]))
+
+
+def test_bvh_random_soup_with_degenerates():
+    rng = np.random.default_rng(3)
+    n = 500
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    pos = (c + rng.normal(scale=0.05, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    pos[:9] = pos[0]  # zero-area triangles
+    pos[30:60, 2] = 0.25  # coplanar cluster (zero extent on one axis)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    for b in (H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT):
+        s = H.Mesh(pos, idx, [L.material_diffuse((1, 1, 1))], builder=b).stats()
+        assert s["children_inside_parents"] and s["triangles_inside_leaves"] and s["all_triangles_referenced"]
+
+
+def test_identical_triangles_do_not_recurse_forever():
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (100, 1))
+    idx = np.arange(300, dtype=np.uint32).reshape(100, 3)
+    s = H.Mesh(pos, idx, [L.material_diffuse((1, 1, 1))], builder=H.BVH_SPATIAL_SPLIT).stats()
+    assert s["all_triangles_referenced"] and s["max_leaf_size"] == 100  # no SAH gain: one big leaf, as the reference
+
+
+def test_empty_mesh_and_bad_indices_are_errors():
+    with pytest.raises(RuntimeError):
+        H.Mesh(np.zeros((3, 3), np.float32), np.zeros((0, 3), np.uint32), [L.material_diffuse((1, 1, 1))])
+    with pytest.raises(RuntimeError, match="out of range"):
+        H.Mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32), [L.material_diffuse((1, 1, 1))])
+
+
+def test_flatten_rebases_indices_and_shares_instanced_meshes():
+    b = scenes.instanced_grid(64, 36, nx=3, nz=2, level=2, sky_size=(16, 8))
+    f = b.flat
+    # 4 unique meshes (ground, light, 2 blobs) but 8 instances
+    assert f.num_instances == 8 and (f.top_nodes["isLeaf"] != 0).sum() == 8
+    assert len(f.top_nodes) == 2 * 8 - 1 and f.top_root == len(f.top_nodes) - 1  # root is the last node
+    assert f.triangles["indices"].max() < len(f.vertices) and f.triangles["materialIndex"].max() < len(f.materials)
+    leaves = f.sub_nodes[f.sub_nodes["count"] != 0]
+    assert (leaves["left"].astype(np.int64) + leaves["count"]).max() <= len(f.triangles)
+    roots = f.top_nodes["a"][f.top_nodes["isLeaf"] != 0]
+    assert len(set(roots.tolist())) == 4, "instances of one mesh share its sub-BVH"
+    assert f.instanced_triangles == 2 + 2 + 3 * 320 + 3 * 320
+    # every top-level inner box encloses its children; leaves carry inverse(world)
+    for n in f.top_nodes[f.top_nodes["isLeaf"] == 0]:
+        for c in (f.top_nodes[n["a"]], f.top_nodes[n["b"]]):
+            assert np.all(n["min"][:3] <= c["min"][:3]) and np.all(n["max"][:3] >= c["max"][:3])
+    leaf = f.top_nodes[f.top_nodes["isLeaf"] != 0][2]
+    m = leaf["invTransform"].reshape(4, 4).T  # column-major
+    assert abs(np.linalg.det(m[:3, :3])) > 0 and np.allclose(m[3], [0, 0, 0, 1])
+    # lights are world-space: the emissive quad was placed at y = 4
+    assert len(f.lights) == 2 and np.allclose(f.lights["vertices"][:, :, 1], 4.0)
+
+
+def test_inverse_transform_round_trip():
+    sc = H.Scene()
+    m = scenes.blob_mesh(L.material_diffuse((1, 1, 1)), level=1)
+    q = np.array([np.cos(0.3), 0, np.sin(0.3), 0], np.float32)
+    sc.add_node(m, location=(1, 2, 3), orientation_wxyz=q, scale=(2, 2, 2))
+    f = sc.flatten()
+    inv = f.top_nodes[0]["invTransform"].reshape(4, 4).T.astype(np.float64)
+    c, s = np.cos(0.6), np.sin(0.6)
+    world = np.array([[2 * c, 0, 2 * s, 1], [0, 2, 0, 2], [-2 * s, 0, 2 * c, 3], [0, 0, 0, 1]])
+    assert np.allclose(inv @ world, np.eye(4), atol=1e-5)
+
+
+def test_camera_data_closed_form():
+    cam = H.camera_data((0, 0, 0), (1, 0, 0, 0), 90.0, 2.0, focal_distance=1.0, thin_lens=True)
+    f = 0.05
+    proj = 1.0 / (1.0 / f - 1.0)
+    half_w = np.tan(np.radians(45.0)) * proj
+    assert np.allclose(cam["u"][:3], [2 * half_w, 0, 0], rtol=1e-6) and np.allclose(cam["v"][:3], [0, -half_w, 0], rtol=1e-6)
+    assert np.allclose(cam["screenPoint"][:3], [-half_w, half_w / 2, proj], rtol=1e-6)
+    assert np.isclose(cam["apertureRadius"], f / 8.0 / 2.0) and cam["thinLensEnabled"] == 1
+    assert np.isclose(cam["relativeAperture"], 8.0) and np.isclose(cam["shutterTime"], 1 / 32) and np.isclose(cam["ISO"], 1200)
+    assert abs(np.dot(cam["u"][:3], cam["v"][:3])) < 1e-4  # assert of src/camera.cpp:52
+
+
+def test_cornell_has_36_triangles_and_inward_normals():
+    f = scenes.cornell_box(64, 64).flat
+    assert len(f.triangles) == 36 and len(f.lights) == 2 and len(f.top_nodes) == 1
+    centre = np.array([0, 1, 0], np.float32)
+    for t in f.triangles[:10]:  # the 5 walls: geometric normal faces the room centre
+        p = f.vertices["vertex"][t["indices"], :3]
+        n = np.cross(p[1] - p[0], p[2] - p[0])
+        assert np.dot(n, centre - p[0]) > 0

@@ -1,0 +1,77 @@
+"""N > 1 path on CPU (gloo, world_size 2): the tile partition bench.py uses, per-rank rendering of
+disjoint tiles and ONE reduce of the HDR accumulator onto rank 0.  The per-rank 'renderer' here is the
+oracle (CPU) restricted to the rank's pixels -- it stands in for the GPU context, whose tile logic is
+tested on the device in test_gpu_render.py; the collective call is the one bench.py issues."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+W, H, SPP = 64, 40, 2
+
+
+def _pixels_of(rects, width):
+    px = []
+    for x0, y0, x1, y1 in rects:
+        ys, xs = np.mgrid[y0:y1, x0:x1]
+        px.append((ys * width + xs).reshape(-1))
+    return np.concatenate(px).astype(np.uint32)
+
+
+def _worker(rank, world, port, out_path):
+    for p in (os.path.join(ROOT, "opencl-path-tracer_amd"), os.path.join(ROOT, "oracle"), ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import orclib as O
+    from ptamd import scenes
+    b = scenes.instanced_grid(W, H, level=2, sky_size=(16, 8))
+    sc = O.BoundScene(b.flat, sky=b.sky)
+    rects = bench.tile_rects(W, H, rank, world, tile=16)
+    px = _pixels_of(rects, W)
+    acc, cnt = O.render(sc, b.camera, W, H, SPP, seed=1, pixels=px, threads=1)
+    accum = torch.from_numpy(acc)
+    rays = torch.tensor([cnt["raysExtension"] + cnt["raysShadow"]], dtype=torch.float64)
+    dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.savez(out_path, accum=accum.numpy(), rays=rays.numpy(), tmax=tmax.numpy(), owned=len(px))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_partition_is_exact():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        cover = np.zeros(1080 * 1920, np.int32)
+        counts = []
+        for r in range(world):
+            px = _pixels_of(bench.tile_rects(1920, 1080, r, world), 1920)
+            np.add.at(cover, px, 1)
+            counts.append(len(px))
+        assert cover.min() == 1 and cover.max() == 1, "every pixel belongs to exactly one rank"
+        assert max(counts) - min(counts) <= 0.02 * 1920 * 1080 / world, "interleaved tiles balance the ranks"
+
+
+def test_two_rank_render_and_reduce(tmp_path):
+    out = str(tmp_path / "rank0.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    z = np.load(out)
+    for p in (os.path.join(ROOT, "opencl-path-tracer_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import orclib as O
+    from ptamd import scenes
+    b = scenes.instanced_grid(W, H, level=2, sky_size=(16, 8))
+    full, cnt = O.render(O.BoundScene(b.flat, sky=b.sky), b.camera, W, H, SPP, seed=1, threads=2)
+    assert np.array_equal(z["accum"], full), "reduced tile renders != single-rank render"
+    assert z["rays"][0] == cnt["raysExtension"] + cnt["raysShadow"]
+    assert z["tmax"][0] == 2.0 and 0 < z["owned"] < W * H
