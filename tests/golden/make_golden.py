@@ -23,6 +23,12 @@ def scene_mixed(width, height):
     return scenes.cornell_box(width, height, box_materials=mats)
 
 
+def scene_plain(width, height):
+    """Cornell room (diffuse) with a PBR metal and a PBR dielectric box: no refraction."""
+    mats = [L.material_pbr_metal((0.955, 0.638, 0.538), 0.8), L.material_pbr_dielectric((0.2, 0.5, 0.8), 0.6)]
+    return scenes.cornell_box(width, height, box_materials=mats)
+
+
 def scene_instances(width, height):
     """Textured (alpha cut-out) floor room + two scaled/translated instances of a low-poly blob (metal)
     + a basic-refractive blob; gradient sky."""
@@ -204,6 +210,18 @@ def main():
                 G[f"image_{sname}_accum_{spp + 1}spp"] = st.accum[:, :3].copy()
         # (7) accumulate kernel on the 256-spp sums
         G[f"image_{sname}_resolved_256spp"] = O.accumulate("ref", st.accum, kd, 64, 36, 256)
+
+    # ---- (8) a scene without refractive materials, where fp32 round-off flips decisions so rarely that a
+    # GPU render with the same streams tracks these sums pixel by pixel for the first ~100k paths
+    b = scene_plain(64, 36)
+    G.update(flat_arrays("scene_plain_", b))
+    sc = bound(b)
+    st = O.QueueState(64, 36, 64 * 36)
+    s = O.create_streams(64 * 36, use_ref=True)
+    for spp in range(32):
+        O.trace_rays("ref", sc, b.camera, st, s)
+        if spp + 1 in (4, 32):
+            G[f"image_plain_accum_{spp + 1}spp"] = st.accum[:, :3].copy()
 
     # structured arrays (C-ABI records with overlapping union fields) are stored as raw bytes:
     # key "name@DTYPE" -> uint8[..., itemsize]; tests/golden_io.py turns them back into records
