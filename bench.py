@@ -41,30 +41,45 @@ def tile_rects(width, height, rank, world, tile=32):
     return rects
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(bundle, seconds, width, height):
     """Oracle (kind 'port') on all host cores: 1 spp over 8x8 pixel blocks spread over the frame,
     extended block by block until `seconds` of wall time are used."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orclib as O  # checker / reported baseline only
     O.build(fast=True, ref=False)  # -O3 -march=native for THIS host
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     sc = O.BoundScene(bundle.flat, sky=bundle.sky, material_textures=bundle.material_textures)
     bx, by = width // 8, height // 8
     order = np.random.default_rng(0).permutation(bx * by)
     yy, xx = np.mgrid[0:8, 0:8]
-    rays, pixels_done, t_used, chunk, pos = 0, 0, 0.0, 256, 0
-    while t_used < seconds and pos < len(order):
+    rays, pixels_done, t_used, chunk, pos, sample = 0, 0, 0.0, 256, 0, 0
+    while t_used < seconds:
+        if pos >= len(order):  # the whole frame is done: next sample index
+            pos, sample = 0, sample + 1
         blocks = order[pos:pos + chunk]
         pos += len(blocks)
         px = (((blocks // bx)[:, None, None] * 8 + yy) * width + (blocks % bx)[:, None, None] * 8 + xx).reshape(-1)
         t0 = time.perf_counter()
-        _, cnt = O.render(sc, bundle.camera, width, height, 1, seed=1, pixels=px.astype(np.uint32), threads=cores, fast=True)
+        _, cnt = O.render(sc, bundle.camera, width, height, 1, seed=1, first_sample=sample, pixels=px.astype(np.uint32),
+                          threads=cores, fast=True)
         t_used += time.perf_counter() - t0
         rays += cnt["raysExtension"] + cnt["raysShadow"]
         pixels_done += len(px)
-        chunk = min(chunk * 2, 4096)
+        chunk = min(chunk * 2, 8192)
     return {"value": round(rays / t_used / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{pixels_done} pixels (random 8x8 blocks of the {width}x{height} frame) x 1 spp, "
+            "sample": f"{pixels_done} pixel-samples (random 8x8 blocks of the {width}x{height} frame, 1 spp each pass), "
                       f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
 
 
