@@ -9,21 +9,27 @@
 //  * persistent waves: the grid is sized to the machine (blocks/CU x 256 CUs); each 64-lane wave
 //    pulls rays from the queue with ONE atomicAdd per refill (ballot + popcount ranks the idle
 //    lanes) and refills when enough lanes have gone idle, so long rays do not hold 63 lanes hostage;
-//  * the bottom-level stack lives in LDS, laid out [entry][lane] so a wave's push/pop touches 64
-//    consecutive dwords (conflict-free ds_read/ds_write_b32); entries beyond kLdsStack and the
-//    (rarely touched) top-level stack spill to a lane-interleaved region in global memory;
-//  * one 64-byte PairNode fetch per step (both child boxes), reciprocal direction computed once
-//    per instance entry, 48-byte pre-digested triangles.
+//  * both traversal stacks live in LDS, laid out [entry][lane] so a wave's push/pop touches 64
+//    consecutive dwords (conflict-free ds_read/ds_write_b32); deeper entries spill to a
+//    lane-interleaved region in global memory (never reached by the benchmark scenes);
+//  * the top-level BVH and the instance table are staged in LDS once per workgroup when they fit
+//    (TOP_LDS): a ray visits ~13 top-level nodes, each a dependent pop -> node -> children chain that
+//    would otherwise be three global-memory round trips;
+//  * one 64-byte PairNode fetch per bottom-level step (both child boxes), reciprocal directions
+//    computed once per ray / instance entry, 48-byte pre-digested triangles.
 #pragma once
 #include "pt_math.h"
 
 namespace ptd {
 
-constexpr int kLdsStack = 24; // bottom-level entries kept in LDS per lane (6 KiB per wave)
-constexpr int kSpillStack = 48; // further bottom-level entries in global memory
-constexpr int kTopStack = 64; // top-level entries (global memory)
+constexpr int kLdsStack = 20; // bottom-level entries kept in LDS per lane
+constexpr int kSpillStack = 52; // further bottom-level entries in global memory
+constexpr int kTopLdsStack = 8; // top-level entries kept in LDS per lane
+constexpr int kTopStack = 64; // top-level entries overall (LDS + global spill)
 constexpr int kTraceBlock = 256;
 constexpr int kRefillIdleLanes = 20; // refill the wave once this many lanes are idle
+constexpr int kTopLdsNodes = 128; // top-level nodes / instances staged in LDS (TOP_LDS variant)
+constexpr int kTopLdsInstances = 64;
 
 struct TraceArgs {
     SceneDev sc;
@@ -41,12 +47,16 @@ struct TraceArgs {
     uint32_t* spill; // (kSpillStack + kTopStack) * totalThreads dwords
     uint32_t totalThreads;
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
+    uint32_t numTopNodes, numInstances;
 };
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool TOP_LDS>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
+    __shared__ uint32_t ldsTopStack[kTraceBlock / 64][kTopLdsStack][64];
+    __shared__ TopNode sTop[TOP_LDS ? kTopLdsNodes : 1];
+    __shared__ Instance sInst[TOP_LDS ? kTopLdsInstances : 1];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -56,10 +66,37 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
     const uint32_t count = *a.count;
     const SceneDev& sc = a.sc;
 
+    if (TOP_LDS) { // stage the top level once per workgroup (16-byte copies)
+        const float4* srcN = (const float4*)sc.top;
+        float4* dstN = (float4*)sTop;
+        for (uint32_t i = threadIdx.x; i < a.numTopNodes * 2u; i += kTraceBlock)
+            dstN[i] = srcN[i];
+        const float4* srcI = (const float4*)sc.instances;
+        float4* dstI = (float4*)sInst;
+        for (uint32_t i = threadIdx.x; i < a.numInstances * 4u; i += kTraceBlock)
+            dstI[i] = srcI[i];
+        __syncthreads();
+    }
+    const TopNode* const topNodes = TOP_LDS ? sTop : sc.top;
+    const Instance* const instances = TOP_LDS ? sInst : sc.instances;
+
+    auto pushTop = [&](int slot, uint32_t v) {
+        if (slot < kTopLdsStack)
+            ldsTopStack[wave][slot][lane] = v;
+        else
+            spillTop[(size_t)(slot - kTopLdsStack) * total] = v;
+    };
+    auto popTop = [&](int slot) -> uint32_t {
+        return slot < kTopLdsStack ? ldsTopStack[wave][slot][lane] : spillTop[(size_t)(slot - kTopLdsStack) * total];
+    };
+    auto popBottom = [&](int slot) -> uint32_t {
+        return slot < kLdsStack ? ldsStack[wave][slot][lane] : spillBottom[(size_t)(slot - kLdsStack) * total];
+    };
+
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
     uint32_t rayIdx = 0;
-    V3 o = mk(0.f), d = mk(0.f); // world-space ray
+    V3 o = mk(0.f), d = mk(0.f), id = mk(0.f); // world-space ray and 1/d (only used where d != 0)
     V3 to = mk(0.f), td = mk(0.f), itd = mk(0.f); // instance-space origin, direction, 1/direction
     float tClosest = 0.f, tMax = 0.f, hu = 0.f, hv = 0.f;
     int hprim = -1, hinst = -1, curInst = -1;
@@ -103,6 +140,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                             rayIdx = idx;
                             o = xyz(ro);
                             d = xyz(rd);
+                            id = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                             tClosest = tMax;
                             hprim = -1;
                             hinst = -1;
@@ -110,7 +148,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                             cur = kRefNone;
                             sp = 0;
                             tsp = 1;
-                            spillTop[0] = sc.topRoot;
+                            pushTop(0, sc.topRoot);
                             active = true;
                         }
                     }
@@ -126,9 +164,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
         }
 
         // ---- traverse until enough lanes are idle again -----------------------------------
+        // Each iteration runs ONE of the three step kinds -- the one most lanes are waiting for (ballot
+        // majority vote) -- instead of serialising all three bodies for a third of the lanes each.
         while (true) {
-            if (active) {
-                if (cur == kRefNone) {
+            const bool wantTop = active && cur == kRefNone;
+            const bool wantInner = active && cur != kRefNone && refCount(cur) == 0u;
+            const bool wantLeaf = active && cur != kRefNone && refCount(cur) != 0u;
+            const int nTop = __popcll(__ballot(wantTop)), nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
+            const int kind = (nInner >= nTop && nInner >= nLeaf) ? 1 : (nLeaf >= nTop ? 2 : 0);
+            {
+                if (kind == 0 && wantTop) {
                     // ---------------- top level (scene.cl:105-159) ----------------
                     if (tsp == 0) {
                         // ray finished: closestT != maxT decides hit/miss (scene.cl:257)
@@ -145,29 +190,29 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                         }
                         active = false;
                     } else {
-                        const uint32_t ni = spillTop[(size_t)(--tsp) * total];
-                        const TopNode tn = sc.top[ni];
+                        const uint32_t ni = popTop(--tsp);
+                        const TopNode tn = topNodes[ni];
                         // slab test in world space with the per-axis d != 0 guard (bvh.cl:36-73)
                         float tmin = -INFINITY, tmax = INFINITY;
                         if (d.x != 0.0f) {
-                            float t1 = (tn.lo.x - o.x) / d.x, t2 = (tn.hi.x - o.x) / d.x;
+                            const float t1 = (tn.lo.x - o.x) * id.x, t2 = (tn.hi.x - o.x) * id.x;
                             tmin = fmaxf(tmin, fminf(t1, t2));
                             tmax = fminf(tmax, fmaxf(t1, t2));
                         }
                         if (d.y != 0.0f) {
-                            float t1 = (tn.lo.y - o.y) / d.y, t2 = (tn.hi.y - o.y) / d.y;
+                            const float t1 = (tn.lo.y - o.y) * id.y, t2 = (tn.hi.y - o.y) * id.y;
                             tmin = fmaxf(tmin, fminf(t1, t2));
                             tmax = fminf(tmax, fmaxf(t1, t2));
                         }
                         if (d.z != 0.0f) {
-                            float t1 = (tn.lo.z - o.z) / d.z, t2 = (tn.hi.z - o.z) / d.z;
+                            const float t1 = (tn.lo.z - o.z) * id.z, t2 = (tn.hi.z - o.z) * id.z;
                             tmin = fmaxf(tmin, fminf(t1, t2));
                             tmax = fminf(tmax, fmaxf(t1, t2));
                         }
                         if (tmax >= tmin && tmax >= 0.f && tmin < tClosest) {
                             const uint32_t ca = asU(tn.lo.w), cb = asU(tn.hi.w);
                             if (cb == 0xFFFFFFFFu) { // leaf: enter the instance
-                                const Instance in = sc.instances[ca];
+                                const Instance in = instances[ca];
                                 to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w,
                                     in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
                                     in.r2.x * o.x + in.r2.y * o.y + in.r2.z * o.z + in.r2.w);
@@ -186,18 +231,18 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                                 curInst = (int)ca; // instance index; pt_intersect reports the top-level leaf
                                 sp = 0;
                             } else { // inner: nearer box centre is visited first (scene.cl:141-157)
-                                const TopNode l = sc.top[ca];
-                                const TopNode r = sc.top[cb];
+                                const TopNode l = topNodes[ca];
+                                const TopNode r = topNodes[cb];
                                 const V3 lv = (xyz(l.lo) + xyz(l.hi)) / 2.0f - o;
                                 const V3 rv = (xyz(r.lo) + xyz(r.hi)) / 2.0f - o;
                                 const bool leftFirst = dot(lv, lv) < dot(rv, rv);
-                                spillTop[(size_t)tsp * total] = leftFirst ? cb : ca;
-                                spillTop[(size_t)(tsp + 1) * total] = leftFirst ? ca : cb;
+                                pushTop(tsp, leftFirst ? cb : ca);
+                                pushTop(tsp + 1, leftFirst ? ca : cb);
                                 tsp += 2;
                             }
                         }
                     }
-                } else if (refCount(cur) == 0u) {
+                } else if (kind == 1 && wantInner) {
                     // ---------------- bottom level, inner step (scene.cl:197-231) ----------------
                     const PairNode* np = &sc.nodes[refIndex(cur)];
                     const float4 bx = np->bx, by = np->by, bz = np->bz;
@@ -228,12 +273,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                     } else if (rvis) {
                         cur = rref;
                     } else if (sp > 0) {
-                        sp--;
-                        cur = (sp < kLdsStack) ? ldsStack[wave][sp][lane] : spillBottom[(size_t)(sp - kLdsStack) * total];
+                        cur = popBottom(--sp);
                     } else {
                         cur = kRefNone;
                     }
-                } else {
+                } else if (kind == 2 && wantLeaf) {
                     // ---------------- bottom level, leaf (scene.cl:168-195, shapes.cl:20-72) -------
                     const uint32_t first = refIndex(cur), n = refCount(cur);
                     bool done = false;
@@ -272,8 +316,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                             a.occluded[rayIdx] = 1u;
                         active = false;
                     } else if (sp > 0) {
-                        sp--;
-                        cur = (sp < kLdsStack) ? ldsStack[wave][sp][lane] : spillBottom[(size_t)(sp - kLdsStack) * total];
+                        cur = popBottom(--sp);
                     } else {
                         cur = kRefNone;
                     }

@@ -258,14 +258,36 @@ int ensureSpill(pt_ctx* c)
     if (c->spill.p)
         return PT_OK;
     int blocksPerCU = 0;
-    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, k_trace<false>, kTraceBlock, 0));
-    int blocksAny = 0;
-    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksAny, k_trace<true>, kTraceBlock, 0));
-    blocksPerCU = std::max(1, std::min(std::min(blocksPerCU, blocksAny), 8));
+    blocksPerCU = 8;
+    const void* variants[4] = { (const void*)k_trace<false, false>, (const void*)k_trace<false, true>, (const void*)k_trace<true, false>,
+        (const void*)k_trace<true, true> };
+    for (const void* fn : variants) {
+        int b = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
+        blocksPerCU = std::min(blocksPerCU, b);
+    }
+    blocksPerCU = std::max(1, blocksPerCU);
     c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
     const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
     HIPCHK(c, c->spill.alloc(threads * (kSpillStack + kTopStack)));
     return PT_OK;
+}
+
+void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
+{
+    const bool topLds = a.numTopNodes <= (uint32_t)kTopLdsNodes && a.numInstances <= (uint32_t)kTopLdsInstances;
+    const dim3 grid(c->traceBlocks), block(kTraceBlock);
+    if (anyHit) {
+        if (topLds)
+            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, a);
+    } else {
+        if (topLds)
+            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, a);
+    }
 }
 
 TraceArgs traceArgsBase(pt_ctx* c)
@@ -275,6 +297,8 @@ TraceArgs traceArgsBase(pt_ctx* c)
     a.spill = c->spill.p;
     a.totalThreads = c->traceBlocks * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
+    a.numTopNodes = (uint32_t)c->top.n;
+    a.numInstances = (uint32_t)c->instanceTopNode.size();
     return a;
 }
 
@@ -337,7 +361,7 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass)
     a.inst = c->hitInst.p;
     a.count = &ctl->extCount[pass];
     a.cursor = &ctl->extCursor[pass];
-    hipLaunchKernelGGL(k_trace<false>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+    launchTrace(c, false, a);
 }
 
 void launchShadow(pt_ctx* c, uint32_t pass)
@@ -350,7 +374,7 @@ void launchShadow(pt_ctx* c, uint32_t pass)
     a.accum = accumView(c);
     a.count = &ctl->shadowCount[pass];
     a.cursor = &ctl->shadowCursor[pass];
-    hipLaunchKernelGGL(k_trace<true>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+    launchTrace(c, true, a);
 }
 
 // shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
@@ -1114,10 +1138,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 1u }, a.occluded = dOcc.p;
         a.count = dCtl.p, a.cursor = dCtl.p + 1;
         chk(hipEventRecord(e0, c->stream));
-        if (any_hit)
-            hipLaunchKernelGGL(k_trace<true>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(k_trace<false>, dim3(c->traceBlocks), dim3(kTraceBlock), 0, c->stream, a);
+        launchTrace(c, any_hit != 0, a);
         chk(hipEventRecord(e1, c->stream));
         chk(hipStreamSynchronize(c->stream));
         chk(hipGetLastError());
