@@ -22,14 +22,24 @@
 
 namespace ptd {
 
+#ifndef PT_LEAF_BATCH
+#define PT_LEAF_BATCH 4
+#endif
+#ifndef PT_REFILL_IDLE
+#define PT_REFILL_IDLE 20
+#endif
+#ifndef PT_TRACE_MIN_WAVES
+#define PT_TRACE_MIN_WAVES 1
+#endif
 constexpr int kLdsStack = 20; // bottom-level entries kept in LDS per lane
 constexpr int kSpillStack = 52; // further bottom-level entries in global memory
 constexpr int kTopLdsStack = 8; // top-level entries kept in LDS per lane
 constexpr int kTopStack = 64; // top-level entries overall (LDS + global spill)
 constexpr int kTraceBlock = 256;
-constexpr int kRefillIdleLanes = 20; // refill the wave once this many lanes are idle
+constexpr int kRefillIdleLanes = PT_REFILL_IDLE; // refill the wave once this many lanes are idle
 constexpr int kTopLdsNodes = 128; // top-level nodes / instances staged in LDS (TOP_LDS variant)
 constexpr int kTopLdsInstances = 64;
+constexpr int kLeafBatch = PT_LEAF_BATCH; // triangles fetched together in a leaf
 
 struct TraceArgs {
     SceneDev sc;
@@ -51,7 +61,7 @@ struct TraceArgs {
 };
 
 template <bool ANY_HIT, bool TOP_LDS>
-__global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
     __shared__ uint32_t ldsTopStack[kTraceBlock / 64][kTopLdsStack][64];
@@ -105,25 +115,53 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
     float4 contrib = make_float4(0, 0, 0, 0);
     uint32_t pixel = 0;
 
+    // ---- per-wave ray packets ------------------------------------------------------------------
+    // A wave claims 64 consecutive queue entries with one atomicAdd and loads them with fully coalesced
+    // 16 B/lane reads into registers (lane i holds entry i).  Idle lanes are handed their next ray by
+    // ballot rank through a cross-lane read (ds_bpermute) of those registers, so a refill costs no
+    // memory round trip; as soon as a packet has been handed out completely the next one is requested,
+    // and its loads are in flight while the rays just handed out are traversed.
+    float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO, poolC = poolO;
+    uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
+    auto requestPacket = [&]() {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(a.cursor, 64u);
+        base = __shfl(base, 0);
+        poolBase = base;
+        poolNext = 0;
+        poolEnd = base < count ? min(64u, count - base) : 0u;
+        if (lane < poolEnd) {
+            poolO = a.rayO[base + lane];
+            poolD = a.rayD[base + lane];
+            if (ANY_HIT)
+                poolC = a.rayC[base + lane];
+        }
+    };
+    requestPacket();
+
     while (true) {
-        // ---- refill idle lanes (one atomic per wave) ------------------------------------
+        // ---- hand rays to idle lanes ----------------------------------------------------------
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nIdle = __popcll(idle);
             if (nIdle >= kRefillIdleLanes) {
-                uint32_t base = 0;
-                if (lane == 0)
-                    base = atomicAdd(a.cursor, (uint32_t)nIdle);
-                base = __shfl(base, 0);
-                if (!active) {
+                const uint32_t avail = poolEnd - poolNext;
+                if (avail == 0u) {
+                    exhausted = true; // the request issued after the last hand-out came back empty
+                } else {
                     const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    const uint32_t idx = base + rank;
-                    if (idx < count) {
-                        const float4 ro = a.rayO[idx];
-                        const float4 rd = a.rayD[idx];
+                    const int e = (int)min(poolNext + rank, 63u);
+                    float4 ro, rd, rc;
+                    ro.x = __shfl(poolO.x, e), ro.y = __shfl(poolO.y, e), ro.z = __shfl(poolO.z, e), ro.w = __shfl(poolO.w, e);
+                    rd.x = __shfl(poolD.x, e), rd.y = __shfl(poolD.y, e), rd.z = __shfl(poolD.z, e), rd.w = __shfl(poolD.w, e);
+                    if (ANY_HIT)
+                        rc.x = __shfl(poolC.x, e), rc.y = __shfl(poolC.y, e), rc.z = __shfl(poolC.z, e), rc.w = __shfl(poolC.w, e);
+                    if (!active && rank < avail) {
+                        const uint32_t idx = poolBase + (uint32_t)e;
                         bool live = true;
                         if (ANY_HIT) {
-                            contrib = a.rayC[idx];
+                            contrib = rc;
                             pixel = asU(rd.w);
                             tMax = ro.w;
                             if (a.parityShadow && (asU(contrib.w) & FLAG_FINISHED))
@@ -152,9 +190,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                             active = true;
                         }
                     }
+                    poolNext += min((uint32_t)nIdle, avail);
+                    if (poolNext == poolEnd)
+                        requestPacket();
                 }
-                if (base + (uint32_t)nIdle >= count)
-                    exhausted = true;
             }
         }
         if (__ballot(active) == 0ull) {
@@ -281,34 +320,43 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a)
                     // ---------------- bottom level, leaf (scene.cl:168-195, shapes.cl:20-72) -------
                     const uint32_t first = refIndex(cur), n = refCount(cur);
                     bool done = false;
-                    for (uint32_t k = 0; k < n; k++) {
-                        const TriIsect* tp = &sc.tris[first + k];
-                        const float4 ta = tp->a, tb = tp->b, tc = tp->c;
-                        const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc.x);
-                        const V3 P = cross(td, e2);
-                        const float det = dot(e1, P);
-                        if (det > -FLT_MIN && det < FLT_MIN)
-                            continue;
-                        const float inv = 1.f / det;
-                        const V3 T = to - v0;
-                        const float u = dot(T, P) * inv;
-                        if (u < 0.f || u > 1.f)
-                            continue;
-                        const V3 Q = cross(T, e1);
-                        const float v = dot(td, Q) * inv;
-                        if (v < 0.f || u + v > 1.f)
-                            continue;
-                        const float t = dot(e2, Q) * inv;
-                        if (t > 0.f && t < tClosest) {
-                            if (ANY_HIT) {
-                                done = true;
-                                break;
+                    // Triangles are fetched kLeafBatch at a time so that their 3 x 16 B loads are all in
+                    // flight together (one memory round trip per batch instead of one per triangle); the
+                    // tests then run in index order against the running closestT, as the reference does.
+                    for (uint32_t k0 = 0; k0 < n && !done; k0 += kLeafBatch) {
+                        float4 ta[kLeafBatch], tb[kLeafBatch];
+                        float tc[kLeafBatch];
+#pragma unroll
+                        for (int j = 0; j < kLeafBatch; j++) {
+                            const TriIsect* tp = &sc.tris[first + min(k0 + (uint32_t)j, n - 1u)];
+                            ta[j] = tp->a, tb[j] = tp->b, tc[j] = tp->c.x;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kLeafBatch; j++) {
+                            if (k0 + (uint32_t)j < n && !done) {
+                                const V3 v0 = mk(ta[j].x, ta[j].y, ta[j].z), e1 = mk(ta[j].w, tb[j].x, tb[j].y), e2 = mk(tb[j].z, tb[j].w, tc[j]);
+                                const V3 P = cross(td, e2);
+                                const float det = dot(e1, P);
+                                const float inv = 1.f / det;
+                                const V3 T = to - v0;
+                                const float u = dot(T, P) * inv;
+                                const V3 Q = cross(T, e1);
+                                const float v = dot(td, Q) * inv;
+                                const float t = dot(e2, Q) * inv;
+                                const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f)
+                                    && t > 0.f && t < tClosest;
+                                if (hit) {
+                                    if (ANY_HIT) {
+                                        done = true;
+                                    } else {
+                                        tClosest = t;
+                                        hu = u;
+                                        hv = v;
+                                        hprim = (int)(first + k0 + (uint32_t)j);
+                                        hinst = curInst;
+                                    }
+                                }
                             }
-                            tClosest = t;
-                            hu = u;
-                            hv = v;
-                            hprim = (int)(first + k);
-                            hinst = curInst;
                         }
                     }
                     if (ANY_HIT && done) { // occluded: nothing to deposit

@@ -6,7 +6,7 @@ import numpy as np
 from . import layout as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEVICE_LIB_PATH = os.path.join(_HERE, "..", "csrc", "libptamd.so")
+DEVICE_LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "..", "csrc", "libptamd.so")  # PTAMD_LIB: tuning builds
 
 RNG_COUNTER, RNG_LFSR113_PARITY = 0, 1
 FLAG_ROWMAJOR_PIXELS = 1
@@ -62,6 +62,12 @@ def lib():
         if not os.path.exists(DEVICE_LIB_PATH):
             raise RuntimeError(f"{DEVICE_LIB_PATH} missing: the HIP extension was not built "
                                "(run __graft_entry__.build()); there is no CPU fallback")
+        try:
+            # torch ships its own libamdhip64; two HIP runtimes in one process do not both see the GPU.
+            # Importing torch first makes libptamd.so bind to the runtime torch has already loaded.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(DEVICE_LIB_PATH)
         l.pt_last_error.restype = C.c_char_p
         l.pt_last_error.argtypes = [C.c_void_p]

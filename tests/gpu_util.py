@@ -49,9 +49,18 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=2e-3):
     same_geom = np.all(tri_vertex_ids(flat, got["prim"][both]) == tri_vertex_ids(flat, want["prim"][both]), axis=1)
     same = same_geom & (got["inst"][both] == want["inst"][both])
     assert (~same).mean() <= max_tie_frac, f"{(~same).sum()} of {both.sum()} rays hit a different primitive"
-    uv_ok = same
-    assert np.allclose(got["u"][both][uv_ok], want["u"][both][uv_ok], atol=2e-4)
-    assert np.allclose(got["v"][both][uv_ok], want["v"][both][uv_ok], atol=2e-4)
+    # barycentrics: compared through the hit point they encode (object space), v0 + u*e1 + v*e2, because
+    # u and v of a grazing hit are ill-conditioned (errors scale with 1/det) while the point is not
+    tri = flat.triangles["indices"][want["prim"][both][same]]
+    p0, p1, p2 = (flat.vertices["vertex"][tri[:, k], :3].astype(np.float64) for k in range(3))
+
+    def point(h):
+        u, v = h["u"][both][same].astype(np.float64)[:, None], h["v"][both][same].astype(np.float64)[:, None]
+        return p0 + u * (p1 - p0) + v * (p2 - p0)
+    extent = float(np.abs(flat.vertices["vertex"][:, :3]).max())
+    assert np.abs(point(got) - point(want)).max() < 2e-4 * max(extent, 1.0)
+    assert np.allclose(got["u"][both][same], want["u"][both][same], atol=5e-3)
+    assert np.allclose(got["v"][both][same], want["v"][both][same], atol=5e-3)
     return dict(flips=int(flips.sum()), ties=int((~same).sum()), n=int(both.sum()))
 
 
