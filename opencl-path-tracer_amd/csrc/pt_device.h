@@ -24,12 +24,19 @@ struct PairNode {
     uint32_t _pad0, _pad1;
 };
 
-// child reference: count (5 bits, 0 = inner) | index (27 bits).  inner: index of a PairNode;
-// leaf: first triangle.  Leaves larger than 31 are split at upload.
+// child reference: kind/count (5 bits) | index (27 bits).
+//   count 0      : inner node, index of a PairNode (top level and bottom level share the array)
+//   count 1..30  : leaf, index of its first triangle (larger leaves are split at upload)
+//   count 31     : special -- index = instance to enter, or one of the two markers below
 constexpr uint32_t kRefIndexBits = 27;
 constexpr uint32_t kRefIndexMask = (1u << kRefIndexBits) - 1u;
-constexpr uint32_t kMaxLeafTris = 31;
-constexpr uint32_t kRefNone = 0xFFFFFFFFu;
+constexpr uint32_t kMaxLeafTris = 30;
+constexpr uint32_t kRefSpecial = 31;
+constexpr uint32_t kSpecialFinish = kRefIndexMask; // nothing left to traverse
+constexpr uint32_t kSpecialLeaveInstance = kRefIndexMask - 1u; // stack sentinel: restore the world-space ray
+constexpr uint32_t kRefFinish = 0xFFFFFFFFu;
+constexpr uint32_t kRefLeaveInstance = (kRefSpecial << kRefIndexBits) | kSpecialLeaveInstance;
+constexpr uint32_t kRefNone = kRefFinish;
 __host__ __device__ inline uint32_t makeRef(uint32_t index, uint32_t count) { return (count << kRefIndexBits) | index; }
 __host__ __device__ inline uint32_t refIndex(uint32_t r) { return r & kRefIndexMask; }
 __host__ __device__ inline uint32_t refCount(uint32_t r) { return r >> kRefIndexBits; }
@@ -51,11 +58,6 @@ struct VertexShade { // 32 B
     float4 v_pad; // texCoord.y
 };
 
-// top-level node (32 B) -- TopBvhNode (bvh.cl:18-34) without the matrix
-struct TopNode {
-    float4 lo; // min.xyz, bits(a): left child | instance index for a leaf
-    float4 hi; // max.xyz, bits(b): right child | 0xFFFFFFFF for a leaf
-};
 // instance (64 B): rows of the 3x4 inverse world transform + root reference of the mesh BVH
 struct Instance {
     float4 r0, r1, r2; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major matrix
@@ -87,13 +89,12 @@ struct SceneDev {
     const TriShade* triShade;
     const VertexShade* verts;
     const Material* materials;
-    const TopNode* top;
     const Instance* instances;
     const Light* lights;
     Texture materialTex;
     Texture sky;
     uint32_t numLights;
-    uint32_t topRoot;
+    uint32_t rootRef; // reference of the top-level root: a PairNode, or an instance when there is only one
     uint32_t numTriangles;
     uint32_t _pad;
 };

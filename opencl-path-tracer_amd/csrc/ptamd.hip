@@ -68,11 +68,11 @@ struct pt_ctx {
     DevBuf<TriShade> triShade;
     DevBuf<VertexShade> verts;
     DevBuf<Material> materials;
-    DevBuf<TopNode> top;
     DevBuf<Instance> instances;
     DevBuf<Light> lights;
     DevBuf<float4> texMaterial, texSky;
     SceneDev scene {};
+    std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
     std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
     std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
     std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
@@ -141,7 +141,6 @@ void refreshSceneView(pt_ctx* c)
     s.triShade = c->triShade.p;
     s.verts = c->verts.p;
     s.materials = c->materials.p;
-    s.top = c->top.p;
     s.instances = c->instances.p;
     s.lights = c->lights.p;
     s.materialTex.texels = c->texMaterial.p;
@@ -259,8 +258,7 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     int blocksPerCU = 0;
     blocksPerCU = 8;
-    const void* variants[4] = { (const void*)k_trace<false, false>, (const void*)k_trace<false, true>, (const void*)k_trace<true, false>,
-        (const void*)k_trace<true, true> };
+    const void* variants[2] = { (const void*)k_trace<false>, (const void*)k_trace<true> };
     for (const void* fn : variants) {
         int b = 0;
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
@@ -269,25 +267,17 @@ int ensureSpill(pt_ctx* c)
     blocksPerCU = std::max(1, blocksPerCU);
     c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
     const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
-    HIPCHK(c, c->spill.alloc(threads * (kSpillStack + kTopStack)));
+    HIPCHK(c, c->spill.alloc(threads * kSpillStack));
     return PT_OK;
 }
 
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
-    const bool topLds = a.numTopNodes <= (uint32_t)kTopLdsNodes && a.numInstances <= (uint32_t)kTopLdsInstances;
     const dim3 grid(c->traceBlocks), block(kTraceBlock);
-    if (anyHit) {
-        if (topLds)
-            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, a);
-        else
-            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, a);
-    } else {
-        if (topLds)
-            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, a);
-        else
-            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, a);
-    }
+    if (anyHit)
+        hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
 }
 
 TraceArgs traceArgsBase(pt_ctx* c)
@@ -297,8 +287,6 @@ TraceArgs traceArgsBase(pt_ctx* c)
     a.spill = c->spill.p;
     a.totalThreads = c->traceBlocks * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
-    a.numTopNodes = (uint32_t)c->top.n;
-    a.numInstances = (uint32_t)c->instanceTopNode.size();
     return a;
 }
 
@@ -574,7 +562,7 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->top.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
@@ -740,8 +728,9 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
 
     int rc;
     if ((rc = uploadVec(c, c->tris, hTris)) || (rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
-        || (rc = uploadVec(c, c->materials, hMats)) || (rc = uploadVec(c, c->nodes, hNodes)))
+        || (rc = uploadVec(c, c->materials, hMats)))
         return rc;
+    c->hostBottomNodes = std::move(hNodes);
     c->numRefNodes = nN;
     c->numTris = nT;
     c->haveStatic = true;
@@ -762,17 +751,18 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
     HIPCHK(c, hipSetDevice(c->device));
 
-    std::vector<TopNode> hTop(nTop);
+    // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
     std::vector<Instance> hInst;
+    std::vector<uint32_t> topRef(nTop, kRefNone); // reference of top node i as a child
     c->instanceTopNode.clear();
+    uint32_t numTopInner = 0, maxBottomDepth = 0;
+    const uint32_t bottomCount = (uint32_t)c->hostBottomNodes.size();
     for (uint32_t i = 0; i < nTop; i++) {
         const pt_top_bvh_node& n = topNodes[i];
-        uint32_t a, b;
         if (n.isLeaf) {
             if (n.a >= c->numRefNodes || c->nodeRef[n.a] == kRefNone)
                 return fail(c, PT_ERR_INVALID, "top-level leaf %u: sub-BVH root %u is not a valid node", i, n.a);
-            if (c->subtreeDepth[n.a] + 1 > (uint32_t)(kLdsStack + kSpillStack))
-                return fail(c, PT_ERR_UNSUPPORTED, "top-level leaf %u: sub-BVH depth %u exceeds the traversal stack (%d)", i, c->subtreeDepth[n.a], kLdsStack + kSpillStack);
+            maxBottomDepth = std::max(maxBottomDepth, c->subtreeDepth[n.a] + 1);
             Instance in {};
             const float* m = n.invTransform; // column-major
             in.r0 = make_float4(m[0], m[4], m[8], m[12]);
@@ -780,23 +770,19 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             in.r2 = make_float4(m[2], m[6], m[10], m[14]);
             in.rootRef = c->nodeRef[n.a];
             in.topNode = i;
-            a = (uint32_t)hInst.size();
-            b = 0xFFFFFFFFu;
+            if (hInst.size() >= kSpecialLeaveInstance)
+                return fail(c, PT_ERR_UNSUPPORTED, "too many instances");
+            topRef[i] = makeRef((uint32_t)hInst.size(), kRefSpecial);
             hInst.push_back(in);
             c->instanceTopNode.push_back(i);
         } else {
             if (n.a >= nTop || n.b >= nTop)
                 return fail(c, PT_ERR_INVALID, "top-level node %u: child out of range", i);
-            a = n.a;
-            b = n.b;
+            topRef[i] = makeRef(bottomCount + numTopInner, 0);
+            numTopInner++;
         }
-        uint32_t ua = a, ub = b;
-        float fa, fb;
-        std::memcpy(&fa, &ua, 4);
-        std::memcpy(&fb, &ub, 4);
-        hTop[i].lo = make_float4(n.min[0], n.min[1], n.min[2], fa);
-        hTop[i].hi = make_float4(n.max[0], n.max[1], n.max[2], fb);
     }
+    uint32_t topDepth = 0;
     { // depth / cycle check from the root
         std::vector<std::pair<uint32_t, uint32_t>> st { { topRoot, 1u } };
         size_t visited = 0;
@@ -805,13 +791,33 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             st.pop_back();
             if (++visited > nTop)
                 return fail(c, PT_ERR_INVALID, "top-level BVH is not a tree");
-            if (depth + 1 > (uint32_t)kTopStack)
-                return fail(c, PT_ERR_UNSUPPORTED, "top-level BVH deeper than %d", kTopStack - 1);
+            topDepth = std::max(topDepth, depth);
             if (!topNodes[ni].isLeaf) {
                 st.push_back({ topNodes[ni].a, depth + 1 });
                 st.push_back({ topNodes[ni].b, depth + 1 });
             }
         }
+    }
+    // one pending entry per level of either tree + the leave-instance sentinel
+    if (topDepth + 1 + maxBottomDepth > (uint32_t)(kLdsStack + kSpillStack))
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kLdsStack + kSpillStack);
+    if ((uint64_t)bottomCount + numTopInner > kRefIndexMask)
+        return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
+    std::vector<PairNode> hNodes = c->hostBottomNodes;
+    hNodes.resize(bottomCount + numTopInner);
+    for (uint32_t i = 0; i < nTop; i++) {
+        const pt_top_bvh_node& n = topNodes[i];
+        if (n.isLeaf)
+            continue;
+        const pt_top_bvh_node& L = topNodes[n.a];
+        const pt_top_bvh_node& R = topNodes[n.b];
+        PairNode pn {};
+        pn.bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
+        pn.by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
+        pn.bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
+        pn.left = topRef[n.a];
+        pn.right = topRef[n.b];
+        hNodes[refIndex(topRef[i])] = pn;
     }
     std::vector<Light> hLights(nL);
     for (uint32_t i = 0; i < nL; i++) {
@@ -833,10 +839,10 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc;
-    if ((rc = uploadVec(c, c->top, hTop)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    if ((rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
-    c->scene.topRoot = topRoot;
+    c->scene.rootRef = topRef[topRoot];
     c->haveDynamic = true;
     refreshSceneView(c);
     return PT_OK;
