@@ -1,0 +1,87 @@
+#include "raytracer.h"
+#include <cstring>
+
+namespace raytracer {
+
+void RayTracer::check(int rc, const char* what)
+{
+    if (rc != PT_OK)
+        throw std::runtime_error(std::string(what) + ": " + pt_last_error(m_ctx));
+}
+
+RayTracer::RayTracer(int width, int height, std::shared_ptr<Scene> scene, const TextureArray& materialTextures, const TextureArray& skydomeTextures,
+    int device, uint32_t seed)
+    : m_scene(std::move(scene)), m_width(width), m_height(height)
+{
+    pt_config cfg {};
+    cfg.width = (uint32_t)width;
+    cfg.height = (uint32_t)height;
+    cfg.device = device;
+    cfg.seed = seed;
+    cfg.samples_in_flight = 1; // rayTrace() adds exactly one sample per call, like the reference
+    if (pt_create(&cfg, &m_ctx) != PT_OK)
+        throw std::runtime_error(std::string("pt_create: ") + pt_last_error(nullptr));
+    // static geometry once (reference: initBuffersAndTransferStaticData, src/raytracer.cpp:201-287) ...
+    flattenStatic(*m_scene, m_flat);
+    check(pt_upload_static(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.triangles.data(), (uint32_t)m_flat.triangles.size(),
+              m_flat.materials.data(), (uint32_t)m_flat.materials.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
+        "pt_upload_static");
+    if (materialTextures.layers)
+        check(pt_upload_texture_array(m_ctx, 0, materialTextures.width, materialTextures.height, materialTextures.layers, materialTextures.rgba.data()),
+            "pt_upload_texture_array(material)");
+    if (skydomeTextures.layers)
+        check(pt_upload_texture_array(m_ctx, 1, skydomeTextures.width, skydomeTextures.height, skydomeTextures.layers, skydomeTextures.rgba.data()),
+            "pt_upload_texture_array(skydome)");
+    // ... then the dynamic part (lights + top-level BVH), as the reference's constructor ends with frameTick()
+    frameTick();
+}
+
+RayTracer::~RayTracer() { pt_destroy(m_ctx); }
+
+void RayTracer::frameTick()
+{
+    flattenDynamic(*m_scene, m_flat);
+    check(pt_upload_dynamic(m_ctx, m_flat.emissiveTriangles.data(), (uint32_t)m_flat.emissiveTriangles.size(), m_flat.topBvhNodes.data(),
+              (uint32_t)m_flat.topBvhNodes.size(), m_flat.topBvhRoot),
+        "pt_upload_dynamic");
+}
+
+void RayTracer::rayTrace(const Camera& camera)
+{
+    const CameraData cam = camera.get_camera_data();
+    if (!m_haveCamera || std::memcmp(&cam, &m_prevCamera, sizeof(CameraData)) != 0) { // src/raytracer.cpp:99-105
+        m_prevCamera = cam;
+        m_haveCamera = true;
+        check(pt_set_camera(m_ctx, &cam), "pt_set_camera");
+        check(pt_clear(m_ctx), "pt_clear");
+    }
+    if (getSamplesPerPixel() >= getMaxSamplesPerPixel())
+        return;
+    check(pt_render(m_ctx, 1), "pt_render");
+    check(pt_synchronize(m_ctx), "pt_synchronize"); // queue.finish(), src/raytracer.cpp:117-118
+}
+
+int RayTracer::getSamplesPerPixel() const { return (int)pt_samples_per_pixel(m_ctx); }
+
+std::vector<float> RayTracer::getOutput()
+{
+    std::vector<float> out((size_t)m_width * m_height * 4);
+    check(pt_resolve(m_ctx, out.data()), "pt_resolve");
+    return out;
+}
+
+std::vector<float> RayTracer::getAccumulator()
+{
+    std::vector<float> out((size_t)m_width * m_height * 4);
+    check(pt_read_accum(m_ctx, out.data()), "pt_read_accum");
+    return out;
+}
+
+pt_stats RayTracer::getStats()
+{
+    pt_stats s;
+    check(pt_stats_get(m_ctx, &s), "pt_stats_get");
+    return s;
+}
+
+} // namespace raytracer

@@ -1,0 +1,60 @@
+// RayTracer with the reference's public surface (src/raytracer.h:20-30) on top of the HIP C-ABI
+// (include/ptamd.h).  Differences a caller sees: no GL target (the image is fetched with
+// getOutput()/getAccumulator() -- the GPU box is headless), texture arrays are plain float RGBA
+// arrays instead of FreeImage-loaded files.
+#pragma once
+#include "../../include/ptamd.h"
+#include "camera.h"
+#include "scene.h"
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace raytracer {
+
+// what UniqueTextureArray / CLTextureArray hold after loading (src/opencl/texture.h:18-49):
+// `layers` RGBA float images of one size, already linear and brightness-scaled
+struct TextureArray {
+    uint32_t width = 0, height = 0, layers = 0;
+    std::vector<float> rgba;
+    int add(const float* texels, uint32_t w, uint32_t h)
+    {
+        if (layers == 0)
+            width = w, height = h;
+        if (w != width || h != height)
+            throw std::invalid_argument("TextureArray: all layers must have the same size");
+        rgba.insert(rgba.end(), texels, texels + (size_t)w * h * 4);
+        return (int)layers++;
+    }
+};
+
+class RayTracer {
+public:
+    RayTracer(int width, int height, std::shared_ptr<Scene> scene, const TextureArray& materialTextures, const TextureArray& skydomeTextures,
+        int device = 0, uint32_t seed = 1);
+    ~RayTracer();
+    RayTracer(const RayTracer&) = delete;
+    RayTracer& operator=(const RayTracer&) = delete;
+
+    void rayTrace(const Camera& camera); // one sample per pixel; resets the accumulation when the camera changed
+    void frameTick(); // re-flatten lights + top-level BVH after scene-graph transforms changed
+    int getSamplesPerPixel() const;
+    int getMaxSamplesPerPixel() const { return 20000000; } // MAX_SAMPLES_PER_PIXEL, src/raytracer.cpp:38
+
+    std::vector<float> getOutput(); // width*height RGBA in [0,1]: the `accumulate` kernel's image
+    std::vector<float> getAccumulator(); // width*height float4 HDR sums
+    pt_stats getStats();
+    pt_ctx* context() { return m_ctx; }
+
+private:
+    void check(int rc, const char* what);
+    pt_ctx* m_ctx = nullptr;
+    std::shared_ptr<Scene> m_scene;
+    FlattenedScene m_flat;
+    CameraData m_prevCamera;
+    bool m_haveCamera = false;
+    int m_width, m_height;
+};
+
+} // namespace raytracer

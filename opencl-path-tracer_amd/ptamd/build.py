@@ -39,5 +39,23 @@ def build_device(force=False):
     return out
 
 
+def build_raytracer(force=False):
+    """libptamd_raytracer.so: the C++ RayTracer class (host/raytracer.cpp) on top of both libraries,
+    and the examples/render_cornell demo that drives it."""
+    out = os.path.join(HOST_DIR, "libptamd_raytracer.so")
+    deps = _all_files(HOST_DIR, (".cpp", ".h"))
+    if force or _newer(out, deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "raytracer.cpp", "-o", out, "-L.", "-lptamd_host",
+                        "-L../csrc", "-lptamd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc"], cwd=HOST_DIR, check=True)
+    ex_dir = os.path.abspath(os.path.join(ROOT, "..", "examples"))
+    exe = os.path.join(ex_dir, "render_cornell")
+    if force or _newer(exe, [os.path.join(ex_dir, "render_cornell.cpp"), out]):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "render_cornell.cpp", "-o", "render_cornell", "-L" + HOST_DIR, "-lptamd_raytracer",
+                        "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
+    return out, exe
+
+
 def build_all(force=False):
-    return build_host(force), build_device(force)
+    host, dev = build_host(force), build_device(force)
+    build_raytracer(force)
+    return host, dev
