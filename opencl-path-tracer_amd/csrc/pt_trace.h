@@ -61,6 +61,15 @@ struct TraceArgs {
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
 };
 
+#ifdef PT_TRACE_STATS
+// diagnostic build only (tools/variants.sh ... -DPT_TRACE_STATS): where do the lanes of a wave go?
+// [0] iterations, [1] sum of active lanes, [2..4] iterations per kind, [5..7] lanes served per kind, [8] hand-outs, [9] rays
+__device__ unsigned long long g_traceStats[16];
+#define PT_STAT(i, v) statAcc[i] += (unsigned long long)(v)
+#else
+#define PT_STAT(i, v)
+#endif
+
 __device__ inline float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); } // v_rcp_f32, 1 ulp
 // Reciprocal direction for the slab test, clamped to +-1e18: a zero (or FLT_MIN, scene.cl:123-137)
 // component then yields plane distances of +-1e18 * (b - o) -- far beyond any scene, with the correct
@@ -88,6 +97,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     };
     auto pop = [&](int slot) -> uint32_t { return slot < kLdsStack ? ldsStack[wave][slot][lane] : spill[(size_t)(slot - kLdsStack) * total]; };
 
+#ifdef PT_TRACE_STATS
+    unsigned long long statAcc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
     uint32_t rayIdx = 0;
@@ -174,6 +186,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             active = true;
                         }
                     }
+                    PT_STAT(8, 1);
+                    PT_STAT(9, min((uint32_t)nIdle, avail));
                     poolNext += min((uint32_t)nIdle, avail);
                     if (poolNext == poolEnd)
                         requestPacket();
@@ -194,6 +208,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const bool wantSpecial = active && kindBits == kRefSpecial;
             const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf)), nSpecial = __popcll(__ballot(wantSpecial));
             const int kind = (nInner >= nLeaf && nInner >= nSpecial) ? 0 : (nLeaf >= nSpecial ? 1 : 2);
+            PT_STAT(0, 1);
+            PT_STAT(1, nInner + nLeaf + nSpecial);
+            PT_STAT(2 + kind, 1);
+            PT_STAT(5 + kind, kind == 0 ? nInner : (kind == 1 ? nLeaf : nSpecial));
             if (kind == 0) {
                 if (wantInner) {
                     // -------- inner step at either level (scene.cl:197-231): one 64-byte fetch, both child boxes
@@ -320,6 +338,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 break;
         }
     }
+#ifdef PT_TRACE_STATS
+    if (lane == 0)
+        for (int i = 0; i < 10; i++)
+            atomicAdd(&g_traceStats[i], statAcc[i]);
+#endif
 }
 
 } // namespace ptd

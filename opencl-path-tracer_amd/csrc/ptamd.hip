@@ -495,6 +495,17 @@ extern "C" {
 
 const char* pt_version(void) { return "ptamd 0.1 (gfx950)"; }
 
+#ifdef PT_TRACE_STATS
+// diagnostic builds only: read and clear the traversal-loop counters
+int pt_debug_trace_stats(unsigned long long* out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_traceStats), sizeof(unsigned long long) * 16) != hipSuccess)
+        return -1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_traceStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
 int pt_create(const pt_config* cfg, pt_ctx** out)

@@ -1,0 +1,35 @@
+"""Diagnostic: lane-level accounting of the k_trace loop (needs the -DPT_TRACE_STATS build)."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["PTAMD_LIB"] = os.path.join(ROOT, "opencl-path-tracer_amd", "csrc", "variants", "libptamd_stats.so")
+sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
+import numpy as np
+from ptamd import scenes, device as D
+
+def read():
+    out = (C.c_ulonglong * 16)()
+    assert D.lib().pt_debug_trace_stats(out) == 0
+    return list(out)
+
+def report(tag, s, nrays):
+    it, act, ki, kl, ks, li, ll, ls, ho, hr = s[:10]
+    print(f"{tag:12s} rays {nrays:8d} wave-iters/ray*64 {it*64/max(nrays,1):6.1f}  active/iter {act/max(it,1):5.1f}  iters inner/leaf/special {ki/it:.2f}/{kl/it:.2f}/{ks/it:.2f} "
+          f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
+
+W, Hh = 1920, 1080
+b = scenes.instanced_grid(W, Hh, level=6)
+ctx = D.Context(W, Hh, seed=1)
+ctx.upload_scene(b.flat, sky=b.sky); ctx.set_camera(b.camera)
+o, d, _ = ctx.gen_rays(0, W * Hh)
+read()
+r = ctx.intersect(o, d)
+report("primary", read(), len(o))
+hit = r["prim"] >= 0
+rng = np.random.default_rng(0)
+p = o[hit] + d[hit] * r["t"][hit][:, None] * 0.999
+nd = rng.normal(size=p.shape).astype(np.float32); nd /= np.linalg.norm(nd, axis=1, keepdims=True); nd[:, 1] = np.abs(nd[:, 1])
+ctx.intersect(p, nd)
+report("secondary", read(), len(p))
+tm = np.full(len(p), 3.0, np.float32)
+ctx.intersect(p, nd, tmax=tm, any_hit=True)
+report("shadow-like", read(), len(p))
