@@ -35,6 +35,15 @@ namespace ptd {
 #ifndef PT_TRACE_MIN_WAVES
 #define PT_TRACE_MIN_WAVES 4
 #endif
+#ifndef PT_VOTE_W_INNER
+#define PT_VOTE_W_INNER 4
+#endif
+#ifndef PT_VOTE_W_LEAF
+#define PT_VOTE_W_LEAF 4
+#endif
+#ifndef PT_VOTE_W_SPECIAL
+#define PT_VOTE_W_SPECIAL 4
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 26
 #endif
@@ -95,7 +104,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         else
             spill[(size_t)(slot - kLdsStack) * total] = v;
     };
-    auto pop = [&](int slot) -> uint32_t { return slot < kLdsStack ? ldsStack[wave][slot][lane] : spill[(size_t)(slot - kLdsStack) * total]; };
+    // always a plain ds_read_b32; the (rare) spilled entry overrides it.  Selecting between the two
+    // addresses instead makes hipcc emit ONE flat_load on the critical pop -> node-fetch path.
+    auto pop = [&](int slot) -> uint32_t {
+        uint32_t v = ldsStack[wave][min(slot, kLdsStack - 1)][lane];
+        if (slot >= kLdsStack)
+            v = ((const volatile uint32_t*)spill)[(size_t)(slot - kLdsStack) * total]; // volatile: keeps the two loads apart
+        return v;
+    };
 
 #ifdef PT_TRACE_STATS
     unsigned long long statAcc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -207,7 +223,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
             const bool wantSpecial = active && kindBits == kRefSpecial;
             const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf)), nSpecial = __popcll(__ballot(wantSpecial));
-            const int kind = (nInner >= nLeaf && nInner >= nSpecial) ? 0 : (nLeaf >= nSpecial ? 1 : 2);
+            const int wI = nInner * PT_VOTE_W_INNER, wL = nLeaf * PT_VOTE_W_LEAF, wS = nSpecial * PT_VOTE_W_SPECIAL;
+            const int kind = (wI >= wL && wI >= wS) ? 0 : (wL >= wS ? 1 : 2);
             PT_STAT(0, 1);
             PT_STAT(1, nInner + nLeaf + nSpecial);
             PT_STAT(2 + kind, 1);

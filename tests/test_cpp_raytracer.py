@@ -26,7 +26,7 @@ def test_cpp_raytracer_renders(gpu, tmp_path):
     assert int(fields["spp"]) == 32 and int(fields["rays"]) > 32 * 256 * 256
     data = out.read_bytes()
     assert data.startswith(b"P6\n256 256\n255\n") and len(data) == len(b"P6\n256 256\n255\n") + 256 * 256 * 3
-    assert 0.02 < float(fields["mean"]) < 0.9
+    assert 0.002 < float(fields["mean"]) < 0.9  # exposure 4.9e-3 (EV100 7.4) makes the tone-mapped room dark
     # same frame again: bit-identical image (counter PRNG, deterministic sums)
     out2 = tmp_path / "again.ppm"
     subprocess.run([EXE, "32", str(out2)], check=True, capture_output=True, timeout=120)
