@@ -44,12 +44,16 @@ namespace ptd {
 #ifndef PT_VOTE_W_SPECIAL
 #define PT_VOTE_W_SPECIAL 4
 #endif
+#ifndef PT_PARKED_BREAK
+#define PT_PARKED_BREAK 16
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 26
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 constexpr int kSpillStack = 100; // further entries in global memory
 constexpr int kTraceBlock = 256;
+constexpr int kParkedBreak = PT_PARKED_BREAK; // leave the hot loop once this many lanes are parked on a special step or idle
 constexpr int kRefillIdleLanes = PT_REFILL_IDLE; // hand out new rays once this many lanes are idle
 
 struct TraceArgs {
@@ -210,26 +214,87 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 }
             }
         }
+        // ---- resolve special references (instance entry / leave, end of traversal) -------------------
+        // They are kept OUT of the hot loop below: lanes that reach one park until the loop breaks, then all
+        // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
+        // the ray-space registers stay loop-invariant in it.
+        while (true) {
+            const bool wantSpecial = active && refCount(cur) == kRefSpecial;
+            const unsigned long long m = __ballot(wantSpecial);
+            if (m == 0ull)
+                break;
+            PT_STAT(4, 1);
+            PT_STAT(7, __popcll(m));
+            if (wantSpecial) {
+                const uint32_t what = refIndex(cur);
+                if (what == kSpecialFinish) {
+                    // -------- ray finished: closestT != maxT decides hit/miss (scene.cl:257) ------------
+                    if (ANY_HIT) {
+                        if (a.occluded)
+                            a.occluded[rayIdx] = 0u;
+                        float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                        float4 px = *ap;
+                        px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                        *ap = px;
+                    } else {
+                        a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+                        a.inst[rayIdx] = hinst;
+                    }
+                    active = false;
+                } else {
+                    const V3 o = mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]);
+                    const V3 d = mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]);
+                    if (what == kSpecialLeaveInstance) {
+                        // -------- back to world space ------------------------------------------------------
+                        setRay(o, d);
+                        curInst = -1;
+                        cur = sp > 0 ? pop(--sp) : kRefFinish;
+                    } else {
+                        // -------- enter instance `what` (scene.cl:116-139) ---------------------------------
+                        const Instance in = sc.instances[what];
+                        V3 to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w, in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
+                            in.r2.x * o.x + in.r2.y * o.y + in.r2.z * o.z + in.r2.w);
+                        V3 td = mk(in.r0.x * d.x + in.r0.y * d.y + in.r0.z * d.z, in.r1.x * d.x + in.r1.y * d.y + in.r1.z * d.z,
+                            in.r2.x * d.x + in.r2.y * d.y + in.r2.z * d.z);
+                        // NO_PARALLEL_RAYS fix-up (scene.cl:123-137)
+                        if (td.x == 0.0f) td.x = FLT_MIN;
+                        if (td.y == 0.0f) td.y = FLT_MIN;
+                        if (td.z == 0.0f) td.z = FLT_MIN;
+                        if (to.x == 0.0f) to.x = -FLT_MIN;
+                        if (to.y == 0.0f) to.y = -FLT_MIN;
+                        if (to.z == 0.0f) to.z = -FLT_MIN;
+                        setRay(to, td);
+                        curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
+                        push(sp, kRefLeaveInstance);
+                        sp++;
+                        cur = in.rootRef;
+                    }
+                }
+            }
+        }
         if (__ballot(active) == 0ull) {
             if (exhausted)
                 break;
             continue;
         }
 
-        // ---- traverse until enough lanes are idle again -----------------------------------
+        // ---- hot loop: inner steps and leaves, until enough lanes are parked (special) or idle -------
         while (true) {
             const uint32_t kindBits = refCount(cur);
             const bool wantInner = active && kindBits == 0u;
             const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
-            const bool wantSpecial = active && kindBits == kRefSpecial;
-            const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf)), nSpecial = __popcll(__ballot(wantSpecial));
-            const int wI = nInner * PT_VOTE_W_INNER, wL = nLeaf * PT_VOTE_W_LEAF, wS = nSpecial * PT_VOTE_W_SPECIAL;
-            const int kind = (wI >= wL && wI >= wS) ? 0 : (wL >= wS ? 1 : 2);
+            const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
             PT_STAT(0, 1);
-            PT_STAT(1, nInner + nLeaf + nSpecial);
-            PT_STAT(2 + kind, 1);
-            PT_STAT(5 + kind, kind == 0 ? nInner : (kind == 1 ? nLeaf : nSpecial));
-            if (kind == 0) {
+            PT_STAT(1, nInner + nLeaf);
+            // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
+            // enough lanes are idle for a hand-out (and the queue still has rays)
+            const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
+            const int nWork = nInner + nLeaf;
+            if (nWork == 0 || nSpecial >= kParkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
+                break;
+            if (nInner * PT_VOTE_W_INNER >= nLeaf * PT_VOTE_W_LEAF) {
+                PT_STAT(2, 1);
+                PT_STAT(5, nInner);
                 if (wantInner) {
                     // -------- inner step at either level (scene.cl:197-231): one 64-byte fetch, both child boxes
                     const PairNode* np = &sc.nodes[refIndex(cur)];
@@ -261,7 +326,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     }
                 }
-            } else if (kind == 1) {
+            } else {
+                PT_STAT(3, 1);
+                PT_STAT(6, nLeaf);
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
@@ -302,57 +369,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     }
                 }
-            } else {
-                if (wantSpecial) {
-                    const uint32_t what = refIndex(cur);
-                    if (what == kSpecialFinish) {
-                        // -------- ray finished: closestT != maxT decides hit/miss (scene.cl:257) ------------
-                        if (ANY_HIT) {
-                            if (a.occluded)
-                                a.occluded[rayIdx] = 0u;
-                            float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
-                            float4 px = *ap;
-                            px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
-                            *ap = px;
-                        } else {
-                            a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
-                            a.inst[rayIdx] = hinst;
-                        }
-                        active = false;
-                    } else {
-                        const V3 o = mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]);
-                        const V3 d = mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]);
-                        if (what == kSpecialLeaveInstance) {
-                            // -------- back to world space ------------------------------------------------------
-                            setRay(o, d);
-                            curInst = -1;
-                            cur = sp > 0 ? pop(--sp) : kRefFinish;
-                        } else {
-                            // -------- enter instance `what` (scene.cl:116-139) ---------------------------------
-                            const Instance in = sc.instances[what];
-                            V3 to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w, in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
-                                in.r2.x * o.x + in.r2.y * o.y + in.r2.z * o.z + in.r2.w);
-                            V3 td = mk(in.r0.x * d.x + in.r0.y * d.y + in.r0.z * d.z, in.r1.x * d.x + in.r1.y * d.y + in.r1.z * d.z,
-                                in.r2.x * d.x + in.r2.y * d.y + in.r2.z * d.z);
-                            // NO_PARALLEL_RAYS fix-up (scene.cl:123-137)
-                            if (td.x == 0.0f) td.x = FLT_MIN;
-                            if (td.y == 0.0f) td.y = FLT_MIN;
-                            if (td.z == 0.0f) td.z = FLT_MIN;
-                            if (to.x == 0.0f) to.x = -FLT_MIN;
-                            if (to.y == 0.0f) to.y = -FLT_MIN;
-                            if (to.z == 0.0f) to.z = -FLT_MIN;
-                            setRay(to, td);
-                            curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
-                            push(sp, kRefLeaveInstance);
-                            sp++;
-                            cur = in.rootRef;
-                        }
-                    }
-                }
             }
-            const int nActive = __popcll(__ballot(active));
-            if (nActive == 0 || (!exhausted && nActive <= 64 - kRefillIdleLanes))
-                break;
         }
     }
 #ifdef PT_TRACE_STATS
