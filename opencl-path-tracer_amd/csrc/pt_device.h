@@ -24,6 +24,19 @@ struct PairNode {
     uint32_t _pad0, _pad1;
 };
 
+// 4-wide node with 8-bit quantised child boxes (64 B), built at upload by collapsing every second level
+// of the pair-node tree (children of node i = its grandchildren where a child is an inner node).
+// Child box k = origin + 2^exp * q (per axis), q in [0,255], rounded outwards: a superset of the exact
+// box, so traversal visits at worst a few extra nodes and finds exactly the same triangles.  One step
+// now needs four 16-byte loads for four children instead of eight for the same two levels.
+struct WideNode {
+    float ox, oy, oz; // quantisation origin = min corner of the union of the children
+    uint32_t exps; // biased float exponents of the per-axis scale: ex | ey << 8 | ez << 16
+    uint32_t qlox, qhix, qloy, qhiy; // byte k of each word belongs to child k
+    uint32_t qloz, qhiz, _pad0, _pad1;
+    uint32_t child[4]; // references (kRefNone = empty slot)
+};
+
 // child reference: kind/count (5 bits) | index (27 bits).
 //   count 0      : inner node, index of a PairNode (top level and bottom level share the array)
 //   count 1..30  : leaf, index of its first triangle (larger leaves are split at upload)
@@ -84,7 +97,8 @@ struct Texture {
 };
 
 struct SceneDev {
-    const PairNode* nodes;
+    const PairNode* nodes; // PT_WIDE=0 builds
+    const WideNode* wide;
     const TriIsect* tris;
     const TriShade* triShade;
     const VertexShade* verts;

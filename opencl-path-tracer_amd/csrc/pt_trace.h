@@ -47,6 +47,9 @@ namespace ptd {
 #ifndef PT_PARKED_BREAK
 #define PT_PARKED_BREAK 16
 #endif
+#ifndef PT_WIDE
+#define PT_WIDE 1
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 26
 #endif
@@ -296,6 +299,58 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 if (wantInner) {
+#if PT_WIDE
+                    // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
+                    const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
+                    const uint4 A = wp[0], B = wp[1], C = wp[2], D = wp[3];
+                    // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
+                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
+                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    const float bx = fmaf(asF(A.x), cid.x, coid.x), by = fmaf(asF(A.y), cid.y, coid.y), bz = fmaf(asF(A.z), cid.z, coid.z);
+                    float key[4];
+                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float x0 = fmaf((float)((B.x >> (8 * k)) & 0xFFu), ax, bx), x1 = fmaf((float)((B.y >> (8 * k)) & 0xFFu), ax, bx);
+                        const float y0 = fmaf((float)((B.z >> (8 * k)) & 0xFFu), ay, by), y1 = fmaf((float)((B.w >> (8 * k)) & 0xFFu), ay, by);
+                        const float z0 = fmaf((float)((C.x >> (8 * k)) & 0xFFu), az, bz), z1 = fmaf((float)((C.y >> (8 * k)) & 0xFFu), az, bz);
+                        const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                        const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box
+                        const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest && ref[k] != kRefNone;
+                        key[k] = vis ? tmin : INFINITY;
+                    }
+                    // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
+#define PT_CSWAP(i, j)                                   \
+    {                                                    \
+        const bool sw = key[j] < key[i];                 \
+        const float tk = sw ? key[j] : key[i];           \
+        key[j] = sw ? key[i] : key[j];                   \
+        key[i] = tk;                                     \
+        const uint32_t tr = sw ? ref[j] : ref[i];        \
+        ref[j] = sw ? ref[i] : ref[j];                   \
+        ref[i] = tr;                                     \
+    }
+                    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+                    // farthest first onto the stack, continue with the nearest
+                    if (key[3] < INFINITY) {
+                        push(sp, ref[3]);
+                        sp++;
+                    }
+                    if (key[2] < INFINITY) {
+                        push(sp, ref[2]);
+                        sp++;
+                    }
+                    if (key[1] < INFINITY) {
+                        push(sp, ref[1]);
+                        sp++;
+                    }
+                    if (key[0] < INFINITY)
+                        cur = ref[0];
+                    else
+                        cur = sp > 0 ? pop(--sp) : kRefFinish;
+#else
                     // -------- inner step at either level (scene.cl:197-231): one 64-byte fetch, both child boxes
                     const PairNode* np = &sc.nodes[refIndex(cur)];
                     const float4 bx = np->bx, by = np->by, bz = np->bz;
@@ -325,6 +380,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     } else {
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     }
+#endif
                 }
             } else {
                 PT_STAT(3, 1);

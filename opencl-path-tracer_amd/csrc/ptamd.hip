@@ -64,6 +64,7 @@ struct pt_ctx {
 
     // scene (HBM)
     DevBuf<PairNode> nodes;
+    DevBuf<WideNode> wide;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> triShade;
     DevBuf<VertexShade> verts;
@@ -137,6 +138,7 @@ void refreshSceneView(pt_ctx* c)
 {
     SceneDev& s = c->scene;
     s.nodes = c->nodes.p;
+    s.wide = c->wide.p;
     s.tris = c->tris.p;
     s.triShade = c->triShade.p;
     s.verts = c->verts.p;
@@ -184,6 +186,94 @@ void lfsrJump(uint32_t g[4])
         ^ ((b >> 11) & 0x001FFFFF) ^ ((b >> 14) & 0x0003FFFF) ^ ((b >> 15) & 0x0001FFFF) ^ ((b >> 16) & 0x0000FFFF)
         ^ ((b >> 23) & 0x000001FF) ^ ((b >> 24) & 0x000000FF);
     g[3] = z;
+}
+
+// Collapse the pair-node tree into 4-wide nodes with 8-bit quantised child boxes (pt_device.h, WideNode).
+// wide[i] describes the same subtree as pair[i], so child references keep their indices.
+std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair)
+{
+    std::vector<WideNode> wide(pair.size());
+    struct Child {
+        float lo[3], hi[3];
+        uint32_t ref;
+    };
+    auto childOf = [](const PairNode& n, int side) {
+        Child c;
+        const float* bx = &n.bx.x;
+        const float* by = &n.by.x;
+        const float* bz = &n.bz.x;
+        c.lo[0] = bx[side * 2], c.hi[0] = bx[side * 2 + 1];
+        c.lo[1] = by[side * 2], c.hi[1] = by[side * 2 + 1];
+        c.lo[2] = bz[side * 2], c.hi[2] = bz[side * 2 + 1];
+        c.ref = side ? n.right : n.left;
+        return c;
+    };
+    for (size_t i = 0; i < pair.size(); i++) {
+        Child kids[4];
+        int n = 0;
+        for (int side = 0; side < 2; side++) {
+            Child c = childOf(pair[i], side);
+            if (refCount(c.ref) == 0u && refIndex(c.ref) < pair.size() && refIndex(c.ref) != i) {
+                const PairNode& g = pair[refIndex(c.ref)];
+                kids[n++] = childOf(g, 0);
+                kids[n++] = childOf(g, 1);
+            } else {
+                kids[n++] = c;
+            }
+        }
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for (int k = 0; k < n; k++)
+            for (int a = 0; a < 3; a++) {
+                if (kids[k].lo[a] <= kids[k].hi[a]) { // ignore empty boxes (pads)
+                    lo[a] = std::min(lo[a], kids[k].lo[a]);
+                    hi[a] = std::max(hi[a], kids[k].hi[a]);
+                }
+            }
+        WideNode w {};
+        uint32_t ex[3];
+        float scale[3];
+        for (int a = 0; a < 3; a++) {
+            if (!(lo[a] <= hi[a]))
+                lo[a] = hi[a] = 0.f;
+            // smallest power of two s with (hi - lo) / s <= 255, evaluated in float like the kernel does
+            int e = 0;
+            float extent = hi[a] - lo[a];
+            std::frexp(extent / 255.0f, &e); // extent/255 = m * 2^e, m in [0.5,1)  =>  2^e >= extent/255
+            e = std::max(-126, std::min(e, 127));
+            scale[a] = std::ldexp(1.0f, e);
+            while (extent > 0.f && lo[a] + scale[a] * 255.0f < hi[a] && e < 127) // guard float round-off
+                scale[a] = std::ldexp(1.0f, ++e);
+            ex[a] = (uint32_t)(e + 127);
+        }
+        w.ox = lo[0], w.oy = lo[1], w.oz = lo[2];
+        w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        uint32_t* q[6] = { &w.qlox, &w.qhix, &w.qloy, &w.qhiy, &w.qloz, &w.qhiz };
+        for (int k = 0; k < 4; k++) {
+            w.child[k] = kRefNone;
+            if (k >= n)
+                continue;
+            const bool empty = !(kids[k].lo[0] <= kids[k].hi[0]);
+            w.child[k] = empty ? kRefNone : kids[k].ref;
+            for (int a = 0; a < 3; a++) {
+                uint32_t ql = 255, qh = 0;
+                if (!empty) {
+                    // outward rounding, then verify with the exact expression the kernel evaluates (origin + scale*q)
+                    float fl = std::floor((kids[k].lo[a] - lo[a]) / scale[a]);
+                    float fh = std::ceil((kids[k].hi[a] - lo[a]) / scale[a]);
+                    ql = (uint32_t)std::max(0.f, std::min(255.f, fl));
+                    qh = (uint32_t)std::max(0.f, std::min(255.f, fh));
+                    while (ql > 0 && lo[a] + scale[a] * (float)ql > kids[k].lo[a])
+                        ql--;
+                    while (qh < 255 && lo[a] + scale[a] * (float)qh < kids[k].hi[a])
+                        qh++;
+                }
+                *q[a * 2] |= ql << (8 * k);
+                *q[a * 2 + 1] |= qh << (8 * k);
+            }
+        }
+        wide[i] = w;
+    }
+    return wide;
 }
 
 int resetStreams(pt_ctx* c)
@@ -573,7 +663,7 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->wide.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
@@ -850,7 +940,7 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc;
-    if ((rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    if ((rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
     c->scene.rootRef = topRef[topRoot];

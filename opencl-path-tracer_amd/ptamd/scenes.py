@@ -188,8 +188,10 @@ def cornell_box(width=512, height=512, builder=H.BVH_BINNED_SAH, box_materials=N
     mats += list(box_materials)
     mb = _MeshBuilder()
     _room(mb, mats)
-    mb.add_box((0.35, 0.3, -0.3), (0.3, 0.3, 0.3), -18.0, 4)
-    mb.add_box((-0.35, 0.6, 0.3), (0.3, 0.6, 0.3), 20.0, 5)
+    # the boxes float 2 mm above the floor: coincident faces (box bottom == floor) would make the reported
+    # hit depend on the BVH visit order -- in the reference too -- and with it the material of the path
+    mb.add_box((0.35, 0.302, -0.3), (0.3, 0.3, 0.3), -18.0, 4)
+    mb.add_box((-0.35, 0.602, 0.3), (0.3, 0.6, 0.3), 20.0, 5)
     scene = H.Scene()
     scene.add_node(mb.build(mats, builder))
     cam = _camera(width, height, (0.0, 1.0, -3.9), (0.0, 1.0, 0.0), 40.0)

@@ -38,7 +38,7 @@ def tri_vertex_ids(flat, prim):
     return np.sort(flat.triangles["indices"][prim], axis=1)
 
 
-def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=2e-3):
+def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2):
     """hit/miss identical; t/u/v within tolerance; (prim, inst) identical except where two primitives are
     hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t."""
     gh, wh = got["prim"] >= 0, want["prim"] >= 0
@@ -49,6 +49,10 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=2e-3):
     same_geom = np.all(tri_vertex_ids(flat, got["prim"][both]) == tri_vertex_ids(flat, want["prim"][both]), axis=1)
     same = same_geom & (got["inst"][both] == want["inst"][both])
     assert (~same).mean() <= max_tie_frac, f"{(~same).sum()} of {both.sum()} rays hit a different primitive"
+    # a different primitive is only legitimate as a tie: coincident / edge-sharing triangles hit at the same t
+    # (which one is reported depends on the visit order, which is ours -- see pt_trace.h)
+    tie_dt = np.abs(got["t"][both][~same] - want["t"][both][~same]) / np.maximum(want["t"][both][~same], 1e-6)
+    assert tie_dt.size == 0 or tie_dt.max() < 2e-5, f"different primitive at a different distance: {tie_dt.max():.2e}"
     # barycentrics: compared through the hit point they encode (object space), v0 + u*e1 + v*e2, because
     # u and v of a grazing hit are ill-conditioned (errors scale with 1/det) while the point is not
     tri = flat.triangles["indices"][want["prim"][both][same]]
