@@ -240,6 +240,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
                         *ap = px;
                     } else {
+                        if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of a single-leaf instance: map it back
+                            const float4 tc = sc.tris[hprim].c;
+                            hprim = (int)asU(tc.y);
+                            hinst = (int)asU(tc.z);
+                        }
                         a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
                         a.inst[rayIdx] = hinst;
                     }

@@ -73,6 +73,7 @@ struct pt_ctx {
     DevBuf<Light> lights;
     DevBuf<float4> texMaterial, texSky;
     SceneDev scene {};
+    std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
     std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
     std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
     std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
@@ -828,7 +829,8 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
 
     int rc;
-    if ((rc = uploadVec(c, c->tris, hTris)) || (rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
+    c->hostTris = hTris;
+    if ((rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
         || (rc = uploadVec(c, c->materials, hMats)))
         return rc;
     c->hostBottomNodes = std::move(hNodes);
@@ -855,6 +857,7 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
     std::vector<Instance> hInst;
     std::vector<uint32_t> topRef(nTop, kRefNone); // reference of top node i as a child
+    std::vector<TriIsect> baked; // world-space copies of single-leaf instances
     c->instanceTopNode.clear();
     uint32_t numTopInner = 0, maxBottomDepth = 0;
     const uint32_t bottomCount = (uint32_t)c->hostBottomNodes.size();
@@ -873,9 +876,70 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             in.topNode = i;
             if (hInst.size() >= kSpecialLeaveInstance)
                 return fail(c, PT_ERR_UNSUPPORTED, "too many instances");
-            topRef[i] = makeRef((uint32_t)hInst.size(), kRefSpecial);
+            const uint32_t instIndex = (uint32_t)hInst.size();
+            topRef[i] = makeRef(instIndex, kRefSpecial);
             hInst.push_back(in);
             c->instanceTopNode.push_back(i);
+            // A mesh that is a single leaf (a ground quad, an area light) is not worth an instance entry + leave
+            // per ray: its triangles are copied to world space and referenced from the top level as a plain
+            // leaf.  (t,u,v) are the same in both spaces (the reference never renormalises the transformed
+            // direction, scene.cl:118-121); k_trace maps the copy back to (original triangle, instance).
+            const uint32_t rr = in.rootRef;
+            if (refCount(rr) >= 1u && refCount(rr) <= kMaxLeafTris && !(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES)) {
+                double w[4][8];
+                for (int r = 0; r < 4; r++)
+                    for (int col = 0; col < 4; col++) {
+                        w[r][col] = m[col * 4 + r];
+                        w[r][col + 4] = (r == col) ? 1.0 : 0.0;
+                    }
+                bool singular = false;
+                for (int col = 0; col < 4 && !singular; col++) { // world = inverse(invTransform), Gauss-Jordan
+                    int piv = col;
+                    for (int r = col + 1; r < 4; r++)
+                        if (std::fabs(w[r][col]) > std::fabs(w[piv][col]))
+                            piv = r;
+                    if (std::fabs(w[piv][col]) < 1e-300) {
+                        singular = true;
+                        break;
+                    }
+                    for (int k = 0; k < 8; k++)
+                        std::swap(w[piv][k], w[col][k]);
+                    const double dv = w[col][col];
+                    for (int k = 0; k < 8; k++)
+                        w[col][k] /= dv;
+                    for (int r = 0; r < 4; r++)
+                        if (r != col) {
+                            const double f = w[r][col];
+                            for (int k = 0; k < 8; k++)
+                                w[r][k] -= f * w[col][k];
+                        }
+                }
+                if (!singular) {
+                    const uint32_t first = refIndex(rr), cnt = refCount(rr);
+                    const uint32_t bakedFirst = (uint32_t)(c->hostTris.size() + baked.size());
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const TriIsect& t = c->hostTris[first + k];
+                        const double v0[3] = { t.a.x, t.a.y, t.a.z }, e1[3] = { t.a.w, t.b.x, t.b.y }, e2[3] = { t.b.z, t.b.w, t.c.x };
+                        float V0[3], E1[3], E2[3];
+                        for (int r = 0; r < 3; r++) {
+                            V0[r] = (float)(w[r][4] * v0[0] + w[r][5] * v0[1] + w[r][6] * v0[2] + w[r][7]);
+                            E1[r] = (float)(w[r][4] * e1[0] + w[r][5] * e1[1] + w[r][6] * e1[2]);
+                            E2[r] = (float)(w[r][4] * e2[0] + w[r][5] * e2[1] + w[r][6] * e2[2]);
+                        }
+                        TriIsect b {};
+                        uint32_t orig = first + k;
+                        float fo, fi;
+                        std::memcpy(&fo, &orig, 4);
+                        std::memcpy(&fi, &instIndex, 4);
+                        b.a = make_float4(V0[0], V0[1], V0[2], E1[0]);
+                        b.b = make_float4(E1[1], E1[2], E2[0], E2[1]);
+                        b.c = make_float4(E2[2], fo, fi, 0.f);
+                        baked.push_back(b);
+                    }
+                    if ((uint64_t)bakedFirst + cnt <= kRefIndexMask)
+                        topRef[i] = makeRef(bakedFirst, cnt);
+                }
+            }
         } else {
             if (n.a >= nTop || n.b >= nTop)
                 return fail(c, PT_ERR_INVALID, "top-level node %u: child out of range", i);
@@ -940,7 +1004,9 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc;
-    if ((rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    std::vector<TriIsect> allTris = c->hostTris;
+    allTris.insert(allTris.end(), baked.begin(), baked.end());
+    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
     c->scene.rootRef = topRef[topRoot];
