@@ -145,11 +145,26 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     // ---- per-wave ray packets (see header comment) ---------------------------------------------
     float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO, poolC = poolO;
     uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
+    // Claiming queue entries: the first packet of every wave is static (wave w takes entries [64w, 64w+64)),
+    // later ones come from ONE shared cursor in spans of up to 512 entries -- a single device-scope word
+    // sustains only ~88 atomics/us (MI355X_MICROARCH.md, row `dequeue`), which at 64 rays per atomic would
+    // cap the kernel near 5.6 Grays/s and costs ~46 us per launch for the 4096 initial requests alone.
+    const uint32_t totalWaves = total >> 6, gwave = gtid >> 6;
+    const uint32_t spanSize = 64u * min(8u, max(1u, count / (totalWaves * 64u * 8u)));
+    uint32_t spanNext = gwave * 64u, spanEnd = spanNext + 64u; // wave-uniform: claimed, not yet loaded
     auto requestPacket = [&]() {
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(a.cursor, 64u);
-        base = __shfl(base, 0);
+        if (spanNext >= spanEnd) {
+            uint32_t base = 0xFFFFFFC0u; // "nothing left"
+            if (gwave * 64u < count) { // otherwise even the static packets were not all needed: no dynamic part
+                if (lane == 0)
+                    base = atomicAdd(a.cursor, spanSize);
+                base = totalWaves * 64u + __shfl(base, 0);
+            }
+            spanNext = base;
+            spanEnd = base + spanSize;
+        }
+        const uint32_t base = spanNext;
+        spanNext += 64u;
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
