@@ -461,8 +461,10 @@ struct ShadeArgs {
 
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
 // output queues, finished or not (kernel.cl:292-300), at the SAME index, in slot order.
+constexpr int kShadeBlock = 1024;
+
 template <bool PARITY>
-__global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
+__global__ void __launch_bounds__(kShadeBlock) k_shade(ShadeArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -523,18 +525,34 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a)
         }
         return;
     }
-    // wave-aggregated compaction: one atomic per wave and per queue
+    // Workgroup-aggregated compaction: ballots rank the lanes of a wave, the waves of the block exchange
+    // their counts through LDS, and ONE lane per queue issues the atomicAdd for the whole block.  (One atomic
+    // per wave was not enough: 130 k waves on one device-scope word at ~88 atomics/us is 1.5 ms -- the whole
+    // first-bounce shade launch.)
+    __shared__ uint32_t sCount[kShadeBlock / 64][3];
+    __shared__ uint32_t sBase[3];
     const unsigned long long mRay = __ballot(emitRay);
     const unsigned long long mSh = __ballot(emitShadow);
     const unsigned long long mHit = __ballot(shaded);
-    uint32_t baseRay = 0, baseSh = 0;
+    const uint32_t wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
     if (lane == 0) {
-        if (mRay) baseRay = atomicAdd(a.outCount, (uint32_t)__popcll(mRay));
-        if (mSh) baseSh = atomicAdd(a.shadowCount, (uint32_t)__popcll(mSh));
-        if (mHit) atomicAdd(a.shadeHits, (uint32_t)__popcll(mHit));
+        sCount[wave][0] = (uint32_t)__popcll(mRay);
+        sCount[wave][1] = (uint32_t)__popcll(mSh);
+        sCount[wave][2] = (uint32_t)__popcll(mHit);
     }
-    baseRay = __shfl(baseRay, 0);
-    baseSh = __shfl(baseSh, 0);
+    __syncthreads();
+    if (threadIdx.x < 3) { // thread q: exclusive prefix of queue q over the waves + the block's atomic
+        uint32_t sum = 0;
+        for (uint32_t w = 0; w < nWaves; w++) {
+            const uint32_t n = sCount[w][threadIdx.x];
+            sCount[w][threadIdx.x] = sum;
+            sum += n;
+        }
+        uint32_t* counter = threadIdx.x == 0 ? a.outCount : (threadIdx.x == 1 ? a.shadowCount : a.shadeHits);
+        sBase[threadIdx.x] = sum ? atomicAdd(counter, sum) : 0u;
+    }
+    __syncthreads();
+    const uint32_t baseRay = sBase[0] + sCount[wave][0], baseSh = sBase[1] + sCount[wave][1];
     const unsigned long long below = (1ull << lane) - 1ull;
     if (emitRay) {
         const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);

@@ -471,12 +471,12 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.shadowCount = &ctl->shadowCount[pass];
     a.shadeHits = &ctl->shadeHits[pass];
     a.streams = c->streams.p;
-    const uint32_t blocks = (std::max(launchEntries, 1u) + 255u) / 256u;
+    const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock;
     if (parityMode(c)) {
         a.out = c->stagedRays.view();
         a.shadow = c->stagedShadow.view();
         a.activeFlag = c->activeFlag.p;
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
         CompactArgs ca {};
         ca.staged = c->stagedRays.view();
         ca.out = c->rays[out].view();
@@ -491,7 +491,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     } else {
         a.out = c->rays[out].view();
         a.shadow = c->shadow.view();
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
     }
 }
 
