@@ -130,7 +130,7 @@ typedef struct {
     int32_t device; /* HIP device ordinal */
     uint32_t flags; /* PT_FLAG_* */
     uint32_t samples_in_flight; /* samples of one pixel traced concurrently, each into its own accumulator
-                                   plane (folded after the batch); 0 = auto (~8M path segments per launch).
+                                   plane (folded after the batch); 0 = auto (~32M path segments per launch), max 1024.
                                    Only with max_active_rays == 0 and PT_RNG_COUNTER. */
 } pt_config;
 

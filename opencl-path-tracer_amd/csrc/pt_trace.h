@@ -30,7 +30,7 @@
 namespace ptd {
 
 #ifndef PT_REFILL_IDLE
-#define PT_REFILL_IDLE 24
+#define PT_REFILL_IDLE 16
 #endif
 #ifndef PT_TRACE_MIN_WAVES
 #define PT_TRACE_MIN_WAVES 4
