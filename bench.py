@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,9 +113,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     W, Hh = args.width, args.height
     bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT)
@@ -137,6 +144,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def on_comm_device(t):  # gloo rehearsals reduce on the host
+        return t if args.backend == "nccl" else t.cpu()
+
     for _ in range(args.warmup):
         ctx.render(spp_step, sync=False)
     barrier()
@@ -147,14 +157,19 @@ def main():
     for _ in range(args.steps):
         ctx.render(spp_step, sync=False)
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # the one exchange step: HDR accumulator over xGMI
+        if args.backend == "nccl":
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # the one exchange step: HDR accumulator over xGMI
+        else:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
     barrier()
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
-    counts = torch.tensor([st["rays_extension"], st["rays_shadow"], st["rays_generated"], st["shade_hits"]],
-                          dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    counts = on_comm_device(torch.tensor([st["rays_extension"], st["rays_shadow"], st["rays_generated"], st["shade_hits"]],
+                                         dtype=torch.float64, device="cuda"))
+    tmax = on_comm_device(torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -175,9 +190,18 @@ def main():
         rays_per_launch = ps["rays_extension"] / launches
         avg_ms = ps["ms_intersect"] / launches
         achieved = BYTES_PER_EXT_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC profile of this exact configuration
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic_k_trace_closest.json")))
+            cfgt = tj["config"]
+            if (cfgt["width"], cfgt["height"], cfgt["level"], cfgt["samples_in_flight"], cfgt["n_gpus"]) == (W, Hh, args.level, in_flight, world):
+                traffic = round(tj["bytes_per_ray"]["total"] * rays_per_launch)
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": "k_trace<false> (closest-hit two-level BVH traversal)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_note": "bytes per launch = 108.3 B/ray (FETCH_SIZE/WRITE_SIZE PMC passes, profiles/round1/traffic_k_trace_closest.json) x rays per launch" if traffic else None,
                     "algorithmic_bytes_per_ray": BYTES_PER_EXT_RAY, "rays_per_launch": int(rays_per_launch),
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "mrays_per_s_in_kernel": round(rays_per_launch / avg_ms / 1e3, 1),
