@@ -29,11 +29,13 @@
 
 namespace ptd {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 #ifndef PT_REFILL_IDLE
 #define PT_REFILL_IDLE 16
 #endif
 #ifndef PT_TRACE_MIN_WAVES
-#define PT_TRACE_MIN_WAVES 4
+#define PT_TRACE_MIN_WAVES 6
 #endif
 #ifndef PT_VOTE_W_INNER
 #define PT_VOTE_W_INNER 4
@@ -48,10 +50,13 @@ namespace ptd {
 #define PT_PARKED_BREAK 16
 #endif
 #ifndef PT_WIDE
-#define PT_WIDE 1
+#define PT_WIDE 2
+#endif
+#ifndef PT_WORLD_LDS
+#define PT_WORLD_LDS 1 // world-space ray parked in LDS while an instance is traversed (0: re-read from the queue)
 #endif
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 26
+#define PT_LDS_STACK 16
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 constexpr int kSpillStack = 100; // further entries in global memory
@@ -96,7 +101,9 @@ template <bool ANY_HIT>
 __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
+#if PT_WORLD_LDS
     __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -132,8 +139,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     int hprim = -1, hinst = -1, curInst = -1;
     uint32_t cur = kRefFinish;
     int sp = 0;
-    float4 contrib = make_float4(0, 0, 0, 0);
-    uint32_t pixel = 0;
 
     auto setRay = [&](V3 o, V3 d) {
         co = o;
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     };
 
     // ---- per-wave ray packets (see header comment) ---------------------------------------------
-    float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO, poolC = poolO;
+    float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO;
     uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
     // Claiming queue entries: the first packet of every wave is static (wave w takes entries [64w, 64w+64)),
     // later ones come from ONE shared cursor in spans of up to 512 entries -- a single device-scope word
@@ -171,8 +176,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         if (lane < poolEnd) {
             poolO = a.rayO[base + lane];
             poolD = a.rayD[base + lane];
-            if (ANY_HIT)
-                poolC = a.rayC[base + lane];
         }
     };
     requestPacket();
@@ -189,20 +192,17 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 } else {
                     const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const int e = (int)min(poolNext + rank, 63u);
-                    float4 ro, rd, rc = make_float4(0, 0, 0, 0);
+                    float4 ro, rd;
                     ro.x = __shfl(poolO.x, e), ro.y = __shfl(poolO.y, e), ro.z = __shfl(poolO.z, e), ro.w = __shfl(poolO.w, e);
                     rd.x = __shfl(poolD.x, e), rd.y = __shfl(poolD.y, e), rd.z = __shfl(poolD.z, e), rd.w = __shfl(poolD.w, e);
-                    if (ANY_HIT)
-                        rc.x = __shfl(poolC.x, e), rc.y = __shfl(poolC.y, e), rc.z = __shfl(poolC.z, e), rc.w = __shfl(poolC.w, e);
                     if (!active && rank < avail) {
                         const uint32_t idx = poolBase + (uint32_t)e;
                         bool live = true;
                         float tMax = INFINITY;
                         if (ANY_HIT) {
-                            contrib = rc;
-                            pixel = asU(rd.w);
+                            // contribution and pixel stay in the queue until the ray turns out unoccluded
                             tMax = ro.w;
-                            if (a.parityShadow && (asU(contrib.w) & FLAG_FINISHED))
+                            if (a.parityShadow && (asU(a.rayC[idx].w) & FLAG_FINISHED))
                                 live = false;
                         } else if (asU(rd.w) & FLAG_FINISHED) { // parity mode keeps finished rays in the queue
                             live = false;
@@ -211,8 +211,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         }
                         if (live) {
                             rayIdx = idx;
+#if PT_WORLD_LDS
                             ldsWorld[wave][0][lane] = ro.x, ldsWorld[wave][1][lane] = ro.y, ldsWorld[wave][2][lane] = ro.z;
                             ldsWorld[wave][3][lane] = rd.x, ldsWorld[wave][4][lane] = rd.y, ldsWorld[wave][5][lane] = rd.z;
+#endif
                             setRay(xyz(ro), xyz(rd));
                             tClosest = tMax;
                             hprim = -1;
@@ -250,6 +252,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     if (ANY_HIT) {
                         if (a.occluded)
                             a.occluded[rayIdx] = 0u;
+                        const float4 contrib = a.rayC[rayIdx];
+                        const uint32_t pixel = asU(a.rayD[rayIdx].w);
                         float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
                         float4 px = *ap;
                         px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
@@ -265,14 +269,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     }
                     active = false;
                 } else {
-                    const V3 o = mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]);
-                    const V3 d = mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]);
                     if (what == kSpecialLeaveInstance) {
-                        // -------- back to world space ------------------------------------------------------
-                        setRay(o, d);
+                        // -------- back to world space ---------------------------------------------------------
+#if PT_WORLD_LDS
+                        setRay(mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]),
+                            mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]));
+#else
+                        setRay(xyz(a.rayO[rayIdx]), xyz(a.rayD[rayIdx])); // the ray is still in the queue, bit for bit
+#endif
                         curInst = -1;
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     } else {
+                        const V3 o = co, d = cd; // instances are only ever entered from world space
                         // -------- enter instance `what` (scene.cl:116-139) ---------------------------------
                         const Instance in = sc.instances[what];
                         V3 to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w, in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
@@ -319,7 +327,79 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 if (wantInner) {
-#if PT_WIDE
+#if PT_WIDE == 2
+                    // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
+                    const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
+                    const uint4 A = wp[0], B = wp[1];
+                    const uint2 C = *(const uint2*)&wp[2];
+                    const uint4 D = wp[3];
+                    // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
+                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
+                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    const float bx = fmaf(asF(A.x), cid.x, coid.x), by = fmaf(asF(A.y), cid.y, coid.y), bz = fmaf(asF(A.z), cid.z, coid.z);
+                    // entry / exit planes chosen by the sign of the ray direction (whole dwords: 4 children at once)
+                    // instead of min/max per plane pair; an empty slot is an inverted box (q 255..0) and can never
+                    // satisfy exit >= entry -- and if round-off ever made it, its reference is a degenerate triangle
+                    const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                    const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
+                    const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
+                    const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
+                    const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
+                    float key[4];
+                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
+                        const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
+                        const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
+                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
+                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                        const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
+                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box
+                        const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest;
+                        key[k] = vis ? tmin : INFINITY;
+                    }
+                    // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
+#define PT_CSWAP(i, j)                                   \
+    {                                                    \
+        const bool sw = key[j] < key[i];                 \
+        const float tk = sw ? key[j] : key[i];           \
+        key[j] = sw ? key[i] : key[j];                   \
+        key[i] = tk;                                     \
+        const uint32_t tr = sw ? ref[j] : ref[i];        \
+        ref[j] = sw ? ref[i] : ref[j];                   \
+        ref[i] = tr;                                     \
+    }
+                    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+                    // farthest first onto the stack, continue with the nearest
+                    if (sp + 3 <= kLdsStack) { // common case: no spill checks
+                        if (key[3] < INFINITY)
+                            ldsStack[wave][sp++][lane] = ref[3];
+                        if (key[2] < INFINITY)
+                            ldsStack[wave][sp++][lane] = ref[2];
+                        if (key[1] < INFINITY)
+                            ldsStack[wave][sp++][lane] = ref[1];
+                    } else {
+                        if (key[3] < INFINITY) {
+                            push(sp, ref[3]);
+                            sp++;
+                        }
+                        if (key[2] < INFINITY) {
+                            push(sp, ref[2]);
+                            sp++;
+                        }
+                        if (key[1] < INFINITY) {
+                            push(sp, ref[1]);
+                            sp++;
+                        }
+                    }
+                    if (key[0] < INFINITY)
+                        cur = ref[0];
+                    else
+                        cur = sp > 0 ? pop(--sp) : kRefFinish;
+#elif PT_WIDE
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
                     const uint4 A = wp[0], B = wp[1], C = wp[2], D = wp[3];

@@ -191,7 +191,9 @@ void lfsrJump(uint32_t g[4])
 
 // Collapse the pair-node tree into 4-wide nodes with 8-bit quantised child boxes (pt_device.h, WideNode).
 // wide[i] describes the same subtree as pair[i], so child references keep their indices.
-std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair)
+// `emptyRef`: what an unused child slot refers to (its box is inverted, so it is never entered unless
+// round-off makes the inverted box look non-empty; the reference must therefore be harmless to visit)
+std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t emptyRef)
 {
     std::vector<WideNode> wide(pair.size());
     struct Child {
@@ -250,11 +252,8 @@ std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair)
         w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
         uint32_t* q[6] = { &w.qlox, &w.qhix, &w.qloy, &w.qhiy, &w.qloz, &w.qhiz };
         for (int k = 0; k < 4; k++) {
-            w.child[k] = kRefNone;
-            if (k >= n)
-                continue;
-            const bool empty = !(kids[k].lo[0] <= kids[k].hi[0]);
-            w.child[k] = empty ? kRefNone : kids[k].ref;
+            const bool empty = k >= n || !(kids[k].lo[0] <= kids[k].hi[0]) || kids[k].ref == kRefNone;
+            w.child[k] = empty ? emptyRef : kids[k].ref;
             for (int a = 0; a < 3; a++) {
                 uint32_t ql = 255, qh = 0;
                 if (!empty) {
@@ -1006,7 +1005,12 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     int rc;
     std::vector<TriIsect> allTris = c->hostTris;
     allTris.insert(allTris.end(), baked.begin(), baked.end());
-    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    // one all-zero triangle (det == 0: never hit) for the unused child slots of the 4-wide nodes to refer to
+    if (allTris.size() >= kRefIndexMask - 2u)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_upload_dynamic: too many triangle references");
+    const uint32_t emptyRef = makeRef((uint32_t)allTris.size(), 1u);
+    allTris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) });
+    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes, emptyRef))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
     c->scene.rootRef = topRef[topRoot];
