@@ -66,6 +66,7 @@ def cpu_baseline(bundle, seconds, width, height):
     order = np.random.default_rng(0).permutation(bx * by)
     yy, xx = np.mgrid[0:8, 0:8]
     rays, pixels_done, t_used, chunk, pos, sample = 0, 0, 0.0, 256, 0, 0
+    work = {"innerSteps": 0, "triangleTests": 0, "topVisits": 0}  # reference-layout traversal work (SURVEY 8d, L2-level model)
     while t_used < seconds:
         if pos >= len(order):  # the whole frame is done: next sample index
             pos, sample = 0, sample + 1
@@ -77,9 +78,12 @@ def cpu_baseline(bundle, seconds, width, height):
                           threads=cores, fast=True)
         t_used += time.perf_counter() - t0
         rays += cnt["raysExtension"] + cnt["raysShadow"]
+        for k in work:
+            work[k] += cnt[k]
         pixels_done += len(px)
         chunk = min(chunk * 2, 8192)
     return {"value": round(rays / t_used / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "per_ray": {k: round(work[k] / max(rays, 1), 2) for k in ("innerSteps", "triangleTests", "topVisits")},
             "sample": f"{pixels_done} pixel-samples (random 8x8 blocks of the {width}x{height} frame, 1 spp each pass), "
                       f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
 
@@ -198,9 +202,26 @@ def main():
                 traffic = round(tj["bytes_per_ray"]["total"] * rays_per_launch)
         except (OSError, KeyError, ValueError):
             pass
+        # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(src)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        # SURVEY 8(d) formula over the whole step (deposits are not counted on device and left out)
+        path_bytes = 48.0 * ps["rays_generated"] + 48.0 * ps["rays_extension"] + 160.0 * ps["shade_hits"] + 44.0 * ps["rays_shadow"]
+        path_ms = ps["ms_gen"] + ps["ms_intersect"] + ps["ms_shade"] + ps["ms_shadow"]
         roofline = {"bound": "hbm", "kernel": "k_trace<false> (closest-hit two-level BVH traversal)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
+                    "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
                     "traffic_note": "bytes per launch = 108.3 B/ray (FETCH_SIZE/WRITE_SIZE PMC passes, profiles/round1/traffic_k_trace_closest.json) x rays per launch" if traffic else None,
                     "algorithmic_bytes_per_ray": BYTES_PER_EXT_RAY, "rays_per_launch": int(rays_per_launch),
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,

@@ -49,11 +49,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_PARKED_BREAK
 #define PT_PARKED_BREAK 16
 #endif
-#ifndef PT_WIDE
-#define PT_WIDE 2
-#endif
 #ifndef PT_WORLD_LDS
 #define PT_WORLD_LDS 1 // world-space ray parked in LDS while an instance is traversed (0: re-read from the queue)
+#endif
+#ifndef PT_ANYHIT_SORT
+#define PT_ANYHIT_SORT 0
+#endif
+#ifndef PT_LEAF_PIPE
+#define PT_LEAF_PIPE 0
 #endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 16
@@ -85,10 +88,14 @@ struct TraceArgs {
 #ifdef PT_TRACE_STATS
 // diagnostic build only (tools/variants.sh ... -DPT_TRACE_STATS): where do the lanes of a wave go?
 // [0] iterations, [1] sum of active lanes, [2..4] iterations per kind, [5..7] lanes served per kind, [8] hand-outs, [9] rays
-__device__ unsigned long long g_traceStats[16];
+__device__ unsigned long long g_traceStats[24];
 #define PT_STAT(i, v) statAcc[i] += (unsigned long long)(v)
+#define PT_TIC(t) const unsigned long long t = __builtin_readcyclecounter()
+#define PT_TOC(i, t) statAcc[i] += __builtin_readcyclecounter() - t
 #else
 #define PT_STAT(i, v)
+#define PT_TIC(t)
+#define PT_TOC(i, t)
 #endif
 
 __device__ inline float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); } // v_rcp_f32, 1 ulp
@@ -128,7 +135,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     };
 
 #ifdef PT_TRACE_STATS
-    unsigned long long statAcc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long statAcc[24] = {};
+    PT_TIC(tKernel);
 #endif
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
@@ -139,6 +147,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     int hprim = -1, hinst = -1, curInst = -1;
     uint32_t cur = kRefFinish;
     int sp = 0;
+    // value of pop() given the prefetched LDS entry `top` (does not move sp)
+    auto popTop = [&](uint32_t top) -> uint32_t {
+        uint32_t v = sp > 0 ? top : kRefFinish;
+        if (sp > kLdsStack)
+            v = ((const volatile uint32_t*)spill)[(size_t)(sp - 1 - kLdsStack) * total];
+        return v;
+    };
+
 
     auto setRay = [&](V3 o, V3 d) {
         co = o;
@@ -182,6 +198,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 
     while (true) {
         // ---- hand rays to idle lanes ----------------------------------------------------------
+        PT_TIC(tHand);
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nIdle = __popcll(idle);
@@ -190,11 +207,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 if (avail == 0u) {
                     exhausted = true; // the request issued after the last hand-out came back empty
                 } else {
+                    PT_TIC(tShfl);
                     const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const int e = (int)min(poolNext + rank, 63u);
                     float4 ro, rd;
                     ro.x = __shfl(poolO.x, e), ro.y = __shfl(poolO.y, e), ro.z = __shfl(poolO.z, e), ro.w = __shfl(poolO.w, e);
                     rd.x = __shfl(poolD.x, e), rd.y = __shfl(poolD.y, e), rd.z = __shfl(poolD.z, e), rd.w = __shfl(poolD.w, e);
+                    PT_TOC(16, tShfl);
+                    PT_TIC(tAssign);
                     if (!active && rank < avail) {
                         const uint32_t idx = poolBase + (uint32_t)e;
                         bool live = true;
@@ -226,14 +246,20 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             active = true;
                         }
                     }
+                    PT_TOC(17, tAssign);
                     PT_STAT(8, 1);
                     PT_STAT(9, min((uint32_t)nIdle, avail));
                     poolNext += min((uint32_t)nIdle, avail);
-                    if (poolNext == poolEnd)
+                    if (poolNext == poolEnd) {
+                        PT_TIC(tReq);
                         requestPacket();
+                        PT_TOC(15, tReq);
+                    }
                 }
             }
         }
+        PT_TOC(14, tHand);
+        PT_TIC(tSpec);
         // ---- resolve special references (instance entry / leave, end of traversal) -------------------
         // They are kept OUT of the hot loop below: lanes that reach one park until the loop breaks, then all
         // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
@@ -303,6 +329,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 }
             }
         }
+        PT_TOC(13, tSpec);
         if (__ballot(active) == 0ull) {
             if (exhausted)
                 break;
@@ -311,6 +338,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 
         // ---- hot loop: inner steps and leaves, until enough lanes are parked (special) or idle -------
         while (true) {
+            // the entry a pop would return, fetched before the node / triangle loads so that its LDS latency
+            // hides under theirs (whichever step runs this iteration pops at most once, and only when it has
+            // pushed nothing)
+            const uint32_t stackTop = ldsStack[wave][min(max(sp - 1, 0), kLdsStack - 1)][lane];
             const uint32_t kindBits = refCount(cur);
             const bool wantInner = active && kindBits == 0u;
             const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
@@ -326,13 +357,24 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             if (nInner * PT_VOTE_W_INNER >= nLeaf * PT_VOTE_W_LEAF) {
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
+                PT_TIC(tInner);
                 if (wantInner) {
-#if PT_WIDE == 2
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
                     const uint4 A = wp[0], B = wp[1];
                     const uint2 C = *(const uint2*)&wp[2];
                     const uint4 D = wp[3];
+#ifdef PT_EXTRA_LOADS // diagnostic: how sensitive is the kernel to vector-memory instruction count?
+                    uint32_t extra = 0;
+                    for (int q = 0; q < PT_EXTRA_LOADS; q++) {
+                        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                        const u4 E = __builtin_nontemporal_load((const u4*)wp + (q & 3)); // distinct instruction, not CSE'd with A..D
+                        asm volatile("" : "+v"(extra));
+                        extra ^= E.x;
+                    }
+                    if (extra == 0x12345u) // never true for real nodes; keeps the loads alive
+                        tClosest = 0.f;
+#endif
                     // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
                     const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
                                 az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
@@ -371,16 +413,25 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         ref[j] = sw ? ref[i] : ref[j];                   \
         ref[i] = tr;                                     \
     }
-                    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#if PT_ANYHIT_SORT == 0
+                    if (ANY_HIT) { // any occluder will do: only move a visible child to the front
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2)
+                    } else
+#endif
+                    {
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+                    }
 #undef PT_CSWAP
                     // farthest first onto the stack, continue with the nearest
-                    if (sp + 3 <= kLdsStack) { // common case: no spill checks
-                        if (key[3] < INFINITY)
-                            ldsStack[wave][sp++][lane] = ref[3];
-                        if (key[2] < INFINITY)
-                            ldsStack[wave][sp++][lane] = ref[2];
-                        if (key[1] < INFINITY)
-                            ldsStack[wave][sp++][lane] = ref[1];
+                    if (sp + 3 <= kLdsStack) {
+                        // common case, branch-free: every candidate is stored, the stack pointer only moves past the
+                        // ones that are kept (a rejected one is overwritten by the next store)
+                        ldsStack[wave][sp][lane] = ref[3];
+                        sp += key[3] < INFINITY ? 1 : 0;
+                        ldsStack[wave][sp][lane] = ref[2];
+                        sp += key[2] < INFINITY ? 1 : 0;
+                        ldsStack[wave][sp][lane] = ref[1];
+                        sp += key[1] < INFINITY ? 1 : 0;
                     } else {
                         if (key[3] < INFINITY) {
                             push(sp, ref[3]);
@@ -395,104 +446,41 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             sp++;
                         }
                     }
+                    // no visible child => nothing was pushed => the prefetched stack top is still the top
+                    const uint32_t next = popTop(stackTop);
                     if (key[0] < INFINITY)
                         cur = ref[0];
                     else
-                        cur = sp > 0 ? pop(--sp) : kRefFinish;
-#elif PT_WIDE
-                    // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
-                    const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
-                    const uint4 A = wp[0], B = wp[1], C = wp[2], D = wp[3];
-                    // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
-                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
-                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
-                    const float bx = fmaf(asF(A.x), cid.x, coid.x), by = fmaf(asF(A.y), cid.y, coid.y), bz = fmaf(asF(A.z), cid.z, coid.z);
-                    float key[4];
-                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float x0 = fmaf((float)((B.x >> (8 * k)) & 0xFFu), ax, bx), x1 = fmaf((float)((B.y >> (8 * k)) & 0xFFu), ax, bx);
-                        const float y0 = fmaf((float)((B.z >> (8 * k)) & 0xFFu), ay, by), y1 = fmaf((float)((B.w >> (8 * k)) & 0xFFu), ay, by);
-                        const float z0 = fmaf((float)((C.x >> (8 * k)) & 0xFFu), az, bz), z1 = fmaf((float)((C.y >> (8 * k)) & 0xFFu), az, bz);
-                        const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                        const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box
-                        const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest && ref[k] != kRefNone;
-                        key[k] = vis ? tmin : INFINITY;
-                    }
-                    // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
-#define PT_CSWAP(i, j)                                   \
-    {                                                    \
-        const bool sw = key[j] < key[i];                 \
-        const float tk = sw ? key[j] : key[i];           \
-        key[j] = sw ? key[i] : key[j];                   \
-        key[i] = tk;                                     \
-        const uint32_t tr = sw ? ref[j] : ref[i];        \
-        ref[j] = sw ? ref[i] : ref[j];                   \
-        ref[i] = tr;                                     \
-    }
-                    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
-#undef PT_CSWAP
-                    // farthest first onto the stack, continue with the nearest
-                    if (key[3] < INFINITY) {
-                        push(sp, ref[3]);
-                        sp++;
-                    }
-                    if (key[2] < INFINITY) {
-                        push(sp, ref[2]);
-                        sp++;
-                    }
-                    if (key[1] < INFINITY) {
-                        push(sp, ref[1]);
-                        sp++;
-                    }
-                    if (key[0] < INFINITY)
-                        cur = ref[0];
-                    else
-                        cur = sp > 0 ? pop(--sp) : kRefFinish;
-#else
-                    // -------- inner step at either level (scene.cl:197-231): one 64-byte fetch, both child boxes
-                    const PairNode* np = &sc.nodes[refIndex(cur)];
-                    const float4 bx = np->bx, by = np->by, bz = np->bz;
-                    const uint32_t lref = np->left, rref = np->right;
-                    const float lx0 = fmaf(bx.x, cid.x, coid.x), lx1 = fmaf(bx.y, cid.x, coid.x);
-                    const float rx0 = fmaf(bx.z, cid.x, coid.x), rx1 = fmaf(bx.w, cid.x, coid.x);
-                    const float ly0 = fmaf(by.x, cid.y, coid.y), ly1 = fmaf(by.y, cid.y, coid.y);
-                    const float ry0 = fmaf(by.z, cid.y, coid.y), ry1 = fmaf(by.w, cid.y, coid.y);
-                    const float lz0 = fmaf(bz.x, cid.z, coid.z), lz1 = fmaf(bz.y, cid.z, coid.z);
-                    const float rz0 = fmaf(bz.z, cid.z, coid.z), rz1 = fmaf(bz.w, cid.z, coid.z);
-                    const float ltmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-                    const float ltmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
-                    const float rtmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-                    const float rtmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
-                    // accept test of bvh.cl:72,114
-                    const bool lvis = ltmax >= ltmin && ltmax >= 0.f && ltmin < tClosest;
-                    const bool rvis = rtmax >= rtmin && rtmax >= 0.f && rtmin < tClosest;
-                    if (lvis && rvis) {
-                        const bool leftFirst = ltmin < rtmin;
-                        push(sp, leftFirst ? rref : lref);
-                        sp++;
-                        cur = leftFirst ? lref : rref;
-                    } else if (lvis) {
-                        cur = lref;
-                    } else if (rvis) {
-                        cur = rref;
-                    } else {
-                        cur = sp > 0 ? pop(--sp) : kRefFinish;
-                    }
-#endif
+                        cur = next, sp = max(sp - 1, 0);
                 }
+                PT_TOC(11, tInner);
             } else {
                 PT_STAT(3, 1);
                 PT_STAT(6, nLeaf);
+                PT_TIC(tLeaf);
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
                     bool done = false;
+#if PT_LEAF_PIPE
+                    // software-pipelined: triangle k+1 is in flight while triangle k is tested
+                    const TriIsect* tp0 = &sc.tris[first];
+                    float4 ta = tp0->a, tb = tp0->b;
+                    float tcx = tp0->c.x;
+#endif
                     for (uint32_t k = 0; k < n; k++) {
+#if PT_LEAF_PIPE
+                        float4 na = ta, nb = tb;
+                        float ncx = tcx;
+                        if (k + 1 < n) {
+                            const TriIsect* tn = &sc.tris[first + k + 1];
+                            na = tn->a, nb = tn->b, ncx = tn->c.x;
+                        }
+#else
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
+#endif
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
                         const V3 P = cross(cd, e2);
                         const float det = dot(e1, P);
@@ -515,6 +503,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             hprim = (int)(first + k);
                             hinst = curInst;
                         }
+#if PT_LEAF_PIPE
+                        ta = na, tb = nb, tcx = ncx;
+#endif
                     }
                     if (ANY_HIT && done) { // occluded: nothing to deposit
                         if (a.occluded)
@@ -522,15 +513,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         active = false;
                         cur = kRefFinish;
                     } else {
-                        cur = sp > 0 ? pop(--sp) : kRefFinish;
+                        cur = popTop(stackTop);
+                        sp = max(sp - 1, 0);
                     }
                 }
+                PT_TOC(12, tLeaf);
             }
         }
     }
+    PT_TOC(10, tKernel);
 #ifdef PT_TRACE_STATS
     if (lane == 0)
-        for (int i = 0; i < 10; i++)
+        for (int i = 0; i < 24; i++)
             atomicAdd(&g_traceStats[i], statAcc[i]);
 #endif
 }

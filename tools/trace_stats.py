@@ -7,7 +7,7 @@ import numpy as np
 from ptamd import scenes, device as D
 
 def read():
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 24)()
     assert D.lib().pt_debug_trace_stats(out) == 0
     return list(out)
 
@@ -15,12 +15,18 @@ def report(tag, s, nrays):
     it, act, ki, kl, ks, li, ll, ls, ho, hr = s[:10]
     print(f"{tag:12s} rays {nrays:8d} wave-iters/ray*64 {it*64/max(nrays,1):6.1f}  active/iter {act/max(it,1):5.1f}  iters inner/leaf/special {ki/it:.2f}/{kl/it:.2f}/{ks/it:.2f} "
           f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
+    tot, tin, tle, tsp, tha = s[10], s[11], s[12], s[13], s[14]
+    if tot:
+        print(f"             wave cycles: inner {100*tin/tot:4.1f}% ({tin/max(ki,1):6.0f}/step)  leaf {100*tle/tot:4.1f}% ({tle/max(kl,1):6.0f}/step)  special {100*tsp/tot:4.1f}% ({tsp/max(ks,1):6.0f}/pass)"
+              f"  hand-out {100*tha/tot:4.1f}% ({tha/max(ho,1):6.0f}/hand-out)  (request {100*s[15]/tot:4.1f}% shuffles {100*s[16]/tot:4.1f}% assign {100*s[17]/tot:4.1f}%)  vote+rest {100*(tot-tin-tle-tsp-tha)/tot:4.1f}% ({(tot-tin-tle-tsp-tha)/it:6.0f}/iter)  total/iter {tot/it:6.0f}")
 
 W, Hh = 1920, 1080
 b = scenes.instanced_grid(W, Hh, level=6)
 ctx = D.Context(W, Hh, seed=1)
 ctx.upload_scene(b.flat, sky=b.sky); ctx.set_camera(b.camera)
 o, d, _ = ctx.gen_rays(0, W * Hh)
+REP = 8  # launch size comparable to one bench launch
+o, d = np.tile(o, (REP, 1)), np.tile(d, (REP, 1))
 read()
 r = ctx.intersect(o, d)
 report("primary", read(), len(o))
