@@ -461,10 +461,16 @@ struct ShadeArgs {
 
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
 // output queues, finished or not (kernel.cl:292-300), at the SAME index, in slot order.
-constexpr int kShadeBlock = 1024;
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+#ifndef PT_SHADE_MIN_WAVES
+#define PT_SHADE_MIN_WAVES 4
+#endif
+constexpr int kShadeBlock = PT_SHADE_BLOCK;
 
 template <bool PARITY>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(ShadeArgs a)
+__global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -526,9 +532,11 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(ShadeArgs a)
         return;
     }
     // Workgroup-aggregated compaction: ballots rank the lanes of a wave, the waves of the block exchange
-    // their counts through LDS, and ONE lane per queue issues the atomicAdd for the whole block.  (One atomic
-    // per wave was not enough: 130 k waves on one device-scope word at ~88 atomics/us is 1.5 ms -- the whole
-    // first-bounce shade launch.)
+    // their counts through LDS, and ONE lane per queue issues the atomicAdd for the whole block.  One atomic
+    // per wave was not enough: a single device-scope word sustains ~90-100 atomics/us, so the 1 M waves of a
+    // first-bounce launch would spend > 10 ms on it.  The block size trades that atomic rate (one per
+    // kShadeBlock entries) against waves idling at the two barriers: measured 1024 / 512 / 256 / 128 / 64
+    // threads -> 7.0 / 5.4 / 5.0 / 7.5 / 13.8 ms of k_shade per 32-sample batch.
     __shared__ uint32_t sCount[kShadeBlock / 64][3];
     __shared__ uint32_t sBase[3];
     const unsigned long long mRay = __ballot(emitRay);
