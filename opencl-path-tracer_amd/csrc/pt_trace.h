@@ -58,6 +58,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_LEAF_PIPE
 #define PT_LEAF_PIPE 0
 #endif
+#ifndef PT_POOL_DIRECT
+#define PT_POOL_DIRECT 1
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 16
 #endif
@@ -88,7 +91,7 @@ struct TraceArgs {
 #ifdef PT_TRACE_STATS
 // diagnostic build only (tools/variants.sh ... -DPT_TRACE_STATS): where do the lanes of a wave go?
 // [0] iterations, [1] sum of active lanes, [2..4] iterations per kind, [5..7] lanes served per kind, [8] hand-outs, [9] rays
-__device__ unsigned long long g_traceStats[24];
+__device__ unsigned long long g_traceStats[48]; // [0..23] closest-hit launches, [24..47] any-hit launches
 #define PT_STAT(i, v) statAcc[i] += (unsigned long long)(v)
 #define PT_TIC(t) const unsigned long long t = __builtin_readcyclecounter()
 #define PT_TOC(i, t) statAcc[i] += __builtin_readcyclecounter() - t
@@ -164,7 +167,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     };
 
     // ---- per-wave ray packets (see header comment) ---------------------------------------------
+#if !PT_POOL_DIRECT
     float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO;
+#endif
     uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
     // Claiming queue entries: the first packet of every wave is static (wave w takes entries [64w, 64w+64)),
     // later ones come from ONE shared cursor in spans of up to 512 entries -- a single device-scope word
@@ -189,10 +194,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
+#if !PT_POOL_DIRECT
         if (lane < poolEnd) {
             poolO = a.rayO[base + lane];
             poolD = a.rayD[base + lane];
         }
+#endif
     };
     requestPacket();
 
@@ -211,8 +218,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const int e = (int)min(poolNext + rank, 63u);
                     float4 ro, rd;
+#if PT_POOL_DIRECT
+                    // the packet is only claimed; the lanes that take a ray read it straight from the queue
+                    // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
+                    ro = rd = make_float4(0, 0, 0, 0);
+                    if (!active && rank < avail) {
+                        ro = a.rayO[poolBase + (uint32_t)e];
+                        rd = a.rayD[poolBase + (uint32_t)e];
+                    }
+#else
                     ro.x = __shfl(poolO.x, e), ro.y = __shfl(poolO.y, e), ro.z = __shfl(poolO.z, e), ro.w = __shfl(poolO.w, e);
                     rd.x = __shfl(poolD.x, e), rd.y = __shfl(poolD.y, e), rd.z = __shfl(poolD.z, e), rd.w = __shfl(poolD.w, e);
+#endif
                     PT_TOC(16, tShfl);
                     PT_TIC(tAssign);
                     if (!active && rank < avail) {
@@ -525,7 +542,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 #ifdef PT_TRACE_STATS
     if (lane == 0)
         for (int i = 0; i < 24; i++)
-            atomicAdd(&g_traceStats[i], statAcc[i]);
+            atomicAdd(&g_traceStats[i + (ANY_HIT ? 24 : 0)], statAcc[i]);
 #endif
 }
 

@@ -587,11 +587,11 @@ const char* pt_version(void) { return "ptamd 0.1 (gfx950)"; }
 
 #ifdef PT_TRACE_STATS
 // diagnostic builds only: read and clear the traversal-loop counters
-int pt_debug_trace_stats(unsigned long long* out24)
+int pt_debug_trace_stats(unsigned long long* out48)
 {
-    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_traceStats), sizeof(unsigned long long) * 24) != hipSuccess)
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_traceStats), sizeof(unsigned long long) * 48) != hipSuccess)
         return -1;
-    unsigned long long zero[24] = {};
+    unsigned long long zero[48] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_traceStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif

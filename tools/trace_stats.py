@@ -7,7 +7,7 @@ import numpy as np
 from ptamd import scenes, device as D
 
 def read():
-    out = (C.c_ulonglong * 24)()
+    out = (C.c_ulonglong * 48)()
     assert D.lib().pt_debug_trace_stats(out) == 0
     return list(out)
 
@@ -38,4 +38,14 @@ ctx.intersect(p, nd)
 report("secondary", read(), len(p))
 tm = np.full(len(p), 3.0, np.float32)
 ctx.intersect(p, nd, tmax=tm, any_hit=True)
-report("shadow-like", read(), len(p))
+report("shadow-like", read()[24:], len(p))
+
+# the real pipeline: one 32-sample batch, per bounce depth limit (difference between rows = that bounce)
+for mb in (1, 2, 4):
+    c2 = D.Context(W, Hh, seed=1, samples_in_flight=32, max_bounces=mb)
+    c2.upload_scene(b.flat, sky=b.sky); c2.set_camera(b.camera)
+    c2.render(32); read(); c2.reset_stats()
+    c2.render(32); st = c2.stats(); s = read()
+    report(f"render b<{mb} ext", s[:24], st["rays_extension"])
+    report(f"render b<{mb} shd", s[24:], st["rays_shadow"])
+    c2.close()
