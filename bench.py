@@ -2,10 +2,12 @@
 """Headline benchmark: Mrays/s of the ray-queue render path on the ~1M-triangle two-level-BVH scene at
 1080p (BASELINE.json metric), one process per GPU.
 
-A *step* is one pass of the hot path over one batch: `32*N*R` samples per pixel for the pixels this rank
-owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~66 M path
-segments in the first launches on every rank (every launch ends in a latency-bound tail of ~0.15 ms, so
-large batches matter: 4 samples in flight give 2.9 Grays/s, 32 give 3.8).  Image tiles (32x32, interleaved) shard across ranks, every rank
+A *step* is one pass of the hot path over one batch: `128*N*R` samples per pixel for the pixels this rank
+owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~265 M path
+segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
+large batches matter (16 / 32 / 64 / 128 samples in flight: 4.36 / 4.67 / 4.90 / 5.04 Grays/s); 128 in flight
+keep ~48 GB of queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles
+(32x32, interleaved) shard across ranks, every rank
 traces the same number of paths per step whatever N is (weak scaling: the image simply receives N x
 more samples per step), and there is no data-path collective: the only exchange is ONE RCCL reduce of
 the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the timed
@@ -94,7 +96,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=1, help="batches per step")
-    ap.add_argument("--in-flight", type=int, default=32, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
+    ap.add_argument("--in-flight", type=int, default=128, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")

@@ -649,12 +649,14 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accu
     out[i] = make_float4(c[0], c[1], c[2], 1.0f);
 }
 
-// fold the extra accumulator planes of a batch into the accumulator and clear them
-__global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes)
+// fold the extra accumulator planes of a batch into the accumulator and clear them; only the pixels this
+// context owns were written (pixels == nullptr: all of them), so a rank of an N-GPU job reads 1/N of every plane
+__global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes, const uint32_t* pixels, uint32_t numOwned)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= acc.stride)
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= numOwned)
         return;
+    const uint32_t i = pixels ? pixels[k] : k;
     float4 s = acc.plane0[i];
     for (uint32_t p = 1; p < planes; p++) {
         float4* e = acc.extra + (size_t)(p - 1u) * acc.stride + i;

@@ -55,8 +55,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_ANYHIT_SORT
 #define PT_ANYHIT_SORT 0
 #endif
-#ifndef PT_LEAF_PIPE
-#define PT_LEAF_PIPE 0
+#ifndef PT_LEAF_ONE
+#define PT_LEAF_ONE 0
 #endif
 #ifndef PT_POOL_DIRECT
 #define PT_POOL_DIRECT 1
@@ -479,25 +479,15 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
                     bool done = false;
-#if PT_LEAF_PIPE
-                    // software-pipelined: triangle k+1 is in flight while triangle k is tested
-                    const TriIsect* tp0 = &sc.tris[first];
-                    float4 ta = tp0->a, tb = tp0->b;
-                    float tcx = tp0->c.x;
-#endif
-                    for (uint32_t k = 0; k < n; k++) {
-#if PT_LEAF_PIPE
-                        float4 na = ta, nb = tb;
-                        float ncx = tcx;
-                        if (k + 1 < n) {
-                            const TriIsect* tn = &sc.tris[first + k + 1];
-                            na = tn->a, nb = tn->b, ncx = tn->c.x;
-                        }
+#if PT_LEAF_ONE
+                    const uint32_t nHere = 1u; // one triangle per step: the rest of the leaf goes back into the vote
 #else
+                    const uint32_t nHere = n;
+#endif
+                    for (uint32_t k = 0; k < nHere; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
-#endif
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
                         const V3 P = cross(cd, e2);
                         const float det = dot(e1, P);
@@ -520,16 +510,19 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             hprim = (int)(first + k);
                             hinst = curInst;
                         }
-#if PT_LEAF_PIPE
-                        ta = na, tb = nb, tcx = ncx;
-#endif
                     }
                     if (ANY_HIT && done) { // occluded: nothing to deposit
                         if (a.occluded)
                             a.occluded[rayIdx] = 1u;
                         active = false;
                         cur = kRefFinish;
-                    } else {
+                    }
+#if PT_LEAF_ONE
+                    else if (n > 1u) {
+                        cur = makeRef(first + 1u, n - 1u);
+                    }
+#endif
+                    else {
                         cur = popTop(stackTop);
                         sp = max(sp - 1, 0);
                     }

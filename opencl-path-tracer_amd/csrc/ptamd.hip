@@ -521,8 +521,9 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
     if (batch > 1) {
-        const uint32_t n = c->cfg.width * c->cfg.height;
-        hipLaunchKernelGGL(k_fold_planes, dim3((n + 255) / 256), dim3(256), 0, c->stream, accumView(c), batch);
+        const uint32_t n = c->numOwned;
+        hipLaunchKernelGGL(k_fold_planes, dim3((n + 255) / 256), dim3(256), 0, c->stream, accumView(c), batch,
+            c->identityPixels ? nullptr : c->pixelList.p, n);
     }
     HIPCHK(c, hipGetLastError());
     return PT_OK;
