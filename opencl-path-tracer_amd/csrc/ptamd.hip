@@ -211,18 +211,32 @@ std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t
         c.ref = side ? n.right : n.left;
         return c;
     };
+    auto area = [](const Child& c) {
+        const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+        return dx >= 0.f && dy >= 0.f && dz >= 0.f ? dx * dy + dy * dz + dz * dx : -1.f;
+    };
     for (size_t i = 0; i < pair.size(); i++) {
+        // the two children of the binary node, then (surface-area greedy) the largest inner child is replaced
+        // by its own two children until four are collected: the expensive-to-miss boxes are the ones opened up
         Child kids[4];
         int n = 0;
-        for (int side = 0; side < 2; side++) {
-            Child c = childOf(pair[i], side);
-            if (refCount(c.ref) == 0u && refIndex(c.ref) < pair.size() && refIndex(c.ref) != i) {
-                const PairNode& g = pair[refIndex(c.ref)];
-                kids[n++] = childOf(g, 0);
-                kids[n++] = childOf(g, 1);
-            } else {
-                kids[n++] = c;
+        kids[n++] = childOf(pair[i], 0);
+        kids[n++] = childOf(pair[i], 1);
+        while (n < 4) {
+            int best = -1;
+            float bestArea = -1.f;
+            for (int k = 0; k < n; k++) {
+                const uint32_t r = kids[k].ref;
+                if (r != kRefNone && refCount(r) == 0u && refIndex(r) < pair.size() && refIndex(r) != i && area(kids[k]) > bestArea) {
+                    best = k;
+                    bestArea = area(kids[k]);
+                }
             }
+            if (best < 0)
+                break;
+            const PairNode& g = pair[refIndex(kids[best].ref)];
+            kids[best] = childOf(g, 0);
+            kids[n++] = childOf(g, 1);
         }
         float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         for (int k = 0; k < n; k++)
@@ -274,6 +288,69 @@ std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t
         wide[i] = w;
     }
     return wide;
+}
+
+// Worst-case number of pending stack entries while traversing the 4-wide tree from `rootRef`: visiting a node
+// can leave all its other children on the stack, and entering an instance adds the leave-instance sentinel.
+// (Children are visited nearest first, so any order can occur: the bound takes the deepest child first.)
+uint32_t wideStackNeed(const std::vector<WideNode>& wide, const std::vector<Instance>& inst, uint32_t rootRef, uint32_t emptyRef)
+{
+    constexpr uint32_t kUnset = 0xFFFFFFFFu;
+    std::vector<uint32_t> need(wide.size(), kUnset);
+    auto childRefs = [&](uint32_t ref, uint32_t out[4]) { // references below `ref` that still have to be sized
+        int n = 0;
+        if (refCount(ref) == 0u && refIndex(ref) < wide.size()) {
+            for (uint32_t r : wide[refIndex(ref)].child)
+                if (r != emptyRef)
+                    out[n++] = r;
+        } else if (refCount(ref) == kRefSpecial && refIndex(ref) < inst.size()) {
+            out[n++] = inst[refIndex(ref)].rootRef;
+        }
+        return n;
+    };
+    auto known = [&](uint32_t ref, uint32_t* v) { // leaves need nothing; inner nodes are memoised; instances are derived
+        if (refCount(ref) == 0u && refIndex(ref) < wide.size()) {
+            *v = need[refIndex(ref)];
+            return *v != kUnset;
+        }
+        if (refCount(ref) == kRefSpecial && refIndex(ref) < inst.size()) {
+            uint32_t below = 0;
+            const uint32_t rr = inst[refIndex(ref)].rootRef;
+            if (refCount(rr) == 0u && refIndex(rr) < wide.size()) {
+                below = need[refIndex(rr)];
+                if (below == kUnset)
+                    return false;
+            }
+            *v = 1u + below;
+            return true;
+        }
+        *v = 0u;
+        return true;
+    };
+    std::vector<uint32_t> todo { rootRef };
+    while (!todo.empty()) {
+        const uint32_t ref = todo.back();
+        uint32_t kids[4], v = 0;
+        const int n = childRefs(ref, kids);
+        bool ready = true;
+        uint32_t deepest = 0;
+        for (int k = 0; k < n; k++) {
+            if (known(kids[k], &v))
+                deepest = std::max(deepest, v);
+            else {
+                ready = false;
+                todo.push_back(refCount(kids[k]) == kRefSpecial ? inst[refIndex(kids[k])].rootRef : kids[k]);
+            }
+        }
+        if (!ready)
+            continue;
+        todo.pop_back();
+        if (refCount(ref) == 0u && refIndex(ref) < wide.size())
+            need[refIndex(ref)] = (n > 0 ? (uint32_t)(n - 1) : 0u) + deepest;
+    }
+    uint32_t v = 0;
+    known(rootRef, &v);
+    return v;
 }
 
 int resetStreams(pt_ctx* c)
@@ -1011,7 +1088,11 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         return fail(c, PT_ERR_UNSUPPORTED, "pt_upload_dynamic: too many triangle references");
     const uint32_t emptyRef = makeRef((uint32_t)allTris.size(), 1u);
     allTris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) });
-    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, collapseToWide(hNodes, emptyRef))) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    const std::vector<WideNode> hWide = collapseToWide(hNodes, emptyRef);
+    const uint32_t stackNeed = wideStackNeed(hWide, hInst, topRef[topRoot], emptyRef);
+    if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
+    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, hWide)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
     c->scene.rootRef = topRef[topRoot];
