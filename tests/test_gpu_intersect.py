@@ -109,3 +109,68 @@ def test_large_leaves_are_split_at_upload(gpu):
     got, want = ctx.intersect(o, d), O.intersect_batch(O.BoundScene(flat), o, d)
     assert np.array_equal(got["prim"], want["prim"]) and np.allclose(got["t"][:2], want["t"][:2])
     ctx.close()
+
+
+def _chain_scene(n):
+    """n parallel triangles (z = 0.1 k) under a hand-made degenerate BVH: node k -> (leaf k, rest)."""
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (n, 1))
+    pos[:, 2] = np.repeat(np.arange(n, dtype=np.float32) * 0.1, 3)
+    mesh = H.Mesh(pos, np.arange(3 * n, dtype=np.uint32).reshape(n, 3), [L.material_diffuse((1, 1, 1))], builder=H.BVH_BINNED_SAH)
+    sc = H.Scene()
+    sc.add_node(mesh)
+    flat = sc.flatten()
+    z = flat.vertices["vertex"][flat.triangles["indices"][:, 0], 2]  # triangles were reordered by the builder
+    order = np.argsort(z, kind="stable")
+    flat.triangles = flat.triangles[order]
+    z = z[order]
+    nodes = np.zeros(2 * n, L.SUB_BVH_NODE)  # node 0 root, node 1 the reference allocator's dummy, then pairs
+    for k in range(n - 1):
+        me = 0 if k == 0 else 2 * k + 1
+        nodes[me]["min"][:3], nodes[me]["max"][:3] = (0, 0, z[k]), (1, 1, z[n - 1])
+        nodes[me]["left"], nodes[me]["count"] = 2 * k + 2, 0
+        leaf = 2 * k + 2
+        nodes[leaf]["min"][:3], nodes[leaf]["max"][:3] = (0, 0, z[k]), (1, 1, z[k])
+        nodes[leaf]["left"], nodes[leaf]["count"] = k, 1
+    last = 2 * (n - 2) + 3
+    nodes[last]["min"][:3], nodes[last]["max"][:3] = (0, 0, z[n - 1]), (1, 1, z[n - 1])
+    nodes[last]["left"], nodes[last]["count"] = n - 1, 1
+    nodes[1] = nodes[last]  # never referenced
+    flat.sub_nodes = nodes
+    return flat, z
+
+
+def test_deep_trees_use_the_spilled_stack_and_too_deep_ones_are_rejected(gpu):
+    """A 100-level chain needs ~100 pending entries when entered from the far side: 16 live in LDS, the rest in
+    the global spill region.  A 130-level chain exceeds LDS + spill and must be refused at upload."""
+    n = 100
+    flat, z = _chain_scene(n)
+    ctx = gpu.Context(8, 8)
+    ctx.upload_scene(flat)
+    m = 4096
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(0.05, 0.45, (m, 2)).astype(np.float32)
+    o = np.concatenate([np.c_[xy, np.full(m, 100.0, np.float32)], np.c_[xy, np.full(m, -100.0, np.float32)]]).astype(np.float32)
+    d = np.concatenate([np.tile([0, 0, -1], (m, 1)), np.tile([0, 0, 1], (m, 1))]).astype(np.float32)
+    got = ctx.intersect(o, d)
+    assert (got["prim"][:m] == n - 1).all() and (got["prim"][m:] == 0).all()
+    assert np.allclose(got["t"][:m], 100.0 - z[n - 1], rtol=1e-5) and np.allclose(got["t"][m:], 100.0 + z[0], rtol=1e-5)
+    # slanted rays: brute force over the n planes
+    o2 = np.c_[rng.uniform(0.05, 0.3, (m, 2)), np.full(m, 50.0)].astype(np.float32)
+    d2 = np.c_[rng.uniform(-0.002, 0.002, (m, 2)), np.full(m, -1.0)].astype(np.float32)
+    got2 = ctx.intersect(o2, d2)
+    t_all = (z[None, :] - o2[:, 2:3]) / d2[:, 2:3]
+    p = o2[:, None, :2] + t_all[..., None] * d2[:, None, :2]
+    inside = (p[..., 0] >= 0) & (p[..., 1] >= 0) & (p[..., 0] + p[..., 1] <= 1)
+    t_all = np.where(inside, t_all, np.inf)
+    want = np.where(np.isfinite(t_all.min(1)), t_all.argmin(1), -1)
+    assert (got2["prim"] == want).mean() > 0.999  # edge-grazing rays may differ by round-off
+    occ = ctx.intersect(o[:m], d[:m], tmax=np.full(m, 85.0, np.float32), any_hit=True)["prim"]  # stops short of every triangle
+    assert not occ.any()
+    occ = ctx.intersect(o[:m], d[:m], tmax=np.full(m, 95.0, np.float32), any_hit=True)["prim"]  # reaches half of them
+    assert occ.all()
+    ctx.close()
+    flat2, _ = _chain_scene(130)
+    ctx = gpu.Context(8, 8)
+    with pytest.raises(RuntimeError, match="stack"):
+        ctx.upload_scene(flat2)
+    ctx.close()
