@@ -76,7 +76,8 @@ struct Instance {
     float4 r0, r1, r2; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major matrix
     uint32_t rootRef; // makeRef
     uint32_t topNode; // index of the top-level leaf (reported as `inst` in hit records)
-    uint32_t _p0, _p1;
+    uint32_t root8; // node index of the mesh root in the 8-wide tree (pt_wide8.h)
+    uint32_t _p1;
 };
 
 struct Material { // the reference's 48-byte record, read as 3 x float4
@@ -96,10 +97,14 @@ struct Texture {
     int32_t width, height, layers, _pad;
 };
 
+struct Node8;
 struct SceneDev {
-    const PairNode* nodes; // PT_WIDE=0 builds
-    const WideNode* wide;
-    const TriIsect* tris;
+    const PairNode* nodes; // the reference's binary tree, both boxes per node (kept for diagnostics)
+    const WideNode* wide; // 4-wide tree (k_trace)
+    const Node8* nodes8; // 8-wide compressed tree (k_trace8), its triangles in node order and its top-level items
+    const TriIsect* tris8;
+    const uint32_t* items;
+    const TriIsect* tris; // caller's triangle numbering (shading re-reads v0/e1/e2 from here)
     const TriShade* triShade;
     const VertexShade* verts;
     const Material* materials;
@@ -110,7 +115,7 @@ struct SceneDev {
     uint32_t numLights;
     uint32_t rootRef; // reference of the top-level root: a PairNode, or an instance when there is only one
     uint32_t numTriangles;
-    uint32_t _pad;
+    uint32_t root8; // node index of the top-level root in the 8-wide tree
 };
 
 // ---- queues ---------------------------------------------------------------------------------

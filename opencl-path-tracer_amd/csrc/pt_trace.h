@@ -234,15 +234,13 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     PT_TIC(tAssign);
                     if (!active && rank < avail) {
                         const uint32_t idx = poolBase + (uint32_t)e;
-                        bool live = true;
-                        float tMax = INFINITY;
-                        if (ANY_HIT) {
-                            // contribution and pixel stay in the queue until the ray turns out unoccluded
-                            tMax = ro.w;
-                            if (a.parityShadow && (asU(a.rayC[idx].w) & FLAG_FINISHED))
-                                live = false;
-                        } else if (asU(rd.w) & FLAG_FINISHED) { // parity mode keeps finished rays in the queue
-                            live = false;
+                        float tMax = ANY_HIT ? ro.w : INFINITY;
+                        asm volatile("" : "+v"(tMax)); // own register (see the note in k_trace8 about the flag load below)
+                        uint32_t state = asU(rd.w); // closest-hit: parity mode keeps finished rays in the queue
+                        if (ANY_HIT) // contribution and pixel stay in the queue until the ray turns out unoccluded
+                            state = a.parityShadow ? asU(a.rayC[idx].w) : 0u;
+                        const bool live = (state & FLAG_FINISHED) == 0u;
+                        if (!ANY_HIT && !live) {
                             a.hit[idx] = make_float4(INFINITY, 0.f, 0.f, asF(0xFFFFFFFFu));
                             a.inst[idx] = -1;
                         }

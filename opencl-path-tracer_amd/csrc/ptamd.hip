@@ -4,6 +4,7 @@
 #include "../../include/ptamd.h"
 #include "pt_shade.h"
 #include "pt_trace.h"
+#include "pt_trace8.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -65,6 +66,9 @@ struct pt_ctx {
     // scene (HBM)
     DevBuf<PairNode> nodes;
     DevBuf<WideNode> wide;
+    DevBuf<Node8> nodes8;
+    DevBuf<TriIsect> tris8;
+    DevBuf<uint32_t> items;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> triShade;
     DevBuf<VertexShade> verts;
@@ -140,6 +144,9 @@ void refreshSceneView(pt_ctx* c)
     SceneDev& s = c->scene;
     s.nodes = c->nodes.p;
     s.wide = c->wide.p;
+    s.nodes8 = c->nodes8.p;
+    s.tris8 = c->tris8.p;
+    s.items = c->items.p;
     s.tris = c->tris.p;
     s.triShade = c->triShade.p;
     s.verts = c->verts.p;
@@ -425,7 +432,11 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     int blocksPerCU = 0;
     blocksPerCU = 8;
+#if PT_BVH8
+    const void* variants[4] = { (const void*)k_trace8<false>, (const void*)k_trace8<true>, (const void*)k_trace<false>, (const void*)k_trace<true> };
+#else
     const void* variants[2] = { (const void*)k_trace<false>, (const void*)k_trace<true> };
+#endif
     for (const void* fn : variants) {
         int b = 0;
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
@@ -441,10 +452,24 @@ int ensureSpill(pt_ctx* c)
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
     const dim3 grid(c->traceBlocks), block(kTraceBlock);
+#if PT_BVH8
+    if (anyHit) {
+        if (PT_BVH8 & 2)
+            hipLaunchKernelGGL(k_trace8<true>, grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
+    } else {
+        if (PT_BVH8 & 1)
+            hipLaunchKernelGGL(k_trace8<false>, grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
+    }
+#else
     if (anyHit)
         hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
     else
         hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
+#endif
 }
 
 TraceArgs traceArgsBase(pt_ctx* c)
@@ -741,7 +766,7 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->wide.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->wide.release(), c->nodes8.release(), c->tris8.release(), c->items.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
@@ -1092,6 +1117,27 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     const uint32_t stackNeed = wideStackNeed(hWide, hInst, topRef[topRoot], emptyRef);
     if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
         return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
+#if PT_BVH8
+    // ---- 8-wide compressed tree over the same pair nodes (pt_wide8.h) --------------------------------
+    {
+        std::vector<uint32_t> bottomRoots;
+        for (const Instance& in : hInst)
+            bottomRoots.push_back(in.rootRef);
+        const pt_top_bvh_node& tr = topNodes[topRoot];
+        const Wide8 w8 = buildWide8(hNodes, allTris, bottomRoots, topRef[topRoot], tr.min, tr.max, (uint32_t)c->hostTris.size());
+        std::vector<uint32_t> instRootNode(hInst.size());
+        for (size_t k = 0; k < hInst.size(); k++)
+            instRootNode[k] = hInst[k].root8 = w8.rootOf.at(hInst[k].rootRef);
+        const uint32_t need8 = wide8StackNeed(w8, instRootNode);
+        if (need8 > (uint32_t)(kLdsStack8 + kSpillStack8))
+            return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack groups, %d are available", need8, kLdsStack8 + kSpillStack8);
+        if (w8.nodes.size() > 0x7FFFFFFFu || w8.tris.size() > 0x7FFFFFFFu)
+            return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
+        if ((rc = uploadVec(c, c->nodes8, w8.nodes)) || (rc = uploadVec(c, c->tris8, w8.tris)) || (rc = uploadVec(c, c->items, w8.items)))
+            return rc;
+        c->scene.root8 = w8.topRoot;
+    }
+#endif
     if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, hWide)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;

@@ -62,8 +62,16 @@ def test_edge_cases(gpu):
         d[6 + k, k % 3] = 1.0 if k < 3 else -1.0
     o[6:, 0], o[6:, 2] = -1.0, 1.0  # on the left wall plane and the back wall plane
     got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d)
-    assert np.array_equal(got["prim"] >= 0, want["prim"] >= 0)
-    hit = want["prim"] >= 0
+    gh, wh = got["prim"] >= 0, want["prim"] >= 0
+    assert np.array_equal(gh[:6], wh[:6])
+    # rays 6..11 lie IN two box faces with a zero direction component: the reference's slab test evaluates
+    # 0 * inf there, so whether a box is entered is an accident of the tree; a verdict may only differ where the
+    # ray grazes a triangle's boundary (corner / edge hit)
+    for k in np.nonzero(gh != wh)[0]:
+        h = got if gh[k] else want
+        u, v = float(h["u"][k]), float(h["v"][k])
+        assert min(abs(u), abs(v), abs(1.0 - u - v)) < 1e-5, (k, u, v)
+    hit = gh & wh
     assert np.allclose(got["t"][hit], want["t"][hit], rtol=1e-5)
     far = np.array([[0, 50, 0]], np.float32)
     up = np.array([[0, 1, 0]], np.float32)

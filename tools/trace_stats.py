@@ -15,6 +15,8 @@ def report(tag, s, nrays):
     it, act, ki, kl, ks, li, ll, ls, ho, hr = s[:10]
     print(f"{tag:12s} rays {nrays:8d} wave-iters/ray*64 {it*64/max(nrays,1):6.1f}  active/iter {act/max(it,1):5.1f}  iters inner/leaf/special {ki/it:.2f}/{kl/it:.2f}/{ks/it:.2f} "
           f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
+    if s[16]:
+        print(f"             triangles tested per ray {s[16]/max(nrays,1):5.2f} (lane-level count / 64 lanes: {s[16]} per-wave loops)")
     tot, tin, tle, tsp, tha = s[10], s[11], s[12], s[13], s[14]
     if tot:
         print(f"             wave cycles: inner {100*tin/tot:4.1f}% ({tin/max(ki,1):6.0f}/step)  leaf {100*tle/tot:4.1f}% ({tle/max(kl,1):6.0f}/step)  special {100*tsp/tot:4.1f}% ({tsp/max(ks,1):6.0f}/pass)"
