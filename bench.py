@@ -196,12 +196,14 @@ def main():
         rays_per_launch = ps["rays_extension"] / launches
         avg_ms = ps["ms_intersect"] / launches
         achieved = BYTES_PER_EXT_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC profile of this exact configuration
+        traffic, traffic_note = None, None  # HBM bytes per launch from the committed PMC profile of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic_k_trace_closest.json")))
             cfgt = tj["config"]
             if (cfgt["width"], cfgt["height"], cfgt["level"], cfgt["samples_in_flight"], cfgt["n_gpus"]) == (W, Hh, args.level, in_flight, world):
                 traffic = round(tj["bytes_per_ray"]["total"] * rays_per_launch)
+                traffic_note = (f"bytes per launch = {tj['bytes_per_ray']['total']} B/ray (FETCH_SIZE / WRITE_SIZE PMC passes of this exact "
+                                "configuration, corrected as profiles/round1/traffic_k_trace_closest.json states) x rays per launch")
         except (OSError, KeyError, ValueError):
             pass
         # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
@@ -224,7 +226,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
                     "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
-                    "traffic_note": "bytes per launch = 108.3 B/ray (FETCH_SIZE/WRITE_SIZE PMC passes, profiles/round1/traffic_k_trace_closest.json) x rays per launch" if traffic else None,
+                    "traffic_note": traffic_note,
                     "algorithmic_bytes_per_ray": BYTES_PER_EXT_RAY, "rays_per_launch": int(rays_per_launch),
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "mrays_per_s_in_kernel": round(rays_per_launch / avg_ms / 1e3, 1),
