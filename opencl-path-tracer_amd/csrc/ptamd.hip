@@ -6,6 +6,7 @@
 #include "pt_trace.h"
 #include "pt_trace8.h"
 #include <algorithm>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1388,12 +1389,34 @@ int pt_profile_kernels(pt_ctx* c, int enable)
 
 int pt_reduce_accum(pt_ctx* c, void* nccl_comm, int root)
 {
-    (void)nccl_comm;
-    (void)root;
-    // The accumulator is exposed as device memory (pt_accum_device_ptr / pt_set_accum_buffer) so that the
-    // caller's communicator reduces it: bench.py does torch.distributed.reduce (RCCL) on a tensor that
-    // aliases it.  Linking librccl into this library is deferred.
-    return fail(c, PT_ERR_UNSUPPORTED, "pt_reduce_accum: reduce the buffer of pt_accum_device_ptr() with the caller's RCCL communicator");
+    if (!c || !nccl_comm)
+        return PT_ERR_INVALID;
+    // RCCL is bound at first use, and to the copy the process has ALREADY loaded if there is one (the
+    // communicator comes from the caller's RCCL; a second copy of the library would not know it).
+    // PTAMD_RCCL_LIB names a library explicitly.
+    typedef int (*reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+    static reduce_fn reduce = nullptr;
+    if (!reduce) {
+        void* lib = nullptr;
+        if (const char* path = getenv("PTAMD_RCCL_LIB"))
+            lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        const char* names[] = { "librccl.so.1", "librccl.so" };
+        for (int pass = 0; pass < 2 && !lib; pass++)
+            for (const char* n : names)
+                if (!lib)
+                    lib = dlopen(n, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : RTLD_GLOBAL));
+        if (lib)
+            reduce = (reduce_fn)dlsym(lib, "ncclReduce");
+        if (!reduce)
+            return fail(c, PT_ERR_UNSUPPORTED, "pt_reduce_accum: librccl not found (%s)", dlerror() ? dlerror() : "no ncclReduce symbol");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    float* buf = (float*)c->accum; // in place on the root (sendbuff == recvbuff is allowed there), send-only elsewhere
+    const size_t count = (size_t)c->cfg.width * c->cfg.height * 4;
+    const int rc = reduce(buf, buf, count, /*ncclFloat*/ 7, /*ncclSum*/ 0, root, nccl_comm, c->stream);
+    if (rc != 0)
+        return fail(c, PT_ERR_HIP, "pt_reduce_accum: ncclReduce returned %d", rc);
+    return PT_OK;
 }
 
 // ---- kernel-granular hooks ---------------------------------------------------------------------

@@ -1,4 +1,6 @@
 """Whole ray-queue renders on the GPU against the oracle / the golden images of the reference kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -160,5 +162,45 @@ def test_external_accumulator_and_stream(gpu):
     own = U.make_ctx(gpu, b, 48, 27, seed=2)
     own.render(4)
     assert np.array_equal(acc.cpu().numpy(), own.read_accum())
+    ctx.close()
+    own.close()
+
+
+def test_reduce_accum_through_rccl_single_rank(gpu):
+    """pt_reduce_accum == ncclReduce(float, sum) of the HDR accumulator on the context's stream, with the caller's
+    communicator.  One GPU here, so a communicator of one rank (the N-rank path is bench.py's torch.distributed
+    reduce, rehearsed on CPU by tests/test_multirank_gloo.py): the call must succeed, run on the render stream and
+    leave the sums unchanged."""
+    import ctypes as C
+    import glob
+    import torch
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so.1"]
+    rccl = None
+    for p in cands:  # the copy torch ships first: it shares torch's HIP runtime, which libptamd uses too
+        try:
+            rccl = C.CDLL(p, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library on this box")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    b = scenes.cornell_box(48, 27)
+    ctx = U.make_ctx(gpu, b, 48, 27, seed=2)
+    ctx.render(4, sync=False)
+    assert gpu.lib().pt_reduce_accum(ctx._h, comm, 0) == 0, gpu.lib().pt_last_error(ctx._h)
+    ctx.synchronize()
+    own = U.make_ctx(gpu, b, 48, 27, seed=2)
+    own.render(4)
+    assert np.array_equal(ctx.read_accum(), own.read_accum())
+    assert gpu.lib().pt_reduce_accum(ctx._h, None, 0) != 0  # no communicator: an error code, not a crash
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
     ctx.close()
     own.close()
