@@ -40,6 +40,14 @@ const char* pth_last_error(void);
 pth_mesh* pth_mesh_create(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
     const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles, const pt_material* materials,
     size_t numMaterials, int builder);
+/* Same, with the reference's .bvh cache file (src/model/mesh.cpp:175-263: u32 version 1, u32 root, u32 numNodes,
+ * nodes[48 B], u32 numTriangles, triangles[16 B], '\n'): loaded if present and valid for this mesh, else the
+ * tree is built and the file written.  pth_mesh_bvh_from_cache tells which happened. */
+pth_mesh* pth_mesh_create_cached(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+    const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles, const pt_material* materials,
+    size_t numMaterials, int builder, const char* bvhCacheFile);
+int pth_mesh_store_bvh(const pth_mesh* m, const char* path); /* Mesh::storeBvh, mesh.cpp:202-225 */
+int pth_mesh_bvh_from_cache(const pth_mesh* m);
 pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int builder);
 void pth_mesh_destroy(pth_mesh* m);
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out);

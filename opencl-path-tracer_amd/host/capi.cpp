@@ -56,6 +56,29 @@ pth_mesh* pth_mesh_create(const float* positions, const float* normals, const fl
     return rc == 0 ? (pth_mesh*)h : nullptr;
 }
 
+pth_mesh* pth_mesh_create_cached(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
+    const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles, const pt_material* materials,
+    size_t numMaterials, int builder, const char* bvhCacheFile)
+{
+    MeshHandle* h = nullptr;
+    int rc = guarded([&] {
+        std::vector<Material> mats(numMaterials);
+        for (size_t i = 0; i < numMaterials; i++)
+            static_cast<pt_material&>(mats[i]) = materials[i];
+        auto m = std::make_shared<Mesh>(positions, normals, texCoords, numVertices, indices, materialIndex, numTriangles, mats, (BvhBuilder)builder,
+            bvhCacheFile ? std::string(bvhCacheFile) : std::string());
+        h = new MeshHandle { m };
+    });
+    return rc == 0 ? (pth_mesh*)h : nullptr;
+}
+
+int pth_mesh_store_bvh(const pth_mesh* m, const char* path)
+{
+    return guarded([&] { ((const MeshHandle*)m)->mesh->storeBvh(path); });
+}
+
+int pth_mesh_bvh_from_cache(const pth_mesh* m) { return m && ((const MeshHandle*)m)->mesh->bvhFromCache() ? 1 : 0; }
+
 pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int builder)
 {
     MeshHandle* h = nullptr;

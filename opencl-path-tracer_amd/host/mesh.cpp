@@ -2,6 +2,8 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
+#include <tuple>
 #include <sstream>
 #include <stdexcept>
 
@@ -9,7 +11,7 @@ namespace raytracer {
 
 Mesh::Mesh(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
     const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles,
-    const std::vector<Material>& materials, BvhBuilder builder)
+    const std::vector<Material>& materials, BvhBuilder builder, const std::string& bvhCacheFile)
     : m_materials(materials), m_builder(builder)
 {
     if (materials.empty())
@@ -52,7 +54,11 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
             m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
         }
     }
-    m_bvh = buildBVH(m_vertices.data(), m_vertices.size(), m_inputTriangles.data(), m_inputTriangles.size(), builder);
+    if (bvhCacheFile.empty() || !loadBvh(bvhCacheFile)) {
+        m_bvh = buildBVH(m_vertices.data(), m_vertices.size(), m_inputTriangles.data(), m_inputTriangles.size(), builder);
+        if (!bvhCacheFile.empty())
+            storeBvh(bvhCacheFile);
+    }
     // emissive triangles are listed once per INPUT triangle (spatial splits may duplicate references)
     std::vector<uint8_t> listed(numTriangles, 0);
     for (size_t i = 0; i < m_bvh.triangles.size(); i++) {
@@ -62,6 +68,102 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
             m_emissive.push_back((uint32_t)i);
         }
     }
+}
+
+static const uint32_t BVH_FILE_FORMAT_VERSION = 1; // mesh.cpp:200
+
+void Mesh::storeBvh(const std::string& fileName) const
+{
+    std::ofstream out(fileName, std::ios::out | std::ios::binary | std::ios::trunc);
+    if (!out)
+        throw std::runtime_error("cannot write " + fileName);
+    const uint32_t root = m_bvh.rootNode, numNodes = (uint32_t)m_bvh.nodes.size(), numTriangles = (uint32_t)m_bvh.triangles.size();
+    out.write((const char*)&BVH_FILE_FORMAT_VERSION, 4);
+    out.write((const char*)&root, 4);
+    out.write((const char*)&numNodes, 4);
+    out.write((const char*)m_bvh.nodes.data(), (std::streamsize)numNodes * sizeof(SubBVHNode));
+    out.write((const char*)&numTriangles, 4);
+    out.write((const char*)m_bvh.triangles.data(), (std::streamsize)numTriangles * sizeof(TriangleSceneData));
+    out << std::endl; // the reference ends the file with one (mesh.cpp:223)
+    if (!out)
+        throw std::runtime_error("short write to " + fileName);
+}
+
+bool Mesh::loadBvh(const std::string& fileName)
+{
+    std::ifstream in(fileName, std::ios::binary);
+    if (!in)
+        return false;
+    in.seekg(0, std::ios::end);
+    const uint64_t fileSize = (uint64_t)in.tellg();
+    in.seekg(0);
+    uint32_t version = 0, root = 0, numNodes = 0, numTriangles = 0;
+    in.read((char*)&version, 4);
+    in.read((char*)&root, 4);
+    in.read((char*)&numNodes, 4);
+    if (!in || version != BVH_FILE_FORMAT_VERSION || numNodes == 0 || root >= numNodes || 12 + (uint64_t)numNodes * sizeof(SubBVHNode) + 4 > fileSize)
+        return false;
+    BvhBuildResult r;
+    r.rootNode = root;
+    r.nodes.resize(numNodes);
+    in.read((char*)r.nodes.data(), (std::streamsize)numNodes * sizeof(SubBVHNode));
+    in.read((char*)&numTriangles, 4);
+    const uint64_t payload = 16 + (uint64_t)numNodes * sizeof(SubBVHNode) + (uint64_t)numTriangles * sizeof(TriangleSceneData);
+    if (!in || numTriangles == 0 || (payload != fileSize && payload + 1 != fileSize)) // with or without the trailing newline
+        return false;
+    r.triangles.resize(numTriangles);
+    in.read((char*)r.triangles.data(), (std::streamsize)numTriangles * sizeof(TriangleSceneData));
+    if (!in)
+        return false;
+    // the file must describe THIS mesh: every reference is one of the input triangles, every input triangle is there
+    struct Key {
+        uint32_t a, b, c, m;
+        bool operator<(const Key& o) const { return std::tie(a, b, c, m) < std::tie(o.a, o.b, o.c, o.m); }
+    };
+    std::map<Key, uint32_t> inputOf;
+    for (size_t t = 0; t < m_inputTriangles.size(); t++) {
+        const auto& tri = m_inputTriangles[t];
+        inputOf.emplace(Key { tri.indices[0], tri.indices[1], tri.indices[2], tri.materialIndex }, (uint32_t)t);
+    }
+    std::vector<uint8_t> seen(m_inputTriangles.size(), 0);
+    r.originalTriangle.resize(numTriangles);
+    for (uint32_t i = 0; i < numTriangles; i++) {
+        const auto& tri = r.triangles[i];
+        auto it = inputOf.find(Key { tri.indices[0], tri.indices[1], tri.indices[2], tri.materialIndex });
+        if (it == inputOf.end())
+            return false;
+        r.originalTriangle[i] = it->second;
+        seen[it->second] = 1;
+    }
+    for (const auto& tri : m_inputTriangles) // duplicates of one input triangle share a key: look each one up
+        if (!seen[inputOf.at(Key { tri.indices[0], tri.indices[1], tri.indices[2], tri.materialIndex })])
+            return false;
+    // structure first (checkBVH assumes a well-formed tree): children lie after their parent, so there are no
+    // cycles, and every index is in range
+    {
+        std::vector<uint32_t> todo { root };
+        while (!todo.empty()) {
+            const uint32_t i = todo.back();
+            todo.pop_back();
+            const SubBVHNode& n = r.nodes[i];
+            if (n.triangleCount != 0) {
+                if ((uint64_t)n.leftChildOrFirstTriangle + n.triangleCount > numTriangles)
+                    return false;
+            } else {
+                const uint32_t l = n.leftChildOrFirstTriangle;
+                if (l <= i || (uint64_t)l + 1 >= numNodes)
+                    return false;
+                todo.push_back(l);
+                todo.push_back(l + 1);
+            }
+        }
+    }
+    const BvhStats st = checkBVH(r, m_vertices.data(), m_inputTriangles.size(), false);
+    if (!st.childrenInsideParents || !st.trianglesInsideLeaves || !st.allTrianglesReferenced)
+        return false;
+    m_bvh = std::move(r);
+    m_bvhFromCache = true;
+    return true;
 }
 
 std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& material, BvhBuilder builder)

@@ -36,7 +36,7 @@ public:
     // triangle (null = 0).
     Mesh(const float* positions, const float* normals, const float* texCoords, size_t numVertices,
         const uint32_t* indices, const uint32_t* materialIndex, size_t numTriangles,
-        const std::vector<Material>& materials, BvhBuilder builder = BvhBuilder::SpatialSplit);
+        const std::vector<Material>& materials, BvhBuilder builder = BvhBuilder::SpatialSplit, const std::string& bvhCacheFile = "");
 
     static std::shared_ptr<Mesh> fromPLY(const std::string& path, const Material& material, BvhBuilder builder = BvhBuilder::SpatialSplit);
 
@@ -54,6 +54,15 @@ public:
     void buildBvh() override {}
     uint32_t getBvhRootNode() const override { return m_bvh.rootNode; }
 
+    // The reference's on-disk BVH cache (src/model/mesh.cpp:202-263), byte for byte: u32 version = 1, u32 root,
+    // u32 numNodes, numNodes x 48-B SubBVHNode, u32 numTriangles, numTriangles x 16-B TriangleSceneData, '\n'.
+    // A constructor given `bvhCacheFile` loads it when it exists AND validates (the reference trusts the file;
+    // here sizes, indices, the triangle set and the BvhTester invariants are checked, and a file that fails is
+    // rebuilt and overwritten) and stores the freshly built tree otherwise (mesh.cpp:175-196).
+    void storeBvh(const std::string& fileName) const;
+    bool loadBvh(const std::string& fileName);
+    bool bvhFromCache() const { return m_bvhFromCache; }
+
     const BvhBuildResult& getBvh() const { return m_bvh; }
     size_t numInputTriangles() const { return m_inputTriangles.size(); }
     BvhBuilder builder() const { return m_builder; }
@@ -66,6 +75,7 @@ private:
     BvhBuildResult m_bvh;
     AABB m_bounds;
     BvhBuilder m_builder;
+    bool m_bvhFromCache = false;
 };
 
 } // namespace raytracer

@@ -43,6 +43,10 @@ def lib():
         _lib.pth_mesh_create.restype = C.c_void_p
         _lib.pth_mesh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        _lib.pth_mesh_create_cached.restype = C.c_void_p
+        _lib.pth_mesh_create_cached.argtypes = _lib.pth_mesh_create.argtypes + [C.c_char_p]
+        _lib.pth_mesh_store_bvh.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.pth_mesh_bvh_from_cache.argtypes = [C.c_void_p]
         _lib.pth_mesh_from_ply.restype = C.c_void_p
         _lib.pth_mesh_from_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
         _lib.pth_mesh_destroy.argtypes = [C.c_void_p]
@@ -77,7 +81,7 @@ def _ptr(a):
 
 class Mesh:
     def __init__(self, positions, indices, materials, material_index=None, normals=None, tex_coords=None,
-                 builder=BVH_SPATIAL_SPLIT, _handle=None):
+                 builder=BVH_SPATIAL_SPLIT, _handle=None, bvh_cache=None):
         if _handle is not None:
             self._h = _handle
         else:
@@ -87,8 +91,9 @@ class Mesh:
             idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
             mi = None if material_index is None else np.ascontiguousarray(material_index, dtype=np.uint32)
             mats = np.ascontiguousarray(np.atleast_1d(np.asarray(materials, dtype=L.MATERIAL)))
-            self._h = lib().pth_mesh_create(_ptr(pos), _ptr(nrm), _ptr(uv), len(pos), _ptr(idx), _ptr(mi), len(idx),
-                                            _ptr(mats), len(mats), builder)
+            self._h = lib().pth_mesh_create_cached(_ptr(pos), _ptr(nrm), _ptr(uv), len(pos), _ptr(idx), _ptr(mi), len(idx),
+                                                   _ptr(mats), len(mats), builder,
+                                                   None if bvh_cache is None else str(bvh_cache).encode())
             if not self._h:
                 _err("pth_mesh_create")
         self.builder = builder
@@ -100,6 +105,15 @@ class Mesh:
         if not h:
             _err("pth_mesh_from_ply")
         return Mesh(None, None, None, builder=builder, _handle=h)
+
+    def store_bvh(self, path):
+        """Mesh::storeBvh (reference src/model/mesh.cpp:202-225): the .bvh cache file."""
+        if lib().pth_mesh_store_bvh(self._h, str(path).encode()):
+            _err("pth_mesh_store_bvh")
+
+    @property
+    def bvh_from_cache(self):
+        return bool(lib().pth_mesh_bvh_from_cache(self._h))
 
     def stats(self):
         s = MeshStats()

@@ -108,3 +108,51 @@ def test_cornell_has_36_triangles_and_inward_normals():
         p = f.vertices["vertex"][t["indices"], :3]
         n = np.cross(p[1] - p[0], p[2] - p[0])
         assert np.dot(n, centre - p[0]) > 0
+
+
+def test_bvh_cache_file_is_the_reference_format_and_is_validated(tmp_path):
+    """Mesh::storeBvh / loadBvh (reference src/model/mesh.cpp:202-263): u32 version 1, u32 root, u32 numNodes,
+    48-B nodes, u32 numTriangles, 16-B triangles, one trailing newline.  Round trip is exact; a file that is
+    truncated, of another version, for another mesh, or structurally broken is ignored and rebuilt."""
+    import struct
+    def blob(seed):
+        v, f = scenes.icosphere(3)
+        return (v * (1.0 + 0.25 * np.sin(4.0 * v[:, :1] + seed) * np.cos(3.0 * v[:, 1:2]))).astype(np.float32), f.astype(np.uint32)
+    pos, idx = blob(3)
+    mats = [L.material_diffuse((0.5, 0.5, 0.5))]
+    path = tmp_path / "blob.bvh"
+    a = H.Mesh(pos, idx, mats, builder=H.BVH_SPATIAL_SPLIT, bvh_cache=path)
+    assert not a.bvh_from_cache and path.exists()
+    nodes, tris, _ = a.bvh()
+    raw = path.read_bytes()
+    version, root, n_nodes = struct.unpack_from("<III", raw, 0)
+    assert (version, root, n_nodes) == (1, 0, len(nodes))
+    assert raw[12:12 + 48 * n_nodes] == nodes.tobytes()
+    (n_tris,) = struct.unpack_from("<I", raw, 12 + 48 * n_nodes)
+    assert n_tris == len(tris) and raw[16 + 48 * n_nodes:16 + 48 * n_nodes + 16 * n_tris] == tris.tobytes()
+    assert raw[16 + 48 * n_nodes + 16 * n_tris:] == b"\n"
+    b = H.Mesh(pos, idx, mats, builder=H.BVH_SPATIAL_SPLIT, bvh_cache=path)  # second start-up: loaded, not built
+    assert b.bvh_from_cache
+    nb, tb, ob = b.bvh()
+    assert nb.tobytes() == nodes.tobytes() and tb.tobytes() == tris.tobytes()
+    assert (idx[ob] == tb["indices"]).all()  # the reference -> input triangle map is recovered from the file
+    st = b.stats()
+    assert st["children_inside_parents"] and st["triangles_inside_leaves"] and st["all_triangles_referenced"]
+
+    def rebuilt_from(corrupt):
+        path.write_bytes(corrupt)
+        c = H.Mesh(pos, idx, mats, builder=H.BVH_SPATIAL_SPLIT, bvh_cache=path)
+        ok = not c.bvh_from_cache and c.bvh()[0].tobytes() == nodes.tobytes()
+        return ok and path.read_bytes() == raw  # and the good file is back on disk
+
+    assert rebuilt_from(raw[:len(raw) // 2])  # truncated
+    assert rebuilt_from(struct.pack("<I", 2) + raw[4:])  # other format version
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, 12 + 32, 0)  # root's left child = 0: a cycle
+    assert rebuilt_from(bytes(bad))
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, 16 + 48 * n_nodes, 0xFFFFFF)  # a vertex index this mesh does not have
+    assert rebuilt_from(bytes(bad))
+    pos2, _ = blob(4)  # same topology, other vertices: boxes no longer hold the triangles
+    c = H.Mesh(pos2 * 1.7, idx, mats, builder=H.BVH_SPATIAL_SPLIT, bvh_cache=path)
+    assert not c.bvh_from_cache
