@@ -49,9 +49,15 @@ pth_mesh* pth_mesh_create_cached(const float* positions, const float* normals, c
 int pth_mesh_store_bvh(const pth_mesh* m, const char* path); /* Mesh::storeBvh, mesh.cpp:202-225 */
 int pth_mesh_bvh_from_cache(const pth_mesh* m);
 pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int builder);
+/* Wavefront OBJ + MTL, imported the way the reference imports model files (src/model/mesh.cpp:36-200): polygons
+ * triangulated, corners welded, the TRS `offset` baked in (null = identity), Ke != 0 -> Emissive(Ke) else Diffuse(Kd),
+ * or one override material for everything (null = use the MTL). */
+pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
+    const float scale[3], int builder, const char* bvhCacheFile);
 void pth_mesh_destroy(pth_mesh* m);
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out);
 int pth_mesh_copy_bvh(const pth_mesh* m, pt_sub_bvh_node* nodes, pt_triangle* triangles, uint32_t* originalTriangle);
+int pth_mesh_copy_geometry(const pth_mesh* m, pt_vertex* vertices, pt_material* materials, uint32_t* numMaterials); /* vertices: num_vertices entries */
 
 pth_scene* pth_scene_create(void);
 void pth_scene_destroy(pth_scene* s);

@@ -90,6 +90,26 @@ pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int b
     return rc == 0 ? (pth_mesh*)h : nullptr;
 }
 
+pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
+    const float scale[3], int builder, const char* bvhCacheFile)
+{
+    MeshHandle* h = nullptr;
+    int rc = guarded([&] {
+        Material m;
+        if (overrideMaterial)
+            static_cast<pt_material&>(m) = *overrideMaterial;
+        Transform t;
+        if (location)
+            t.location = vec3(location[0], location[1], location[2]);
+        if (orientation_wxyz)
+            t.orientation = quat { orientation_wxyz[0], orientation_wxyz[1], orientation_wxyz[2], orientation_wxyz[3] };
+        if (scale)
+            t.scale = vec3(scale[0], scale[1], scale[2]);
+        h = new MeshHandle { Mesh::fromOBJ(path, overrideMaterial ? &m : nullptr, t, (BvhBuilder)builder, bvhCacheFile ? std::string(bvhCacheFile) : std::string()) };
+    });
+    return rc == 0 ? (pth_mesh*)h : nullptr;
+}
+
 void pth_mesh_destroy(pth_mesh* m) { delete (MeshHandle*)m; }
 
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out)
@@ -109,6 +129,20 @@ int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out)
         out->all_triangles_referenced = s.allTrianglesReferenced;
         out->reachable_triangle_refs = s.numTriangleRefs;
         out->reachable_nodes = s.numNodes;
+    });
+}
+
+int pth_mesh_copy_geometry(const pth_mesh* m, pt_vertex* vertices, pt_material* materials, uint32_t* numMaterials)
+{
+    return guarded([&] {
+        const Mesh& mesh = *((const MeshHandle*)m)->mesh;
+        if (vertices)
+            std::memcpy(vertices, mesh.getVertices().data(), mesh.getVertices().size() * sizeof(pt_vertex));
+        if (materials)
+            for (size_t i = 0; i < mesh.getMaterials().size(); i++)
+                materials[i] = mesh.getMaterials()[i];
+        if (numMaterials)
+            *numMaterials = (uint32_t)mesh.getMaterials().size();
     });
 }
 

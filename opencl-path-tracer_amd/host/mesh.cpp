@@ -166,6 +166,179 @@ bool Mesh::loadBvh(const std::string& fileName)
     return true;
 }
 
+
+namespace {
+struct MtlEntry {
+    vec3 kd { 0.6f, 0.6f, 0.6f }; // Assimp's default diffuse colour
+    vec3 ke { 0.0f, 0.0f, 0.0f };
+};
+
+std::map<std::string, MtlEntry> readMtl(const std::string& path)
+{
+    std::map<std::string, MtlEntry> out;
+    std::ifstream in(path);
+    std::string line, cur;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#')
+            continue;
+        if (tag == "newmtl") {
+            ls >> cur;
+            out[cur] = MtlEntry {};
+        } else if (!cur.empty() && (tag == "Kd" || tag == "Ke")) {
+            vec3 c;
+            if (ls >> c.x >> c.y >> c.z)
+                (tag == "Kd" ? out[cur].kd : out[cur].ke) = c;
+        }
+    }
+    return out;
+}
+} // namespace
+
+std::shared_ptr<Mesh> Mesh::fromOBJ(const std::string& path, const Material* overrideMaterial, const Transform& offset, BvhBuilder builder,
+    const std::string& bvhCacheFile)
+{
+    std::ifstream in(path);
+    if (!in)
+        throw std::runtime_error("cannot open " + path);
+    const std::string folder = path.find_last_of("/\\") == std::string::npos ? std::string() : path.substr(0, path.find_last_of("/\\") + 1);
+    std::vector<vec3> P, N;
+    std::vector<float> UV; // 2 per entry
+    std::map<std::string, MtlEntry> mtl;
+    std::vector<Material> materials;
+    std::map<std::string, uint32_t> materialOf;
+    uint32_t curMaterial = 0;
+    bool haveMaterial = false;
+    auto useMaterial = [&](const std::string& name) {
+        if (overrideMaterial) {
+            if (materials.empty())
+                materials.push_back(*overrideMaterial);
+            curMaterial = 0;
+        } else {
+            auto it = materialOf.find(name);
+            if (it == materialOf.end()) {
+                const MtlEntry e = mtl.count(name) ? mtl[name] : MtlEntry {};
+                const bool emissive = e.ke.x != 0.0f || e.ke.y != 0.0f || e.ke.z != 0.0f; // mesh.cpp:58
+                materials.push_back(emissive ? Material::Emissive(e.ke) : Material::Diffuse(e.kd));
+                it = materialOf.emplace(name, (uint32_t)materials.size() - 1).first;
+            }
+            curMaterial = it->second;
+        }
+        haveMaterial = true;
+    };
+    struct Corner {
+        int v, t, n;
+        bool operator<(const Corner& o) const { return std::tie(v, t, n) < std::tie(o.v, o.t, o.n); }
+    };
+    std::map<Corner, uint32_t> welded;
+    std::vector<Corner> corners; // unique corners in first-use order
+    std::vector<uint32_t> indices, materialIndex;
+    bool allNormals = true;
+    std::string line;
+    size_t lineNo = 0;
+    while (std::getline(in, line)) {
+        lineNo++;
+        if (!line.empty() && line.back() == '\r')
+            line.pop_back();
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#')
+            continue;
+        if (tag == "v") {
+            vec3 p;
+            if (!(ls >> p.x >> p.y >> p.z))
+                throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": bad vertex");
+            P.push_back(p);
+        } else if (tag == "vn") {
+            vec3 n;
+            if (!(ls >> n.x >> n.y >> n.z))
+                throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": bad normal");
+            N.push_back(n);
+        } else if (tag == "vt") {
+            float u = 0.0f, v = 0.0f;
+            if (!(ls >> u))
+                throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": bad texture coordinate");
+            ls >> v;
+            UV.push_back(u), UV.push_back(v);
+        } else if (tag == "mtllib") {
+            std::string name;
+            ls >> name;
+            for (auto& kv : readMtl(folder + name))
+                mtl[kv.first] = kv.second;
+        } else if (tag == "usemtl") {
+            std::string name;
+            ls >> name;
+            useMaterial(name);
+        } else if (tag == "f") {
+            if (!haveMaterial)
+                useMaterial(""); // faces before any usemtl: the default material
+            std::vector<uint32_t> poly;
+            std::string tok;
+            while (ls >> tok) {
+                Corner c { 0, 0, 0 };
+                // v, v/t, v//n, v/t/n ; 1-based, negative = relative to the end
+                int* fields[3] = { &c.v, &c.t, &c.n };
+                size_t pos = 0;
+                for (int k = 0; k < 3 && pos <= tok.size(); k++) {
+                    size_t slash = tok.find('/', pos);
+                    std::string part = tok.substr(pos, slash == std::string::npos ? std::string::npos : slash - pos);
+                    if (!part.empty())
+                        *fields[k] = std::stoi(part);
+                    if (slash == std::string::npos)
+                        break;
+                    pos = slash + 1;
+                }
+                auto resolve = [&](int idx, size_t count, const char* what) -> int {
+                    if (idx == 0)
+                        return -1;
+                    const long long r = idx > 0 ? idx - 1 : (long long)count + idx;
+                    if (r < 0 || r >= (long long)count)
+                        throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": " + what + " index out of range");
+                    return (int)r;
+                };
+                c.v = resolve(c.v, P.size(), "vertex");
+                c.t = resolve(c.t, UV.size() / 2, "texture coordinate");
+                c.n = resolve(c.n, N.size(), "normal");
+                if (c.v < 0)
+                    throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": face corner without a vertex");
+                if (c.n < 0)
+                    allNormals = false;
+                auto it = welded.find(c);
+                if (it == welded.end()) {
+                    it = welded.emplace(c, (uint32_t)corners.size()).first;
+                    corners.push_back(c);
+                }
+                poly.push_back(it->second);
+            }
+            for (size_t k = 2; k < poly.size(); k++) { // fan triangulation; points and lines are dropped (mesh.cpp:108-110)
+                indices.push_back(poly[0]), indices.push_back(poly[k - 1]), indices.push_back(poly[k]);
+                materialIndex.push_back(curMaterial);
+            }
+        }
+    }
+    if (indices.empty())
+        throw std::runtime_error(path + ": no faces");
+    const mat4 M = offset.matrix();
+    const mat4 Minv = inverse(M);
+    std::vector<float> positions(corners.size() * 3), normals, uvs(corners.size() * 2, 0.0f);
+    if (allNormals)
+        normals.resize(corners.size() * 3);
+    for (size_t i = 0; i < corners.size(); i++) {
+        const vec3 p = (M * vec4(P[corners[i].v], 1.0f)).xyz();
+        positions[3 * i] = p.x, positions[3 * i + 1] = p.y, positions[3 * i + 2] = p.z;
+        if (allNormals) { // normal matrix = transpose(inverse(M)) (mesh_helpers.cpp:20-23), w = 0
+            const vec3 n = N[corners[i].n];
+            for (int r = 0; r < 3; r++)
+                normals[3 * i + r] = Minv.m[r][0] * n.x + Minv.m[r][1] * n.y + Minv.m[r][2] * n.z;
+        }
+        if (corners[i].t >= 0)
+            uvs[2 * i] = UV[2 * corners[i].t], uvs[2 * i + 1] = UV[2 * corners[i].t + 1];
+    }
+    return std::make_shared<Mesh>(positions.data(), allNormals ? normals.data() : nullptr, uvs.data(), corners.size(), indices.data(),
+        materialIndex.data(), indices.size() / 3, materials, builder, bvhCacheFile);
+}
+
 std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& material, BvhBuilder builder)
 {
     std::ifstream in(path, std::ios::binary);

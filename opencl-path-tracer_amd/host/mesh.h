@@ -5,6 +5,7 @@
 #include "aabb.h"
 #include "bvh_build.h"
 #include "material.h"
+#include "transform.h"
 #include <memory>
 #include <string>
 #include <vector>
@@ -39,6 +40,14 @@ public:
         const std::vector<Material>& materials, BvhBuilder builder = BvhBuilder::SpatialSplit, const std::string& bvhCacheFile = "");
 
     static std::shared_ptr<Mesh> fromPLY(const std::string& path, const Material& material, BvhBuilder builder = BvhBuilder::SpatialSplit);
+    // Wavefront OBJ (+ MTL) the way the reference imports a model file (src/model/mesh.cpp:36-200, Assimp):
+    // polygons are triangulated, points and lines dropped, identical (position, uv, normal) corners welded,
+    // `offset` is baked into the positions and its inverse-transpose into the normals (mesh.cpp:76-82), missing
+    // normals are generated smooth.  Materials: `overrideMaterial` for everything, else per `usemtl` group
+    // Ke != 0 -> Material::Emissive(Ke), otherwise Material::Diffuse(Kd) (mesh.cpp:51-70; a map_Kd texture needs an
+    // image decoder and is ignored: the colour stays Kd).  `bvhCacheFile`: see storeBvh.
+    static std::shared_ptr<Mesh> fromOBJ(const std::string& path, const Material* overrideMaterial = nullptr, const Transform& offset = Transform(),
+        BvhBuilder builder = BvhBuilder::SpatialSplit, const std::string& bvhCacheFile = "");
 
     const std::vector<VertexSceneData>& getVertices() const override { return m_vertices; }
     const std::vector<TriangleSceneData>& getTriangles() const override { return m_bvh.triangles; }

@@ -49,6 +49,9 @@ def lib():
         _lib.pth_mesh_bvh_from_cache.argtypes = [C.c_void_p]
         _lib.pth_mesh_from_ply.restype = C.c_void_p
         _lib.pth_mesh_from_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+        _lib.pth_mesh_from_obj.restype = C.c_void_p
+        _lib.pth_mesh_from_obj.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        _lib.pth_mesh_copy_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         _lib.pth_mesh_destroy.argtypes = [C.c_void_p]
         _lib.pth_mesh_info.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
         _lib.pth_mesh_copy_bvh.argtypes = [C.c_void_p] * 4
@@ -105,6 +108,27 @@ class Mesh:
         if not h:
             _err("pth_mesh_from_ply")
         return Mesh(None, None, None, builder=builder, _handle=h)
+
+    @staticmethod
+    def from_obj(path, material=None, location=None, orientation_wxyz=None, scale=None, builder=BVH_SPATIAL_SPLIT, bvh_cache=None):
+        """Wavefront OBJ (+ MTL) import with the reference's material mapping (src/model/mesh.cpp:36-200)."""
+        mat = None if material is None else np.ascontiguousarray(np.asarray(material, dtype=L.MATERIAL).reshape(1))
+        loc, rot, scl = _f32(location, (3,)), _f32(orientation_wxyz, (4,)), _f32(scale, (3,))
+        h = lib().pth_mesh_from_obj(str(path).encode(), _ptr(mat), _ptr(loc), _ptr(rot), _ptr(scl), builder,
+                                    None if bvh_cache is None else str(bvh_cache).encode())
+        if not h:
+            _err("pth_mesh_from_obj")
+        return Mesh(None, None, None, builder=builder, _handle=h)
+
+    def geometry(self):
+        """(vertices, materials) in the reference's device layouts."""
+        n = C.c_uint32(0)
+        lib().pth_mesh_copy_geometry(self._h, None, None, C.byref(n))
+        verts = np.zeros(self.stats()["num_vertices"], L.VERTEX)
+        mats = np.zeros(n.value, L.MATERIAL)
+        if lib().pth_mesh_copy_geometry(self._h, _ptr(verts), _ptr(mats), C.byref(n)):
+            _err("pth_mesh_copy_geometry")
+        return verts, mats
 
     def store_bvh(self, path):
         """Mesh::storeBvh (reference src/model/mesh.cpp:202-225): the .bvh cache file."""

@@ -156,3 +156,49 @@ def test_bvh_cache_file_is_the_reference_format_and_is_validated(tmp_path):
     pos2, _ = blob(4)  # same topology, other vertices: boxes no longer hold the triangles
     c = H.Mesh(pos2 * 1.7, idx, mats, builder=H.BVH_SPATIAL_SPLIT, bvh_cache=path)
     assert not c.bvh_from_cache
+
+
+def test_obj_import_follows_the_reference_material_and_geometry_rules(tmp_path):
+    """Mesh::loadFromFile / addSubMesh (reference src/model/mesh.cpp:36-200) for Wavefront OBJ: polygons are
+    triangulated, lines dropped, corners welded, Ke != 0 -> Emissive(Ke) else Diffuse(Kd), the offset transform is
+    baked into positions and its inverse-transpose into normals, an override material replaces the MTL."""
+    (tmp_path / "box.mtl").write_text("newmtl red\nKd 0.8 0.1 0.1\nnewmtl lamp\nKd 0 0 0\nKe 2 2 1\n")
+    (tmp_path / "box.obj").write_text(
+        "# unit quad pair with uv + normals, one n-gon, one line element\n"
+        "mtllib box.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nv 1 0 1\nv 1 1 1\nv 0 1 1\nv 0.5 1.5 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "vn 0 0 -1\nvn 0 0 1\n"
+        "usemtl red\n"
+        "f 1/1/1 2/2/1 3/3/1 4/4/1\n"          # quad -> 2 triangles
+        "l 1 2\n"                               # dropped
+        "usemtl lamp\n"
+        "f -5/1/2 -4/2/2 -3/3/2 -1/3/2 -2/4/2\n")  # pentagon with negative indices -> 3 triangles
+    m = H.Mesh.from_obj(tmp_path / "box.obj", builder=H.BVH_BINNED_SAH)
+    st = m.stats()
+    assert st["num_input_triangles"] == 5 and st["num_vertices"] == 9  # 4 + 5 welded corners
+    verts, mats = m.geometry()
+    assert len(mats) == 2
+    assert mats[0]["type"] == L.MAT_DIFFUSE and np.allclose(mats[0]["colour"][:3], (0.8, 0.1, 0.1))
+    assert mats[1]["type"] == L.MAT_EMISSIVE and np.allclose(mats[1]["colour"][:3], np.array((2, 2, 1)) * 500.0)  # Emissive(colour): 500 lm default
+    _, tris, orig = m.bvh()
+    by_input = tris[np.argsort(orig)]
+    assert (by_input["materialIndex"] == [0, 0, 1, 1, 1]).all()
+    front = verts[by_input["indices"][0]]
+    assert np.allclose(front["normal"][:, :3], (0, 0, -1)) and np.allclose(sorted(front["texCoord"][:, 0]), (0, 1, 1))
+    assert np.allclose(verts["vertex"][:, 3], 1.0)
+    # offset transform baked in: scale (2,1,1), rotate 90 deg about y, translate (0,0,5); normals by inverse transpose
+    q = (np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0)
+    t = H.Mesh.from_obj(tmp_path / "box.obj", location=(0, 0, 5), orientation_wxyz=q, scale=(2, 1, 1), builder=H.BVH_BINNED_SAH)
+    tv, _ = t.geometry()
+    src = verts["vertex"][:, :3].astype(np.float64)
+    want = np.stack([src[:, 2], src[:, 1], -2 * src[:, 0] + 5], 1)  # R_y(90): (x,y,z) -> (z, y, -x) after the scale
+    assert np.allclose(tv["vertex"][:, :3], want, atol=1e-5)
+    n = tv["normal"][:, :3] / np.linalg.norm(tv["normal"][:, :3], axis=1, keepdims=True)
+    assert np.allclose(np.abs(n[:4]), (1, 0, 0), atol=1e-5)  # (0,0,-1) -> (-1,0,0)
+    # override material (loadFromFile's optional argument): one material, MTL ignored, emissive list follows it
+    o = H.Mesh.from_obj(tmp_path / "box.obj", material=L.material_pbr_metal((0.9, 0.6, 0.5), 0.8), builder=H.BVH_BINNED_SAH)
+    assert len(o.geometry()[1]) == 1 and (o.bvh()[1]["materialIndex"] == 0).all()
+    with pytest.raises(RuntimeError, match="out of range"):
+        (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+        H.Mesh.from_obj(tmp_path / "bad.obj")
