@@ -69,6 +69,12 @@ int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material
 
 int pth_camera_data(const pth_camera_params* p, pt_camera* out);
 
+/* Radiance .hdr -> one RGBA32F layer of a texture array, as CLTextureArray::loadImage prepares it
+ * (src/opencl/texture.cpp:72-120): rescaled to width x height (Lanczos-3), alpha 1, colours x brightnessMultiplier,
+ * rows bottom-up (FreeImage order).  rgba_out: width*height*4 floats = what pt_upload_texture_array takes. */
+int pth_image_hdr_info(const char* path, uint32_t* width, uint32_t* height);
+int pth_image_load_hdr(const char* path, uint32_t width, uint32_t height, float brightnessMultiplier, float* rgba_out);
+
 #ifdef __cplusplus
 }
 #endif

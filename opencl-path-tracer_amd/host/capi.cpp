@@ -3,6 +3,7 @@
 // arrays that pt_upload_static / pt_upload_dynamic consume.  Declared in include/ptamd_host.h.
 #include "../../include/ptamd_host.h"
 #include "camera.h"
+#include "image.h"
 #include "scene.h"
 #include <cstring>
 #include <exception>
@@ -108,6 +109,22 @@ pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMateria
         h = new MeshHandle { Mesh::fromOBJ(path, overrideMaterial ? &m : nullptr, t, (BvhBuilder)builder, bvhCacheFile ? std::string(bvhCacheFile) : std::string()) };
     });
     return rc == 0 ? (pth_mesh*)h : nullptr;
+}
+
+int pth_image_hdr_info(const char* path, uint32_t* width, uint32_t* height)
+{
+    return guarded([&] {
+        const ImageRGBAF img = loadRadianceHDR(path);
+        *width = img.width, *height = img.height;
+    });
+}
+
+int pth_image_load_hdr(const char* path, uint32_t width, uint32_t height, float brightnessMultiplier, float* rgba_out)
+{
+    return guarded([&] {
+        const ImageRGBAF img = loadSkydomeLayer(path, width, height, brightnessMultiplier);
+        std::memcpy(rgba_out, img.rgba.data(), img.rgba.size() * sizeof(float));
+    });
 }
 
 void pth_mesh_destroy(pth_mesh* m) { delete (MeshHandle*)m; }

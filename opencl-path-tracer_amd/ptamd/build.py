@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(_HERE, ".."))
 HOST_DIR = os.path.join(ROOT, "host")
 CSRC_DIR = os.path.join(ROOT, "csrc")
-HOST_SOURCES = ["bvh_build.cpp", "mesh.cpp", "scene.cpp", "capi.cpp"]
+HOST_SOURCES = ["bvh_build.cpp", "mesh.cpp", "scene.cpp", "image.cpp", "capi.cpp"]
 
 
 def _newer(target, deps):

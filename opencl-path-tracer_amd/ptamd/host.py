@@ -62,6 +62,8 @@ def lib():
         _lib.pth_scene_flatten.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
         _lib.pth_scene_copy.argtypes = [C.c_void_p] * 7
         _lib.pth_camera_data.argtypes = [C.POINTER(CameraParams), C.c_void_p]
+        _lib.pth_image_hdr_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _lib.pth_image_load_hdr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
     return _lib
 
 
@@ -267,3 +269,16 @@ def look_at_quat(eye, target, up=(0, 1, 0)):
         s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
         q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
     return np.asarray(q, np.float32)
+
+
+def load_hdr(path, width=None, height=None, brightness=1.0):
+    """Radiance .hdr -> [1][height][width][4] float32 layer for pt_upload_texture_array (reference
+    CLTextureArray::loadImage, src/opencl/texture.cpp:72-120); size defaults to the file's own."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if lib().pth_image_hdr_info(str(path).encode(), C.byref(w), C.byref(h)):
+        _err("pth_image_hdr_info")
+    width, height = width or w.value, height or h.value
+    out = np.zeros((1, height, width, 4), np.float32)
+    if lib().pth_image_load_hdr(str(path).encode(), width, height, float(brightness), _ptr(out)):
+        _err("pth_image_load_hdr")
+    return out

@@ -202,3 +202,66 @@ def test_obj_import_follows_the_reference_material_and_geometry_rules(tmp_path):
     with pytest.raises(RuntimeError, match="out of range"):
         (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
         H.Mesh.from_obj(tmp_path / "bad.obj")
+
+
+def _write_hdr(path, rgbe, rle, resolution=None):
+    """rgbe: (h, w, 4) uint8, top row first."""
+    h, w, _ = rgbe.shape
+    body = bytearray()
+    for row in rgbe:
+        if not rle:
+            body += row.tobytes()
+            continue
+        body += bytes([2, 2, w >> 8, w & 255])
+        for comp in range(4):
+            data, x = row[:, comp], 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and data[x + run] == data[x]:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, int(data[x])])
+                    x += run
+                else:
+                    lit = min(w - x, 5)
+                    body += bytes([lit]) + data[x:x + lit].tobytes()
+                    x += lit
+    header = b"#?RADIANCE\n# made by the test\nFORMAT=32-bit_rle_rgbe\n\n" + (resolution or f"-Y {h} +X {w}").encode() + b"\n"
+    path.write_bytes(header + bytes(body))
+
+
+def test_radiance_hdr_layers_are_prepared_like_the_reference_texture_array(tmp_path):
+    """CLTextureArray::loadImage (reference src/opencl/texture.cpp:72-120) for .hdr files: RGBE decode (flat and
+    run-length scanlines), RGBA32F with alpha 1, brightness multiplier, rows bottom-up (FreeImage order), rescale
+    to the array's layer size."""
+    rng = np.random.default_rng(11)
+    h, w = 12, 40
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(120, 136, (h, w))
+    rgbe[2, 5:30, :] = rgbe[2, 5, :]  # long runs for the RLE path
+    rgbe[7, :, 3] = 0  # exponent 0 = black
+    want = rgbe[..., :3].astype(np.float64) * np.exp2(rgbe[..., 3:4].astype(np.float64) - 136.0)
+    want[rgbe[..., 3] == 0] = 0
+    for rle in (False, True):
+        f = tmp_path / f"sky_{int(rle)}.hdr"
+        _write_hdr(f, rgbe, rle)
+        got = H.load_hdr(f)
+        assert got.shape == (1, h, w, 4) and (got[..., 3] == 1).all()
+        assert np.allclose(got[0, ::-1, :, :3], want, rtol=1e-6)  # bottom-up rows
+        assert np.allclose(H.load_hdr(f, brightness=2.5)[0, ::-1, :, :3], 2.5 * want, rtol=1e-6)
+    _write_hdr(tmp_path / "flip.hdr", rgbe, True, resolution=f"+Y {h} -X {w}")  # bottom-up, right-to-left file
+    assert np.allclose(H.load_hdr(tmp_path / "flip.hdr")[0, :, ::-1, :3], want, rtol=1e-6)
+    # rescale: a constant picture stays constant, a smooth one keeps its mean, sizes come out as asked
+    const = np.tile(np.array([64, 128, 32, 130], np.uint8), (16, 32, 1))
+    _write_hdr(tmp_path / "const.hdr", const, True)
+    big = H.load_hdr(tmp_path / "const.hdr", 80, 24)
+    assert big.shape == (1, 24, 80, 4) and np.allclose(big[0, ..., :3], np.array([64, 128, 32]) / 64.0, rtol=1e-5)
+    yy, xx = np.mgrid[0:32, 0:64]
+    smooth = np.stack([128 + 100 * np.sin(xx / 10.0), 128 + 100 * np.cos(yy / 6.0), 128 + 0 * xx, 129 + 0 * xx], -1).astype(np.uint8)
+    _write_hdr(tmp_path / "smooth.hdr", smooth, False)
+    full, half = H.load_hdr(tmp_path / "smooth.hdr"), H.load_hdr(tmp_path / "smooth.hdr", 32, 16)
+    assert abs(half[..., :3].mean() - full[..., :3].mean()) < 0.01 * full[..., :3].mean()
+    assert np.abs(half[0, :, :, :3] - full[0, ::2, ::2, :3]).max() < 0.08 * full.max()
+    (tmp_path / "bad.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n\x01\x02")
+    with pytest.raises(RuntimeError, match="truncated"):
+        H.load_hdr(tmp_path / "bad.hdr")
