@@ -1,10 +1,11 @@
 // RayTracer with the reference's public surface (src/raytracer.h:20-30) on top of the HIP C-ABI
 // (include/ptamd.h).  Differences a caller sees: no GL target (the image is fetched with
 // getOutput()/getAccumulator() -- the GPU box is headless), texture arrays are plain float RGBA
-// arrays instead of FreeImage-loaded files.
+// arrays (filled from memory or from Radiance .hdr files, host/image.h) instead of FreeImage-loaded files.
 #pragma once
 #include "../../include/ptamd.h"
 #include "camera.h"
+#include "image.h"
 #include "scene.h"
 #include <memory>
 #include <stdexcept>
@@ -26,6 +27,17 @@ struct TextureArray {
             throw std::invalid_argument("TextureArray: all layers must have the same size");
         rgba.insert(rgba.end(), texels, texels + (size_t)w * h * 4);
         return (int)layers++;
+    }
+    // UniqueTextureArray::add(filePath, isLinear = true, brightnessMultiplier) for Radiance .hdr files
+    // (src/opencl/texture.cpp:18-49,72-120): the first file fixes the layer size unless one was set, later ones
+    // are rescaled to it
+    int add(const std::string& hdrFile, float brightnessMultiplier = 1.0f)
+    {
+        ImageRGBAF img = loadRadianceHDR(hdrFile);
+        if (layers == 0 && width == 0)
+            width = img.width, height = img.height;
+        img = loadSkydomeLayer(hdrFile, width, height, brightnessMultiplier);
+        return add(img.rgba.data(), img.width, img.height);
     }
 };
 
