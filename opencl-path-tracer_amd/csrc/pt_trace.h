@@ -8,22 +8,24 @@
 // level by box-centre distance, scene.cl:141-157): the closest hit does not depend on it, only which
 // of two hits at exactly the same t is reported.
 //
-// How it runs is CDNA4-specific:
-//  * persistent waves: the grid is sized to the machine (blocks/CU x 256 CUs); each 64-lane wave
-//    claims 64 consecutive queue entries with ONE atomicAdd, loads them with coalesced 16 B/lane reads
-//    into registers, and hands them to idle lanes by ballot rank through ds_bpermute; the next packet
-//    is requested as soon as one is used up, so its HBM latency overlaps traversal;
-//  * ONE traversal stack in LDS, laid out [entry][lane] (a wave's push/pop touches 64 consecutive
-//    dwords: conflict-free ds_read/ds_write_b32); top level and bottom level share it, separated by a
-//    sentinel entry that restores the world-space ray; deeper entries spill to a lane-interleaved
-//    region in global memory (never reached by the benchmark scenes);
-//  * the world-space ray of every lane is parked in LDS ([component][lane]) while an instance is being
-//    traversed, which keeps the kernel at 4 waves per SIMD;
-//  * top-level and bottom-level inner nodes have the same 64-byte PairNode layout (both child boxes
-//    in one fetch), so one code path -- and one slot in the majority vote below -- serves both;
-//  * each loop iteration executes the step kind most lanes are waiting for (ballot majority vote)
-//    instead of serialising every kind for a fraction of the lanes;
-//  * slab tests are one FMA per plane (b * 1/d - o/d), reciprocals are v_rcp_f32.
+// How it runs is CDNA4-specific (measurements behind every choice: DESIGN.md section 6):
+//  * persistent waves at 6 waves/SIMD (80 VGPRs, 5.5 KB LDS per wave): the grid is sized to the machine; a wave
+//    claims queue entries in spans of up to 512 with ONE atomicAdd (a device-scope word sustains only ~88
+//    atomics/us) and idle lanes read their ray straight from the queue, consecutive entries for consecutive
+//    idle lanes (ballot rank) -- no staging registers, so the kernel fits 80 VGPRs without spills;
+//  * ONE traversal stack in LDS, laid out [entry][lane] (a wave's push/pop touches 64 consecutive dwords:
+//    conflict-free ds_read/ds_write_b32), 16 entries; top level and bottom level share it, separated by a
+//    sentinel entry that restores the world-space ray (parked in LDS, [component][lane]); deeper entries spill
+//    to a lane-interleaved region in global memory;
+//  * 4-wide nodes with 8-bit quantised child boxes (WideNode, 64 B = four 16-byte loads for four children) at
+//    both levels, so one code path -- and one slot in the vote below -- serves both; entry/exit plane bytes are
+//    picked per ray-direction sign as whole dwords, planes are one packed FMA per pair
+//    (q * (2^e / d) + (origin - o) / d, reciprocal clamped so axis-parallel rays stay NaN-free), the four
+//    (distance, reference) pairs go through a 5-comparator network, pushes are branch-free and the stack top is
+//    prefetched before the node fetch;
+//  * each loop iteration executes the step kind most lanes are waiting for (ballot majority vote: inner step or
+//    leaf) instead of serialising both for a fraction of the lanes; the rare kinds -- enter / leave an instance,
+//    write the result -- park the lane until the hot loop breaks and are served in batches outside it.
 #pragma once
 #include "pt_math.h"
 
@@ -37,29 +39,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_TRACE_MIN_WAVES
 #define PT_TRACE_MIN_WAVES 6
 #endif
-#ifndef PT_VOTE_W_INNER
-#define PT_VOTE_W_INNER 4
-#endif
-#ifndef PT_VOTE_W_LEAF
-#define PT_VOTE_W_LEAF 4
-#endif
-#ifndef PT_VOTE_W_SPECIAL
-#define PT_VOTE_W_SPECIAL 4
-#endif
 #ifndef PT_PARKED_BREAK
 #define PT_PARKED_BREAK 16
 #endif
-#ifndef PT_WORLD_LDS
-#define PT_WORLD_LDS 1 // world-space ray parked in LDS while an instance is traversed (0: re-read from the queue)
-#endif
 #ifndef PT_ANYHIT_SORT
 #define PT_ANYHIT_SORT 0
-#endif
-#ifndef PT_LEAF_ONE
-#define PT_LEAF_ONE 0
-#endif
-#ifndef PT_POOL_DIRECT
-#define PT_POOL_DIRECT 1
 #endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 16
@@ -111,9 +95,7 @@ template <bool ANY_HIT>
 __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
-#if PT_WORLD_LDS
     __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
-#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -167,9 +149,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     };
 
     // ---- per-wave ray packets (see header comment) ---------------------------------------------
-#if !PT_POOL_DIRECT
-    float4 poolO = make_float4(0, 0, 0, 0), poolD = poolO;
-#endif
     uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
     // Claiming queue entries: the first packet of every wave is static (wave w takes entries [64w, 64w+64)),
     // later ones come from ONE shared cursor in spans of up to 512 entries -- a single device-scope word
@@ -194,12 +173,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
-#if !PT_POOL_DIRECT
-        if (lane < poolEnd) {
-            poolO = a.rayO[base + lane];
-            poolD = a.rayD[base + lane];
-        }
-#endif
     };
     requestPacket();
 
@@ -218,7 +191,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const int e = (int)min(poolNext + rank, 63u);
                     float4 ro, rd;
-#if PT_POOL_DIRECT
                     // the packet is only claimed; the lanes that take a ray read it straight from the queue
                     // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
                     ro = rd = make_float4(0, 0, 0, 0);
@@ -226,10 +198,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         ro = a.rayO[poolBase + (uint32_t)e];
                         rd = a.rayD[poolBase + (uint32_t)e];
                     }
-#else
-                    ro.x = __shfl(poolO.x, e), ro.y = __shfl(poolO.y, e), ro.z = __shfl(poolO.z, e), ro.w = __shfl(poolO.w, e);
-                    rd.x = __shfl(poolD.x, e), rd.y = __shfl(poolD.y, e), rd.z = __shfl(poolD.z, e), rd.w = __shfl(poolD.w, e);
-#endif
                     PT_TOC(16, tShfl);
                     PT_TIC(tAssign);
                     if (!active && rank < avail) {
@@ -246,10 +214,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         }
                         if (live) {
                             rayIdx = idx;
-#if PT_WORLD_LDS
                             ldsWorld[wave][0][lane] = ro.x, ldsWorld[wave][1][lane] = ro.y, ldsWorld[wave][2][lane] = ro.z;
                             ldsWorld[wave][3][lane] = rd.x, ldsWorld[wave][4][lane] = rd.y, ldsWorld[wave][5][lane] = rd.z;
-#endif
                             setRay(xyz(ro), xyz(rd));
                             tClosest = tMax;
                             hprim = -1;
@@ -312,12 +278,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 } else {
                     if (what == kSpecialLeaveInstance) {
                         // -------- back to world space ---------------------------------------------------------
-#if PT_WORLD_LDS
                         setRay(mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]),
                             mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]));
-#else
-                        setRay(xyz(a.rayO[rayIdx]), xyz(a.rayD[rayIdx])); // the ray is still in the queue, bit for bit
-#endif
                         curInst = -1;
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     } else {
@@ -369,7 +331,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const int nWork = nInner + nLeaf;
             if (nWork == 0 || nSpecial >= kParkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
-            if (nInner * PT_VOTE_W_INNER >= nLeaf * PT_VOTE_W_LEAF) {
+            if (nInner >= nLeaf) {
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
@@ -477,12 +439,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
                     bool done = false;
-#if PT_LEAF_ONE
-                    const uint32_t nHere = 1u; // one triangle per step: the rest of the leaf goes back into the vote
-#else
-                    const uint32_t nHere = n;
-#endif
-                    for (uint32_t k = 0; k < nHere; k++) {
+                    for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
@@ -514,13 +471,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             a.occluded[rayIdx] = 1u;
                         active = false;
                         cur = kRefFinish;
-                    }
-#if PT_LEAF_ONE
-                    else if (n > 1u) {
-                        cur = makeRef(first + 1u, n - 1u);
-                    }
-#endif
-                    else {
+                    } else {
                         cur = popTop(stackTop);
                         sp = max(sp - 1, 0);
                     }
