@@ -56,6 +56,36 @@ def usable_cores():
     return n
 
 
+def reference_kernels_baseline(O, sc, bundle, width, height, seconds=6.0):
+    """Secondary figure: assets/cl/kernel.cl itself (oracle/_ref, serial NDRange, LFSR113 streams) on a 1/10-scale
+    frame of the same scene and camera.  Its traversal stack is the reference's 32 entries per ray, so it is only
+    run when the scene's trees are shallower than that."""
+    if not O.have_ref():
+        return None
+    flat, depth = bundle.flat, 0
+    for root in {int(r) for r in flat.top_nodes[flat.top_nodes["isLeaf"] != 0]["a"]}:
+        todo = [(root, 1)]
+        while todo:
+            i, dpt = todo.pop()
+            depth = max(depth, dpt)
+            if flat.sub_nodes[i]["count"] == 0:
+                left = int(flat.sub_nodes[i]["left"])
+                todo += [(left, dpt + 1), (left + 1, dpt + 1)]
+    if depth + 8 >= 32:
+        return {"skipped": f"bottom-level BVH depth {depth}: too deep for the reference's 32-entry traversal stack"}
+    w, h = width // 10, height // 10
+    st, streams = O.QueueState(w, h, (w * h + 63) // 64 * 64), O.create_streams((w * h + 63) // 64 * 64, use_ref=True)
+    rays, t_used, spp = 0, 0.0, 0
+    while t_used < seconds:
+        t0 = time.perf_counter()
+        trace, _ = O.trace_rays("ref", sc, bundle.camera, st, streams)
+        t_used += time.perf_counter() - t0
+        rays += int(trace[:, 0].sum())  # numInRays of every pass = extension rays traced (shadow rays not counted)
+        spp += 1
+    return {"value": round(rays / t_used / 1e6, 4), "unit": "M extension rays/s", "cores": 1, "kind": "reference",
+            "sample": f"{spp} spp of a {w}x{h} frame, {rays} extension rays in {t_used:.1f} s, reference kernels -O1, serial"}
+
+
 def cpu_baseline(bundle, seconds, width, height):
     """Oracle (kind 'port') on all host cores: 1 spp over 8x8 pixel blocks spread over the frame,
     extended block by block until `seconds` of wall time are used."""
@@ -84,7 +114,13 @@ def cpu_baseline(bundle, seconds, width, height):
             work[k] += cnt[k]
         pixels_done += len(px)
         chunk = min(chunk * 2, 8192)
+    ref = None
+    try:  # the reference's own kernels, compiled for the host and run one work-item at a time (oracle/_ref): 1 core
+        ref = reference_kernels_baseline(O, sc, bundle, width, height)
+    except Exception as e:  # never let the secondary figure take the bench down
+        ref = {"error": str(e)[:200]}
     return {"value": round(rays / t_used / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "reference_kernels": ref,
             "per_ray": {k: round(work[k] / max(rays, 1), 2) for k in ("innerSteps", "triangleTests", "topVisits")},
             "sample": f"{pixels_done} pixel-samples (random 8x8 blocks of the {width}x{height} frame, 1 spp each pass), "
                       f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
