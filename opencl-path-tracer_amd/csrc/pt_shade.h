@@ -82,10 +82,17 @@ __device__ inline void cameraRay(const CameraDev& cam, int x, int y, float width
 }
 
 // ---- BSDF pieces (pbr_brdf.cl, refract.cl) -------------------------------------------------------
-__device__ inline V3 F_Schlick(V3 f0, float f90, float u) { return f0 + (mk(f90) - f0) * powf(1.0f - u, 5.0f); }
+// pow(x, 5) of pbr_brdf.cl as three multiplications (powf is ~50 instructions of exp2/log2 with special cases)
+__device__ inline float pow5(float x)
+{
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+__device__ inline V3 F_Schlick(V3 f0, float f90, float u) { return f0 + (mk(f90) - f0) * pow5(1.0f - u); }
 __device__ inline float G_SmithBeckmannCorrelated(float VdotM, float NdotV, float alpha)
 {
-    const float a = 1.0f / (alpha * tanf(acosf(NdotV)));
+    // 1 / (alpha * tan(acos(NdotV))) with tan(acos c) = sqrt(1 - c^2) / c: same value and the same signs / infinities
+    const float a = NdotV / (alpha * sqrtf(1.0f - NdotV * NdotV));
     const float chi = a > 0 ? 1.0f : 0.0f;
     float approx = 1.0f;
     if (a < 1.6f)
@@ -110,8 +117,8 @@ __device__ inline float Fr_DisneyDiffuse(float NdotV, float NdotL, float LdotH, 
     const float energyBias = 0.0f + (0.5f - 0.0f) * linearRoughness;
     const float energyFactor = 1.0f + (1.0f / 1.51f - 1.0f) * linearRoughness;
     const float fd90 = energyBias + 2.0f * LdotH * LdotH * linearRoughness;
-    const float lightScatter = 1.0f + (fd90 - 1.0f) * powf(1.0f - NdotL, 5.0f);
-    const float viewScatter = 1.0f + (fd90 - 1.0f) * powf(1.0f - NdotV, 5.0f);
+    const float lightScatter = 1.0f + (fd90 - 1.0f) * pow5(1.0f - NdotL);
+    const float viewScatter = 1.0f + (fd90 - 1.0f) * pow5(1.0f - NdotV);
     return lightScatter * viewScatter * energyFactor;
 }
 
@@ -279,9 +286,10 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         const float r0 = rng.u01();
         const float phi = 2.0f * kPI * r0;
         const float r1 = rng.u01();
-        const float theta = acosf(sqrtf((1.0f - r1) / ((alpha * alpha - 1.0f) * r1 + 1.0f)));
-        const V3 halfway = orient(mk(cosf(phi) * cosf(kPI / 2 - theta), sinf(phi) * cosf(kPI / 2 - theta), sinf(kPI / 2 - theta)),
-            shadingNormal, mk(1.0f, 0.0f, 0.0f), in);
+        // theta = acos(c); the reference then takes cos(pi/2 - theta) = sin(theta) and sin(pi/2 - theta) = cos(theta) = c
+        const float cosTheta = sqrtf((1.0f - r1) / ((alpha * alpha - 1.0f) * r1 + 1.0f));
+        const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+        const V3 halfway = orient(mk(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta), shadingNormal, mk(1.0f, 0.0f, 0.0f), in);
         reflection = normalize(2 * dot(halfway, V) * halfway - V);
         cosineTerm = dot(shadingNormal, reflection);
         if (cosineTerm < 0.05f || dot(realNormal, reflection) < kEPS) {
@@ -328,7 +336,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         const float K = 1 - (n1n2 * n1n2) * (1 - cos1 * cos1);
         if (K > kEPS) {
             const float rand01 = rng.u01();
-            const float f0 = powf((n1 - n2) / (n1 + n2), 2.0f);
+            const float f0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
             const V3 F = F_Schlick(mk(f0), 1.0f, dot(raySideNormal, -D));
             if (rand01 < F.x)
                 reflection = normalize(-D - 2 * dot(-D, raySideNormal) * raySideNormal); // sic (shading.cl:522)
@@ -343,9 +351,10 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         const float alpha = (1.2f - 0.2f * sqrtf(fabsf(dot(D, raySideNormal)))) * (1 - mat.p0);
         const float r0 = rng.u01(), r1 = rng.u01();
         const float phi = 2.0f * kPI * r0;
-        const float theta = atanf(-alpha * alpha * log1pf(-r1));
-        const V3 halfway = orient(mk(cosf(phi) * cosf(kPI / 2 - theta), sinf(phi) * cosf(kPI / 2 - theta), sinf(kPI / 2 - theta)),
-            raySideNormal, mk(1.0f, 0.0f, 0.0f), in);
+        // theta = atan(x): cos(theta) = 1 / sqrt(1 + x^2), sin(theta) = x / sqrt(1 + x^2)
+        const float tanTheta = -alpha * alpha * log1pf(-r1);
+        const float cosTheta = 1.0f / sqrtf(1.0f + tanTheta * tanTheta), sinTheta = tanTheta * cosTheta;
+        const V3 halfway = orient(mk(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta), raySideNormal, mk(1.0f, 0.0f, 0.0f), in);
         V3 absorptionFactor = mk(1.0f);
         float n_i, n_t;
         if (dot(realNormal, -D) > 0.0f) {
@@ -357,7 +366,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
             const V3 e = -mat.colour * t;
             absorptionFactor = mk(expf(e.x), expf(e.y), expf(e.z));
         }
-        const float f0 = powf((n_i - n_t) / (n_i + n_t), 2.0f);
+        const float f0 = ((n_i - n_t) / (n_i + n_t)) * ((n_i - n_t) / (n_i + n_t));
         const V3 F = F_Schlick(mk(f0), 1.0f, dot(-D, halfway));
         const float rand01 = rng.u01();
         const V3 I = -D;
