@@ -135,7 +135,8 @@ typedef struct {
 } pt_config;
 
 #define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */
-#define PT_FLAG_NO_BAKED_INSTANCES 2u /* do not copy single-leaf instances to world space (diagnostics) */
+#define PT_FLAG_NO_BAKED_INSTANCES 2u /* keep every instance two-level: no world-space copies at all (diagnostics) */
+#define PT_FLAG_TWO_LEVEL_ONLY 4u /* copy only single-leaf instances (quads, lights) to world space, not whole meshes */
 
 typedef struct { uint32_t x0, y0, x1, y1; } pt_rect; /* [x0,x1) x [y0,y1) */
 

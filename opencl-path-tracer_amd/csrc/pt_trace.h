@@ -214,6 +214,16 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         }
                         if (live) {
                             rayIdx = idx;
+                            // The reference nudges exactly-zero components of the ray it takes into an instance
+                            // (NO_PARALLEL_RAYS, scene.cl:123-137).  Instances copied to world space are never "entered",
+                            // so the same nudge is applied to the world-space ray: identical for the identity and
+                            // axis-aligned transforms, and the top-level box tests do not notice 1e-38.
+                            if (rd.x == 0.0f) rd.x = FLT_MIN;
+                            if (rd.y == 0.0f) rd.y = FLT_MIN;
+                            if (rd.z == 0.0f) rd.z = FLT_MIN;
+                            if (ro.x == 0.0f) ro.x = -FLT_MIN;
+                            if (ro.y == 0.0f) ro.y = -FLT_MIN;
+                            if (ro.z == 0.0f) ro.z = -FLT_MIN;
                             ldsWorld[wave][0][lane] = ro.x, ldsWorld[wave][1][lane] = ro.y, ldsWorld[wave][2][lane] = ro.z;
                             ldsWorld[wave][3][lane] = rd.x, ldsWorld[wave][4][lane] = rd.y, ldsWorld[wave][5][lane] = rd.z;
                             setRay(xyz(ro), xyz(rd));

@@ -5,6 +5,9 @@
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_trace8.h"
+#ifndef PT_PACK_WIDE
+#define PT_PACK_WIDE 1
+#endif
 #include <algorithm>
 #include <dlfcn.h>
 #include <cmath>
@@ -960,7 +963,12 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
     std::vector<Instance> hInst;
     std::vector<uint32_t> topRef(nTop, kRefNone); // reference of top node i as a child
-    std::vector<TriIsect> baked; // world-space copies of single-leaf instances
+    std::vector<TriIsect> baked; // world-space copies of the triangles of baked instances
+    std::vector<PairNode> bakedNodes; // ... and of their BVH nodes (boxes re-fitted around the transformed child boxes)
+    struct BakeCandidate {
+        uint32_t topNode, inst;
+    };
+    std::vector<BakeCandidate> bakeCandidates;
     c->instanceTopNode.clear();
     uint32_t numTopInner = 0, maxBottomDepth = 0;
     const uint32_t bottomCount = (uint32_t)c->hostBottomNodes.size();
@@ -987,67 +995,170 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             // per ray: its triangles are copied to world space and referenced from the top level as a plain
             // leaf.  (t,u,v) are the same in both spaces (the reference never renormalises the transformed
             // direction, scene.cl:118-121); k_trace maps the copy back to (original triangle, instance).
-            const uint32_t rr = in.rootRef;
-            if (refCount(rr) >= 1u && refCount(rr) <= kMaxLeafTris && !(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES)) {
-                double w[4][8];
-                for (int r = 0; r < 4; r++)
-                    for (int col = 0; col < 4; col++) {
-                        w[r][col] = m[col * 4 + r];
-                        w[r][col + 4] = (r == col) ? 1.0 : 0.0;
-                    }
-                bool singular = false;
-                for (int col = 0; col < 4 && !singular; col++) { // world = inverse(invTransform), Gauss-Jordan
-                    int piv = col;
-                    for (int r = col + 1; r < 4; r++)
-                        if (std::fabs(w[r][col]) > std::fabs(w[piv][col]))
-                            piv = r;
-                    if (std::fabs(w[piv][col]) < 1e-300) {
-                        singular = true;
-                        break;
-                    }
-                    for (int k = 0; k < 8; k++)
-                        std::swap(w[piv][k], w[col][k]);
-                    const double dv = w[col][col];
-                    for (int k = 0; k < 8; k++)
-                        w[col][k] /= dv;
-                    for (int r = 0; r < 4; r++)
-                        if (r != col) {
-                            const double f = w[r][col];
-                            for (int k = 0; k < 8; k++)
-                                w[r][k] -= f * w[col][k];
-                        }
-                }
-                if (!singular) {
-                    const uint32_t first = refIndex(rr), cnt = refCount(rr);
-                    const uint32_t bakedFirst = (uint32_t)(c->hostTris.size() + baked.size());
-                    for (uint32_t k = 0; k < cnt; k++) {
-                        const TriIsect& t = c->hostTris[first + k];
-                        const double v0[3] = { t.a.x, t.a.y, t.a.z }, e1[3] = { t.a.w, t.b.x, t.b.y }, e2[3] = { t.b.z, t.b.w, t.c.x };
-                        float V0[3], E1[3], E2[3];
-                        for (int r = 0; r < 3; r++) {
-                            V0[r] = (float)(w[r][4] * v0[0] + w[r][5] * v0[1] + w[r][6] * v0[2] + w[r][7]);
-                            E1[r] = (float)(w[r][4] * e1[0] + w[r][5] * e1[1] + w[r][6] * e1[2]);
-                            E2[r] = (float)(w[r][4] * e2[0] + w[r][5] * e2[1] + w[r][6] * e2[2]);
-                        }
-                        TriIsect b {};
-                        uint32_t orig = first + k;
-                        float fo, fi;
-                        std::memcpy(&fo, &orig, 4);
-                        std::memcpy(&fi, &instIndex, 4);
-                        b.a = make_float4(V0[0], V0[1], V0[2], E1[0]);
-                        b.b = make_float4(E1[1], E1[2], E2[0], E2[1]);
-                        b.c = make_float4(E2[2], fo, fi, 0.f);
-                        baked.push_back(b);
-                    }
-                    if ((uint64_t)bakedFirst + cnt <= kRefIndexMask)
-                        topRef[i] = makeRef(bakedFirst, cnt);
-                }
-            }
+            if (!(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES))
+                bakeCandidates.push_back({ i, instIndex });
         } else {
             if (n.a >= nTop || n.b >= nTop)
                 return fail(c, PT_ERR_INVALID, "top-level node %u: child out of range", i);
             topRef[i] = makeRef(bottomCount + numTopInner, 0);
             numTopInner++;
+        }
+    }
+    // ---- bake instances into world space -----------------------------------------------------------------
+    // An instance costs every ray that enters it two parked steps (transform in, restore out) on top of the
+    // traversal proper.  With 288 GB of HBM the instanced geometry of scenes like the benchmark's (12 x 82 k
+    // triangles: ~110 MB of nodes and triangles) simply fits as world-space copies, so instances are baked while
+    // a byte budget lasts -- single-leaf meshes (a ground quad, an area light) first, they cost almost nothing --
+    // and the rest stay two-level.  (t,u,v) are the same in both spaces (the reference never renormalises the
+    // transformed direction, scene.cl:118-121); k_trace maps a hit on a copy back to (original triangle,
+    // instance).  Boxes of rotated instances are re-fitted around the transformed corners: looser, still conservative.
+    {
+        const uint64_t budgetBytes = 2ull << 30;
+        uint64_t usedBytes = 0;
+        const uint32_t bakedNodeBase = bottomCount + numTopInner;
+        std::stable_sort(bakeCandidates.begin(), bakeCandidates.end(), [&](const BakeCandidate& a, const BakeCandidate& b) {
+            return (refCount(hInst[a.inst].rootRef) != 0u) > (refCount(hInst[b.inst].rootRef) != 0u); // single leaves first
+        });
+        for (const BakeCandidate& bc : bakeCandidates) {
+            const float* m = topNodes[bc.topNode].invTransform; // column-major
+            double w[4][8];
+            for (int r = 0; r < 4; r++)
+                for (int col = 0; col < 4; col++) {
+                    w[r][col] = m[col * 4 + r];
+                    w[r][col + 4] = (r == col) ? 1.0 : 0.0;
+                }
+            bool singular = false;
+            for (int col = 0; col < 4 && !singular; col++) { // world = inverse(invTransform), Gauss-Jordan
+                int piv = col;
+                for (int r = col + 1; r < 4; r++)
+                    if (std::fabs(w[r][col]) > std::fabs(w[piv][col]))
+                        piv = r;
+                if (std::fabs(w[piv][col]) < 1e-300) {
+                    singular = true;
+                    break;
+                }
+                for (int k = 0; k < 8; k++)
+                    std::swap(w[piv][k], w[col][k]);
+                const double dv = w[col][col];
+                for (int k = 0; k < 8; k++)
+                    w[col][k] /= dv;
+                for (int r = 0; r < 4; r++)
+                    if (r != col) {
+                        const double f = w[r][col];
+                        for (int k = 0; k < 8; k++)
+                            w[r][k] -= f * w[col][k];
+                    }
+            }
+            if (singular)
+                continue;
+            const uint32_t instIndex = bc.inst;
+            auto bakeTriangles = [&](uint32_t first, uint32_t cnt) -> uint32_t { // returns the reference of the copies
+                const uint32_t bakedFirst = (uint32_t)(c->hostTris.size() + baked.size());
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const TriIsect& t = c->hostTris[first + k];
+                    const double v0[3] = { t.a.x, t.a.y, t.a.z }, e1[3] = { t.a.w, t.b.x, t.b.y }, e2[3] = { t.b.z, t.b.w, t.c.x };
+                    float V0[3], E1[3], E2[3];
+                    for (int r = 0; r < 3; r++) {
+                        V0[r] = (float)(w[r][4] * v0[0] + w[r][5] * v0[1] + w[r][6] * v0[2] + w[r][7]);
+                        E1[r] = (float)(w[r][4] * e1[0] + w[r][5] * e1[1] + w[r][6] * e1[2]);
+                        E2[r] = (float)(w[r][4] * e2[0] + w[r][5] * e2[1] + w[r][6] * e2[2]);
+                    }
+                    TriIsect b {};
+                    uint32_t orig = first + k;
+                    float fo, fi;
+                    std::memcpy(&fo, &orig, 4);
+                    std::memcpy(&fi, &instIndex, 4);
+                    b.a = make_float4(V0[0], V0[1], V0[2], E1[0]);
+                    b.b = make_float4(E1[1], E1[2], E2[0], E2[1]);
+                    b.c = make_float4(E2[2], fo, fi, 0.f);
+                    baked.push_back(b);
+                }
+                return makeRef(bakedFirst, cnt);
+            };
+            const uint32_t rr = hInst[instIndex].rootRef;
+            if (refCount(rr) >= 1u && refCount(rr) <= kMaxLeafTris) { // the mesh is one leaf
+                if ((uint64_t)c->hostTris.size() + baked.size() + refCount(rr) < kRefIndexMask - 4u)
+                    topRef[bc.topNode] = bakeTriangles(refIndex(rr), refCount(rr));
+                continue;
+            }
+            // parity mode follows the reference to the letter: instances are entered, not copied
+            if (refCount(rr) != 0u || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))
+                continue;
+            // whole subtree: size it first
+            uint64_t nNodes = 0, nTris = 0;
+            {
+                std::vector<uint32_t> todo { refIndex(rr) };
+                while (!todo.empty()) {
+                    const PairNode& pn = c->hostBottomNodes[todo.back()];
+                    todo.pop_back();
+                    nNodes++;
+                    for (uint32_t r : { pn.left, pn.right }) {
+                        if (r == kRefNone)
+                            continue;
+                        if (refCount(r) == 0u)
+                            todo.push_back(refIndex(r));
+                        else
+                            nTris += refCount(r);
+                    }
+                }
+            }
+            const uint64_t bytes = nNodes * (sizeof(PairNode) + sizeof(WideNode)) + nTris * sizeof(TriIsect);
+            if (usedBytes + bytes > budgetBytes || bakedNodeBase + bakedNodes.size() + nNodes >= kRefIndexMask - 4u
+                || c->hostTris.size() + baked.size() + nTris >= kRefIndexMask - 4u)
+                continue;
+            usedBytes += bytes;
+            // copy the subtree, parents before children (the collapse and the packing only follow references)
+            struct Item {
+                uint32_t src, dst;
+            };
+            const uint32_t rootDst = (uint32_t)bakedNodes.size();
+            bakedNodes.emplace_back();
+            std::vector<Item> todo { { refIndex(rr), rootDst } };
+            while (!todo.empty()) {
+                const Item it = todo.back();
+                todo.pop_back();
+                const PairNode& src = c->hostBottomNodes[it.src];
+                PairNode dst {};
+                const float* bx = &src.bx.x;
+                const float* by = &src.by.x;
+                const float* bz = &src.bz.x;
+                float* ox = &dst.bx.x;
+                float* oy = &dst.by.x;
+                float* oz = &dst.bz.x;
+                for (int side = 0; side < 2; side++) {
+                    const uint32_t r = side ? src.right : src.left;
+                    uint32_t& outRef = side ? dst.right : dst.left;
+                    outRef = kRefNone;
+                    ox[side * 2] = oy[side * 2] = oz[side * 2] = 1.f; // empty (inverted) box
+                    ox[side * 2 + 1] = oy[side * 2 + 1] = oz[side * 2 + 1] = -1.f;
+                    if (r == kRefNone || bx[side * 2] > bx[side * 2 + 1])
+                        continue;
+                    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+                    for (int corner = 0; corner < 8; corner++) {
+                        const double p[3] = { bx[side * 2 + (corner & 1)], by[side * 2 + ((corner >> 1) & 1)], bz[side * 2 + ((corner >> 2) & 1)] };
+                        for (int a = 0; a < 3; a++) {
+                            const double q = w[a][4] * p[0] + w[a][5] * p[1] + w[a][6] * p[2] + w[a][7];
+                            lo[a] = std::min(lo[a], q), hi[a] = std::max(hi[a], q);
+                        }
+                    }
+                    // to float, outwards, plus an ulp for the rounding of the transformed triangles themselves
+                    float* o[3] = { ox, oy, oz };
+                    for (int a = 0; a < 3; a++) {
+                        o[a][side * 2] = std::nextafter(std::nextafter((float)lo[a], -INFINITY), -INFINITY);
+                        o[a][side * 2 + 1] = std::nextafter(std::nextafter((float)hi[a], INFINITY), INFINITY);
+                    }
+                    if (refCount(r) == 0u) {
+                        const uint32_t childDst = (uint32_t)bakedNodes.size();
+                        bakedNodes.emplace_back();
+                        outRef = makeRef(bakedNodeBase + childDst, 0u);
+                        todo.push_back({ refIndex(r), childDst });
+                    } else {
+                        outRef = bakeTriangles(refIndex(r), refCount(r));
+                    }
+                }
+                bakedNodes[it.dst] = dst;
+            }
+            topRef[bc.topNode] = makeRef(bakedNodeBase + rootDst, 0u);
         }
     }
     uint32_t topDepth = 0;
@@ -1069,10 +1180,11 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     // one pending entry per level of either tree + the leave-instance sentinel
     if (topDepth + 1 + maxBottomDepth > (uint32_t)(kLdsStack + kSpillStack))
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kLdsStack + kSpillStack);
-    if ((uint64_t)bottomCount + numTopInner > kRefIndexMask)
+    if ((uint64_t)bottomCount + numTopInner + bakedNodes.size() > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
     std::vector<PairNode> hNodes = c->hostBottomNodes;
     hNodes.resize(bottomCount + numTopInner);
+    hNodes.insert(hNodes.end(), bakedNodes.begin(), bakedNodes.end());
     for (uint32_t i = 0; i < nTop; i++) {
         const pt_top_bvh_node& n = topNodes[i];
         if (n.isLeaf)
@@ -1139,10 +1251,46 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         c->scene.root8 = w8.topRoot;
     }
 #endif
-    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, hWide)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    // ---- pack the 4-wide nodes: only the ones the collapse kept (about half of the pair-node indices), each node's
+    // children next to each other, level by level from every root -- half the footprint in the 4 MB-per-XCD L2 and
+    // sibling nodes share 128-byte lines
+    uint32_t packedRoot = topRef[topRoot];
+    std::vector<WideNode> packed;
+#if PT_PACK_WIDE
+    {
+        constexpr uint32_t kUnset = 0xFFFFFFFFu;
+        std::vector<uint32_t> newIndex(hWide.size(), kUnset), order;
+        auto isInner = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < hWide.size(); };
+        auto visit = [&](uint32_t ref) {
+            if (isInner(ref) && newIndex[refIndex(ref)] == kUnset) {
+                newIndex[refIndex(ref)] = (uint32_t)order.size();
+                order.push_back(refIndex(ref));
+            }
+        };
+        visit(packedRoot);
+        for (const Instance& in : hInst)
+            visit(in.rootRef);
+        for (size_t q = 0; q < order.size(); q++) // breadth first: the four children of a node get consecutive slots
+            for (uint32_t r : hWide[order[q]].child)
+                visit(r);
+        auto remap = [&](uint32_t r) { return isInner(r) ? makeRef(newIndex[refIndex(r)], 0u) : r; };
+        packed.resize(order.size());
+        for (size_t q = 0; q < order.size(); q++) {
+            packed[q] = hWide[order[q]];
+            for (uint32_t& r : packed[q].child)
+                r = remap(r);
+        }
+        for (Instance& in : hInst)
+            in.rootRef = remap(in.rootRef);
+        packedRoot = remap(packedRoot);
+    }
+#else
+    packed = hWide;
+#endif
+    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
-    c->scene.rootRef = topRef[topRoot];
+    c->scene.rootRef = packedRoot;
     c->haveDynamic = true;
     refreshSceneView(c);
     return PT_OK;

@@ -10,6 +10,8 @@ DEVICE_LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "..", "csrc
 
 RNG_COUNTER, RNG_LFSR113_PARITY = 0, 1
 FLAG_ROWMAJOR_PIXELS = 1
+FLAG_NO_BAKED_INSTANCES = 2  # every instance stays two-level
+FLAG_TWO_LEVEL_ONLY = 4  # only single-leaf instances are copied to world space
 
 
 class Config(C.Structure):

@@ -38,11 +38,22 @@ def tri_vertex_ids(flat, prim):
     return np.sort(flat.triangles["indices"][prim], axis=1)
 
 
-def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2):
+def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0):
     """hit/miss identical; t/u/v within tolerance; (prim, inst) identical except where two primitives are
-    hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t."""
+    hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t.
+    `edge_flip_frac` > 0 (world-space copies of instances: triangle edges are rounded in another space than the
+    reference's) tolerates that fraction of hit/miss disagreements, each of which must graze a triangle edge."""
     gh, wh = got["prim"] >= 0, want["prim"] >= 0
     flips = gh != wh
+    edge_flips = 0
+    if edge_flip_frac > 0 and flips.any():
+        for k in np.flatnonzero(flips):
+            h = got if gh[k] else want
+            u, v = float(h["u"][k]), float(h["v"][k])
+            assert min(abs(u), abs(v), abs(1.0 - u - v)) < 2e-4, f"ray {k}: hit/miss differs away from any edge (u={u}, v={v})"
+        edge_flips = int(flips.sum())
+        assert flips.mean() <= edge_flip_frac, f"{edge_flips} edge-grazing rays flip"
+        flips = np.zeros_like(flips)
     assert flips.mean() <= 1e-4, f"hit/miss differs for {flips.sum()} rays"
     both = gh & wh
     assert np.allclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=1e-6)
@@ -65,7 +76,7 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2):
     assert np.abs(point(got) - point(want)).max() < 2e-4 * max(extent, 1.0)
     assert np.allclose(got["u"][both][same], want["u"][both][same], atol=5e-3)
     assert np.allclose(got["v"][both][same], want["v"][both][same], atol=5e-3)
-    return dict(flips=int(flips.sum()), ties=int((~same).sum()), n=int(both.sum()))
+    return dict(flips=int(flips.sum()), ties=int((~same).sum()), n=int(both.sum()), edge_flips=edge_flips)
 
 
 def tonemap(accum_rgb, spp, camera):

@@ -12,36 +12,42 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("two_level", [True, False])
 @pytest.mark.parametrize("name", ["mixed", "inst"])
-def test_golden_closest_and_any_hit(gpu, golden, name):
+def test_golden_closest_and_any_hit(gpu, golden, name, two_level):
+    """two_level: instances are entered like the reference does (ray transformed into instance space) -> hit/miss
+    identical to the reference kernels.  Default: instances baked to world space while the byte budget lasts; a
+    triangle edge is then rounded in world space, so a ray within round-off of an edge may change sides -- at most
+    5e-4 of the rays, each verified to graze an edge."""
     flat, cam, sky, tex = golden_io.scene_inputs(golden, name)
-    ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex)
+    ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex, flags=gpu.FLAG_TWO_LEVEL_ONLY if two_level else 0)
     o, d = golden[f"isect_{name}_o"], golden[f"isect_{name}_d"]
     got = ctx.intersect(o, d)
     want = dict(t=golden[f"isect_{name}_t"], u=golden[f"isect_{name}_uv"][:, 0], v=golden[f"isect_{name}_uv"][:, 1],
                 prim=golden[f"isect_{name}_prim"], inst=golden[f"isect_{name}_inst"])
-    info = U.compare_hits(flat, got, want)
+    info = U.compare_hits(flat, got, want, edge_flip_frac=0.0 if two_level else 5e-4)
     assert info["flips"] == 0
     occ = ctx.intersect(o, d, tmax=golden[f"shadow_{name}_len"], any_hit=True)["prim"]
     g = golden[f"shadow_{name}_occluded"]
     # segments cut 0.1 % before / after the first hit are decided by the same fp32 t on both sides
-    assert (occ != g).sum() <= 2, f"{(occ != g).sum()} occlusion verdicts differ"
+    assert (occ != g).sum() <= (2 if two_level else 2 + info["edge_flips"]), f"{(occ != g).sum()} occlusion verdicts differ"
     ctx.close()
 
 
 @pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
-def test_random_rays_two_level(gpu, builder):
+@pytest.mark.parametrize("two_level", [True, False])
+def test_random_rays_two_level(gpu, builder, two_level):
     b = scenes.instanced_grid(64, 36, level=4, builder=builder, sky_size=(16, 8))
-    ctx = U.make_ctx(gpu, b, 64, 36)
+    ctx = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_TWO_LEVEL_ONLY if two_level else 0)
     sc = U.oracle_scene(b)
     o, d = U.random_rays(60000, 5, (-4, 0.05, -4), (4, 3, 4))
     got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
-    info = U.compare_hits(b.flat, got, want)
+    info = U.compare_hits(b.flat, got, want, edge_flip_frac=0.0 if two_level else 5e-4)
     assert info["n"] > 10000 and info["flips"] == 0
     tmax = np.random.default_rng(1).uniform(0.05, 4, len(o)).astype(np.float32)
     occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
     ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
-    assert (occ != ref).sum() <= 3
+    assert (occ != ref).sum() <= 3 + info["edge_flips"]
     ctx.close()
 
 
