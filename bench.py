@@ -5,13 +5,12 @@
 A *step* is one pass of the hot path over one batch: `128*N*R` samples per pixel for the pixels this rank
 owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~265 M path
 segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
-large batches matter (16 / 32 / 64 / 128 samples in flight: 4.36 / 4.67 / 4.90 / 5.04 Grays/s); 128 in flight
-keep ~48 GB of queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles
-(32x32, interleaved) shard across ranks, every rank
-traces the same number of paths per step whatever N is (weak scaling: the image simply receives N x
-more samples per step), and there is no data-path collective: the only exchange is ONE RCCL reduce of
-the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the timed
-region.  A ray = one traceRay invocation on a live queue entry (extension or shadow), counted by the
+large batches matter (16 / 32 / 64 / 128 samples in flight differ by ~15 %); 128 in flight keep ~48 GB of
+queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
+shard across ranks, every rank traces the same number of paths per step whatever N is (weak scaling: the image
+simply receives N x more samples per step), and there is no data-path collective: the only exchange is ONE
+RCCL reduce of the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the
+timed region.  A ray = one traceRay invocation on a live queue entry (extension or shadow), counted by the
 device queues.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live for the dominant kernel (k_trace<false>,

@@ -25,7 +25,9 @@
 //    prefetched before the node fetch;
 //  * each loop iteration executes the step kind most lanes are waiting for (ballot majority vote: inner step or
 //    leaf) instead of serialising both for a fraction of the lanes; the rare kinds -- enter / leave an instance,
-//    write the result -- park the lane until the hot loop breaks and are served in batches outside it.
+//    write the result -- park the lane until the hot loop breaks and are served in batches outside it.  (Most
+//    scenes never enter an instance: ptamd.hip copies instances to world space at upload while a byte budget
+//    lasts, which removed two parked steps per instance visit.)
 #pragma once
 #include "pt_math.h"
 
