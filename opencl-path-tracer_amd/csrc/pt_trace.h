@@ -9,7 +9,7 @@
 // of two hits at exactly the same t is reported.
 //
 // How it runs is CDNA4-specific (measurements behind every choice: DESIGN.md section 6):
-//  * persistent waves at 6 waves/SIMD (80 VGPRs, 5.5 KB LDS per wave): the grid is sized to the machine; a wave
+//  * persistent waves at 7 waves/SIMD (72 VGPRs, 5.5 KB LDS per wave): the grid is sized to the machine; a wave
 //    claims queue entries in spans of up to 512 with ONE atomicAdd (a device-scope word sustains only ~88
 //    atomics/us) and idle lanes read their ray straight from the queue, consecutive entries for consecutive
 //    idle lanes (ballot rank) -- no staging registers, so the kernel fits 80 VGPRs without spills;
@@ -39,7 +39,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_REFILL_IDLE 16
 #endif
 #ifndef PT_TRACE_MIN_WAVES
-#define PT_TRACE_MIN_WAVES 6
+#define PT_TRACE_MIN_WAVES 7
 #endif
 #ifndef PT_PARKED_BREAK
 #define PT_PARKED_BREAK 16
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
-    uint32_t* const spill = a.spill + gtid; // entry e at spill[e * totalThreads]
+#define spill (a.spill + gtid) /* entry e at spill[e * totalThreads]; recomputed where used (rare) to save two registers */
     const uint32_t total = a.totalThreads;
     const uint32_t count = *a.count;
     const SceneDev& sc = a.sc;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     bool exhausted = false; // wave-uniform: queue has no more rays
     uint32_t rayIdx = 0;
     // ray of the space being traversed (world or instance): origin, direction, 1/direction, -origin/direction
-    V3 co = mk(0.f), cd = mk(0.f), cid = mk(0.f), coid = mk(0.f);
+    V3 co = mk(0.f), cd = mk(0.f), cid = mk(0.f);
     float tClosest = 0.f, hu = 0.f, hv = 0.f;
     int hprim = -1, hinst = -1, curInst = -1;
     uint32_t cur = kRefFinish;
@@ -147,7 +147,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         co = o;
         cd = d;
         cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
-        coid = mk(-o.x * cid.x, -o.y * cid.y, -o.z * cid.z);
     };
 
     // ---- per-wave ray packets (see header comment) ---------------------------------------------
@@ -367,7 +366,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
                     const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
                                 az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
-                    const float bx = fmaf(asF(A.x), cid.x, coid.x), by = fmaf(asF(A.y), cid.y, coid.y), bz = fmaf(asF(A.z), cid.z, coid.z);
+                    // (origin - o) / d from the live registers: keeping -o/d around as well would cost three VGPRs, and 72 is
+                    // what 7 waves per SIMD allow
+                    const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
                     // entry / exit planes chosen by the sign of the ray direction (whole dwords: 4 children at once)
                     // instead of min/max per plane pair; an empty slot is an inverted box (q 255..0) and can never
                     // satisfy exit >= entry -- and if round-off ever made it, its reference is a degenerate triangle
@@ -499,5 +500,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             atomicAdd(&g_traceStats[i + (ANY_HIT ? 24 : 0)], statAcc[i]);
 #endif
 }
+
+#undef spill
 
 } // namespace ptd

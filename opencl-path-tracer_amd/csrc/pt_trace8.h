@@ -28,6 +28,9 @@ namespace ptd {
 #ifndef PT_BVH8
 #define PT_BVH8 0 // bit 0: closest-hit launches use the 8-wide tree, bit 1: any-hit launches (0: 4-wide k_trace, the default)
 #endif
+#ifndef PT_TRACE8_MIN_WAVES
+#define PT_TRACE8_MIN_WAVES 5 // 95 VGPRs without spills
+#endif
 #ifndef PT_LDS_STACK8
 #define PT_LDS_STACK8 10
 #endif
@@ -36,7 +39,7 @@ constexpr int kSpillStack8 = kSpillStack / 2; // further groups in global memory
 constexpr uint32_t kGroupFinish = 0xFFFFFFFEu;
 
 template <bool ANY_HIT>
-__global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace8(TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock, PT_TRACE8_MIN_WAVES) k_trace8(TraceArgs a)
 {
     __shared__ uint2 ldsStack[kTraceBlock / 64][kLdsStack8][64];
     __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
