@@ -47,6 +47,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_ANYHIT_SORT
 #define PT_ANYHIT_SORT 0
 #endif
+#ifndef PT_VOTE_INNER
+#define PT_VOTE_INNER 2 // an inner step runs when 2 * (lanes wanting one) >= 3 * (lanes wanting a leaf): leaf steps are the
+#define PT_VOTE_LEAF 3 // long ones (sequential triangle fetches), so they are not left waiting for a majority
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 16
 #endif
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const int nWork = nInner + nLeaf;
             if (nWork == 0 || nSpecial >= kParkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
-            if (nInner >= nLeaf) {
+            if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
