@@ -99,7 +99,7 @@ struct Texture {
 
 struct Node8;
 struct SceneDev {
-    const PairNode* nodes; // the reference's binary tree, both boxes per node (kept for diagnostics)
+    const PairNode* nodes; // the reference's binary tree, both boxes per node: host-side intermediate, not uploaded (null)
     const WideNode* wide; // 4-wide tree (k_trace)
     const Node8* nodes8; // 8-wide compressed tree (k_trace8), its triangles in node order and its top-level items
     const TriIsect* tris8;

@@ -1287,7 +1287,7 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
 #else
     packed = hWide;
 #endif
-    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->nodes, hNodes)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
     c->scene.rootRef = packedRoot;
