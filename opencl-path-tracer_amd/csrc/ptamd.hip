@@ -399,7 +399,9 @@ int ensureQueues(pt_ctx* c)
     if (c->planes > 1) {
         const size_t n = (size_t)(c->planes - 1) * c->cfg.width * c->cfg.height;
         HIPCHK(c, c->accumPlanes.alloc(n));
-        HIPCHK(c, hipMemset(c->accumPlanes.p, 0, n * sizeof(float4)));
+        // stream-ordered: the context's stream is non-blocking, a null-stream memset could still be running (or not
+        // have started) when the first kernels of the render write these buffers
+        HIPCHK(c, hipMemsetAsync(c->accumPlanes.p, 0, n * sizeof(float4), c->stream));
     }
     c->capacity = cap;
     for (int k = 0; k < 2; k++) {
@@ -425,7 +427,7 @@ int ensureQueues(pt_ctx* c)
             return rc;
     }
     HIPCHK(c, c->control.alloc(1));
-    HIPCHK(c, hipMemset(c->control.p, 0, sizeof(Control)));
+    HIPCHK(c, hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
     c->queuesReady = true;
     return PT_OK;
 }
@@ -738,10 +740,10 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     c->ownStream = true;
     if ((e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess)
         return bail(e, "hipEventCreate");
-    if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemset(c->totals.p, 0, sizeof(Totals))) != hipSuccess)
+    if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream)) != hipSuccess)
         return bail(e, "alloc totals");
     if ((e = c->accumOwn.alloc((size_t)cfg->width * cfg->height)) != hipSuccess
-        || (e = hipMemset(c->accumOwn.p, 0, (size_t)cfg->width * cfg->height * sizeof(float4))) != hipSuccess)
+        || (e = hipMemsetAsync(c->accumOwn.p, 0, (size_t)cfg->width * cfg->height * sizeof(float4), c->stream)) != hipSuccess)
         return bail(e, "alloc accumulator");
     c->accum = c->accumOwn.p;
     c->numOwned = cfg->width * cfg->height;
@@ -1598,7 +1600,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         chk(hipMemcpy(dO.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         chk(hipMemcpy(dD.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         chk(hipMemcpy(dC.p, hC.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        chk(hipMemset(dAcc.p, 0, sizeof(float4)));
+        chk(hipMemsetAsync(dAcc.p, 0, sizeof(float4), c->stream));
     }
     float msTotal = 0;
     repeat = std::max(repeat, 1u);

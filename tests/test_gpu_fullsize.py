@@ -44,3 +44,39 @@ def test_full_size_properties(gpu, bundle):
     assert abs(got.mean() - want.mean()) / want.mean() < 2e-3
     close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
     assert close.mean() > 0.97, close.mean()
+
+
+def test_config5_4k_thin_lens_properties(gpu):
+    """BASELINE.json config 5 (same scene at 3840x2160, thin lens f/2 focused on the grid centre): ray-count
+    conservation, tile sharding over 8 ranks' worth of tile lists == the whole frame, sampled pixels against the
+    oracle path by path (the thin lens leaves primary directions un-normalised)."""
+    W4, H4 = 3840, 2160
+    b = scenes.instanced_grid(W4, H4, level=6, thin_lens=True)
+    assert b.camera["thinLensEnabled"]
+    ctx = U.make_ctx(gpu, b, W4, H4, seed=3)
+    ctx.render(2)
+    st = ctx.stats()
+    assert st["rays_generated"] == W4 * H4 * 2
+    assert st["rays_generated"] <= st["rays_extension"] <= 4 * st["rays_generated"]
+    whole = ctx.read_accum()[:, :3]
+    assert np.isfinite(whole).all() and whole.min() >= 0 and whole.mean() > 0
+    ctx.close()
+    # two of eight interleaved tile sets, each on its own context, land exactly on the whole-frame values
+    import bench
+    for rank in (0, 5):
+        part = U.make_ctx(gpu, b, W4, H4, seed=3)
+        rects = bench.tile_rects(W4, H4, rank, 8)
+        part.set_tiles(rects)
+        part.render(2)
+        a = part.read_accum()[:, :3].reshape(H4, W4, 3)
+        mask = np.zeros((H4, W4), bool)
+        for x0, y0, x1, y1 in rects:
+            mask[y0:y1, x0:x1] = True
+        assert np.array_equal(a[mask], whole.reshape(H4, W4, 3)[mask]) and not a[~mask].any()
+        part.close()
+    px = np.random.default_rng(1).choice(W4 * H4, 4000, replace=False).astype(np.uint32)
+    ref, _ = O.render(U.oracle_scene(b), b.camera, W4, H4, 2, seed=3, pixels=px, threads=8)
+    got, want = whole[px], ref[px, :3]
+    assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
+    close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
+    assert close.mean() > 0.97, close.mean()
