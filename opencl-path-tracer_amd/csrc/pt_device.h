@@ -24,8 +24,9 @@ struct PairNode {
     uint32_t _pad0, _pad1;
 };
 
-// 4-wide node with 8-bit quantised child boxes (64 B), built at upload by collapsing every second level
-// of the pair-node tree (children of node i = its grandchildren where a child is an inner node).
+// 4-wide node with 8-bit quantised child boxes (64 B), built at upload by collapsing the pair-node tree: the two
+// children of a pair node, then -- surface-area greedy -- the largest inner child is replaced by its own two
+// children until four are collected (ptamd.hip, collapseToWide).
 // Child box k = origin + 2^exp * q (per axis), q in [0,255], rounded outwards: a superset of the exact
 // box, so traversal visits at worst a few extra nodes and finds exactly the same triangles.  One step
 // now needs four 16-byte loads for four children instead of eight for the same two levels.
@@ -34,7 +35,7 @@ struct WideNode {
     uint32_t exps; // biased float exponents of the per-axis scale: ex | ey << 8 | ez << 16
     uint32_t qlox, qhix, qloy, qhiy; // byte k of each word belongs to child k
     uint32_t qloz, qhiz, _pad0, _pad1;
-    uint32_t child[4]; // references (kRefNone = empty slot)
+    uint32_t child[4]; // references; an unused slot has an inverted box and refers to an all-zero triangle
 };
 
 // child reference: kind/count (5 bits) | index (27 bits).

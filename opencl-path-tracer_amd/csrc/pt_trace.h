@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
                         *ap = px;
                     } else {
-                        if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of a single-leaf instance: map it back
+                        if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of an instance: back to (original triangle, instance)
                             const float4 tc = sc.tris[hprim].c;
                             hprim = (int)asU(tc.y);
                             hinst = (int)asU(tc.z);
