@@ -204,3 +204,38 @@ def test_reduce_accum_through_rccl_single_rank(gpu):
     rccl.ncclCommDestroy(comm)
     ctx.close()
     own.close()
+
+
+@pytest.mark.parametrize("two_level", [False, True])
+def test_dynamic_scene_reupload_matches_a_fresh_context(gpu, two_level):
+    """RayTracer::frameTick (reference src/raytracer.cpp:183-189,497-595): after scene-graph transforms change
+    only the dynamic part -- world-space lights, top-level BVH, and here the world-space copies of the
+    instances -- is rebuilt and uploaded.  The render must equal one from a context that never saw the old
+    transforms (counter PRNG: bit for bit)."""
+    flags = gpu.FLAG_TWO_LEVEL_ONLY if two_level else 0
+    b = scenes.instanced_grid(96, 54, nx=2, nz=2, level=3, sky_size=(16, 8))
+    ctx = U.make_ctx(gpu, b, 96, 54, seed=5, flags=flags)
+    ctx.render(4)
+    before = ctx.read_accum().copy()
+    # move and rescale one blob, rotate another about y (scene nodes 0/1 are the ground and the light)
+    b.scene.set_transform(2, location=(-1.1, 1.4, -0.3), scale=(0.7, 0.7, 0.7))
+    q = (np.cos(0.4), 0.0, np.sin(0.4), 0.0)
+    b.scene.set_transform(3, orientation_wxyz=q)
+    moved = b.scene.flatten()
+    ctx.upload_dynamic(moved)
+    ctx.clear()
+    ctx.render(4)
+    after = ctx.read_accum()
+    assert not np.array_equal(before, after)
+    fresh = gpu.Context(96, 54, seed=5, flags=flags)
+    fresh.upload_scene(moved, sky=b.sky)
+    fresh.set_camera(b.camera)
+    fresh.render(4)
+    assert np.array_equal(after, fresh.read_accum())
+    # and the re-uploaded geometry (one instance rotated: its boxes are re-fitted when copied) is where the oracle says
+    o, d = U.random_rays(30000, 9, (-3, 0.05, -3), (3, 3, 3))
+    info = U.compare_hits(moved, ctx.intersect(o, d), O.intersect_batch(O.BoundScene(moved), o, d, threads=8),
+                          edge_flip_frac=0.0 if two_level else 5e-4)
+    assert info["n"] > 3000 and info["flips"] == 0
+    ctx.close()
+    fresh.close()
