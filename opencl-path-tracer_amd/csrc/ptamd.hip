@@ -301,6 +301,37 @@ std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t
     return wide;
 }
 
+// world = inverse(invTransform) by Gauss-Jordan in double; m is column-major (TopBvhNode::invTransform).
+// On success w[r][4 + c] holds element (r, c) of the world transform.
+bool invertTransform(const float* m, double w[4][8])
+{
+    for (int r = 0; r < 4; r++)
+        for (int col = 0; col < 4; col++) {
+            w[r][col] = m[col * 4 + r];
+            w[r][col + 4] = (r == col) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++)
+            if (std::fabs(w[r][col]) > std::fabs(w[piv][col]))
+                piv = r;
+        if (std::fabs(w[piv][col]) < 1e-300)
+            return false;
+        for (int k = 0; k < 8; k++)
+            std::swap(w[piv][k], w[col][k]);
+        const double dv = w[col][col];
+        for (int k = 0; k < 8; k++)
+            w[col][k] /= dv;
+        for (int r = 0; r < 4; r++)
+            if (r != col) {
+                const double f = w[r][col];
+                for (int k = 0; k < 8; k++)
+                    w[r][k] -= f * w[col][k];
+            }
+    }
+    return true;
+}
+
 // Worst-case number of pending stack entries while traversing the 4-wide tree from `rootRef`: visiting a node
 // can leave all its other children on the stack, and entering an instance adds the leave-instance sentinel.
 // (Children are visited nearest first, so any order can occur: the bound takes the deepest child first.)
@@ -1022,35 +1053,8 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             return (refCount(hInst[a.inst].rootRef) != 0u) > (refCount(hInst[b.inst].rootRef) != 0u); // single leaves first
         });
         for (const BakeCandidate& bc : bakeCandidates) {
-            const float* m = topNodes[bc.topNode].invTransform; // column-major
-            double w[4][8];
-            for (int r = 0; r < 4; r++)
-                for (int col = 0; col < 4; col++) {
-                    w[r][col] = m[col * 4 + r];
-                    w[r][col + 4] = (r == col) ? 1.0 : 0.0;
-                }
-            bool singular = false;
-            for (int col = 0; col < 4 && !singular; col++) { // world = inverse(invTransform), Gauss-Jordan
-                int piv = col;
-                for (int r = col + 1; r < 4; r++)
-                    if (std::fabs(w[r][col]) > std::fabs(w[piv][col]))
-                        piv = r;
-                if (std::fabs(w[piv][col]) < 1e-300) {
-                    singular = true;
-                    break;
-                }
-                for (int k = 0; k < 8; k++)
-                    std::swap(w[piv][k], w[col][k]);
-                const double dv = w[col][col];
-                for (int k = 0; k < 8; k++)
-                    w[col][k] /= dv;
-                for (int r = 0; r < 4; r++)
-                    if (r != col) {
-                        const double f = w[r][col];
-                        for (int k = 0; k < 8; k++)
-                            w[r][k] -= f * w[col][k];
-                    }
-            }
+            double w[4][8]; // [r][4..7] = row r of the world transform
+            const bool singular = !invertTransform(topNodes[bc.topNode].invTransform, w);
             if (singular)
                 continue;
             const uint32_t instIndex = bc.inst;
