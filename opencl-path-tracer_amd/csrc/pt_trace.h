@@ -14,7 +14,7 @@
 //    atomics/us) and idle lanes read their ray straight from the queue, consecutive entries for consecutive
 //    idle lanes (ballot rank) -- no staging registers, so the kernel fits 80 VGPRs without spills;
 //  * ONE traversal stack in LDS, laid out [entry][lane] (a wave's push/pop touches 64 consecutive dwords:
-//    conflict-free ds_read/ds_write_b32), 16 entries; top level and bottom level share it, separated by a
+//    conflict-free ds_read/ds_write_b32), 12 entries; top level and bottom level share it, separated by a
 //    sentinel entry that restores the world-space ray (parked in LDS, [component][lane]); deeper entries spill
 //    to a lane-interleaved region in global memory;
 //  * 4-wide nodes with 8-bit quantised child boxes (WideNode, 64 B = four 16-byte loads for four children) at
@@ -52,7 +52,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_VOTE_LEAF 3 // long ones (sequential triangle fetches), so they are not left waiting for a majority
 #endif
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 16
+#define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 constexpr int kSpillStack = 100; // further entries in global memory
