@@ -99,12 +99,15 @@ struct Texture {
 };
 
 struct Node8;
+struct Node48;
 struct SceneDev {
     const PairNode* nodes; // the reference's binary tree, both boxes per node: host-side intermediate, not uploaded (null)
     const WideNode* wide; // 4-wide tree (k_trace)
     const Node8* nodes8; // 8-wide compressed tree (k_trace8), its triangles in node order and its top-level items
     const TriIsect* tris8;
     const uint32_t* items;
+    const Node48* nodes48; // 48-byte-node tree (k_trace48) and its triangles in node order; null when the scene keeps instances
+    const TriIsect* tris48;
     const TriIsect* tris; // caller's triangle numbering (shading re-reads v0/e1/e2 from here)
     const TriShade* triShade;
     const VertexShade* verts;

@@ -1,0 +1,389 @@
+// Persistent-wave traversal of the 48-byte-node tree (pt_wide48.h): k_trace's loop (pt_trace.h -- same packets, stack,
+// vote and slab tests) with THREE vector-memory instructions per node instead of four and without anything that
+// concerns instances: the scene is one world-space tree, "special" only ever means "finished".
+#pragma once
+#include "pt_trace.h"
+#include "pt_wide48.h"
+
+namespace ptd {
+
+#ifndef PT_TRACE48_MIN_WAVES
+#define PT_TRACE48_MIN_WAVES 7
+#endif
+
+#define spill (a.spill + gtid)
+template <bool ANY_HIT>
+__global__ void __launch_bounds__(kTraceBlock, PT_TRACE48_MIN_WAVES) k_trace48(TraceArgs a)
+{
+    __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t total = a.totalThreads;
+    const uint32_t count = *a.count;
+    const SceneDev& sc = a.sc;
+
+    auto push = [&](int slot, uint32_t v) {
+        if (slot < kLdsStack)
+            ldsStack[wave][slot][lane] = v;
+        else
+            spill[(size_t)(slot - kLdsStack) * total] = v;
+    };
+    // always a plain ds_read_b32; the (rare) spilled entry overrides it.  Selecting between the two
+    // addresses instead makes hipcc emit ONE flat_load on the critical pop -> node-fetch path.
+    auto pop = [&](int slot) -> uint32_t {
+        uint32_t v = ldsStack[wave][min(slot, kLdsStack - 1)][lane];
+        if (slot >= kLdsStack)
+            v = ((const volatile uint32_t*)spill)[(size_t)(slot - kLdsStack) * total]; // volatile: keeps the two loads apart
+        return v;
+    };
+
+#ifdef PT_TRACE_STATS
+    unsigned long long statAcc[24] = {};
+    PT_TIC(tKernel);
+#endif
+    bool active = false;
+    bool exhausted = false; // wave-uniform: queue has no more rays
+    uint32_t rayIdx = 0;
+    // ray of the space being traversed (world or instance): origin, direction, 1/direction, -origin/direction
+    V3 co = mk(0.f), cd = mk(0.f), cid = mk(0.f);
+    float tClosest = 0.f, hu = 0.f, hv = 0.f;
+    int hprim = -1;
+    uint32_t cur = kRefFinish;
+    int sp = 0;
+    // value of pop() given the prefetched LDS entry `top` (does not move sp)
+    auto popTop = [&](uint32_t top) -> uint32_t {
+        uint32_t v = sp > 0 ? top : kRefFinish;
+        if (sp > kLdsStack)
+            v = ((const volatile uint32_t*)spill)[(size_t)(sp - 1 - kLdsStack) * total];
+        return v;
+    };
+
+
+    auto setRay = [&](V3 o, V3 d) {
+        co = o;
+        cd = d;
+        cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
+    };
+
+    // ---- per-wave ray packets (see header comment) ---------------------------------------------
+    uint32_t poolBase = 0, poolNext = 0, poolEnd = 0; // wave-uniform
+    // Claiming queue entries: the first packet of every wave is static (wave w takes entries [64w, 64w+64)),
+    // later ones come from ONE shared cursor in spans of up to 512 entries -- a single device-scope word
+    // sustains only ~88 atomics/us (MI355X_MICROARCH.md, row `dequeue`), which at 64 rays per atomic would
+    // cap the kernel near 5.6 Grays/s and costs ~46 us per launch for the 4096 initial requests alone.
+    const uint32_t totalWaves = total >> 6, gwave = gtid >> 6;
+    const uint32_t spanSize = 64u * min(8u, max(1u, count / (totalWaves * 64u * 8u)));
+    uint32_t spanNext = gwave * 64u, spanEnd = spanNext + 64u; // wave-uniform: claimed, not yet loaded
+    auto requestPacket = [&]() {
+        if (spanNext >= spanEnd) {
+            uint32_t base = 0xFFFFFFC0u; // "nothing left"
+            if (gwave * 64u < count) { // otherwise even the static packets were not all needed: no dynamic part
+                if (lane == 0)
+                    base = atomicAdd(a.cursor, spanSize);
+                base = totalWaves * 64u + __shfl(base, 0);
+            }
+            spanNext = base;
+            spanEnd = base + spanSize;
+        }
+        const uint32_t base = spanNext;
+        spanNext += 64u;
+        poolBase = base;
+        poolNext = 0;
+        poolEnd = base < count ? min(64u, count - base) : 0u;
+    };
+    requestPacket();
+
+    while (true) {
+        // ---- hand rays to idle lanes ----------------------------------------------------------
+        PT_TIC(tHand);
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const int nIdle = __popcll(idle);
+            if (nIdle >= kRefillIdleLanes) {
+                const uint32_t avail = poolEnd - poolNext;
+                if (avail == 0u) {
+                    exhausted = true; // the request issued after the last hand-out came back empty
+                } else {
+                    PT_TIC(tShfl);
+                    const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    const int e = (int)min(poolNext + rank, 63u);
+                    float4 ro, rd;
+                    // the packet is only claimed; the lanes that take a ray read it straight from the queue
+                    // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
+                    ro = rd = make_float4(0, 0, 0, 0);
+                    if (!active && rank < avail) {
+                        ro = a.rayO[poolBase + (uint32_t)e];
+                        rd = a.rayD[poolBase + (uint32_t)e];
+                    }
+                    PT_TOC(16, tShfl);
+                    PT_TIC(tAssign);
+                    if (!active && rank < avail) {
+                        const uint32_t idx = poolBase + (uint32_t)e;
+                        float tMax = ANY_HIT ? ro.w : INFINITY;
+                        asm volatile("" : "+v"(tMax)); // own register (see the note in k_trace8 about the flag load below)
+                        uint32_t state = asU(rd.w); // closest-hit: parity mode keeps finished rays in the queue
+                        if (ANY_HIT) // contribution and pixel stay in the queue until the ray turns out unoccluded
+                            state = a.parityShadow ? asU(a.rayC[idx].w) : 0u;
+                        const bool live = (state & FLAG_FINISHED) == 0u;
+                        if (!ANY_HIT && !live) {
+                            a.hit[idx] = make_float4(INFINITY, 0.f, 0.f, asF(0xFFFFFFFFu));
+                            a.inst[idx] = -1;
+                        }
+                        if (live) {
+                            rayIdx = idx;
+                            // The reference nudges exactly-zero components of the ray it takes into an instance
+                            // (NO_PARALLEL_RAYS, scene.cl:123-137).  Instances copied to world space are never "entered",
+                            // so the same nudge is applied to the world-space ray: identical for the identity and
+                            // axis-aligned transforms, and the top-level box tests do not notice 1e-38.
+                            if (rd.x == 0.0f) rd.x = FLT_MIN;
+                            if (rd.y == 0.0f) rd.y = FLT_MIN;
+                            if (rd.z == 0.0f) rd.z = FLT_MIN;
+                            if (ro.x == 0.0f) ro.x = -FLT_MIN;
+                            if (ro.y == 0.0f) ro.y = -FLT_MIN;
+                            if (ro.z == 0.0f) ro.z = -FLT_MIN;
+                            setRay(xyz(ro), xyz(rd));
+                            tClosest = tMax;
+                            hprim = -1;
+                            hu = hv = 0.f;
+                            cur = makeRef(0u, 0u); // node 0 is the root
+                            sp = 0;
+                            active = true;
+                        }
+                    }
+                    PT_TOC(17, tAssign);
+                    PT_STAT(8, 1);
+                    PT_STAT(9, min((uint32_t)nIdle, avail));
+                    poolNext += min((uint32_t)nIdle, avail);
+                    if (poolNext == poolEnd) {
+                        PT_TIC(tReq);
+                        requestPacket();
+                        PT_TOC(15, tReq);
+                    }
+                }
+            }
+        }
+        PT_TOC(14, tHand);
+        PT_TIC(tSpec);
+        // ---- rays that are done park until the hot loop breaks; their results are written here, in batches ------
+        {
+            const bool finished = active && cur == kRefFinish;
+            const unsigned long long m = __ballot(finished);
+            if (m != 0ull) {
+                PT_STAT(4, 1);
+                PT_STAT(7, __popcll(m));
+            }
+            if (finished) {
+                // closestT != maxT decides hit/miss (scene.cl:257)
+                if (ANY_HIT) {
+                    if (a.occluded)
+                        a.occluded[rayIdx] = 0u;
+                    const float4 contrib = a.rayC[rayIdx];
+                    const uint32_t pixel = asU(a.rayD[rayIdx].w);
+                    float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                    float4 px = *ap;
+                    px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                    *ap = px;
+                } else {
+                    int hinst = -1;
+                    if (hprim >= 0) { // triangles were re-emitted in node order: back to (original triangle, instance)
+                        const float4 tc = sc.tris48[hprim].c;
+                        hprim = (int)asU(tc.y);
+                        hinst = (int)asU(tc.z);
+                    }
+                    a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+                    a.inst[rayIdx] = hinst;
+                }
+                active = false;
+            }
+        }
+        PT_TOC(13, tSpec);
+        if (__ballot(active) == 0ull) {
+            if (exhausted)
+                break;
+            continue;
+        }
+
+        // ---- hot loop: inner steps and leaves, until enough lanes are parked (special) or idle -------
+        while (true) {
+            // the entry a pop would return, fetched before the node / triangle loads so that its LDS latency
+            // hides under theirs (whichever step runs this iteration pops at most once, and only when it has
+            // pushed nothing)
+            const uint32_t stackTop = ldsStack[wave][min(max(sp - 1, 0), kLdsStack - 1)][lane];
+            const uint32_t kindBits = refCount(cur);
+            const bool wantInner = active && kindBits == 0u;
+            const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
+            const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
+            PT_STAT(0, 1);
+            PT_STAT(1, nInner + nLeaf);
+            // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
+            // enough lanes are idle for a hand-out (and the queue still has rays)
+            const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
+            const int nWork = nInner + nLeaf;
+            if (nWork == 0 || nSpecial >= kParkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
+                break;
+            if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
+                PT_STAT(2, 1);
+                PT_STAT(5, nInner);
+                PT_TIC(tInner);
+                if (wantInner) {
+                    // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
+                    const uint4* wp = (const uint4*)&sc.nodes48[refIndex(cur)];
+                    const uint4 A = wp[0], B = wp[1], CD = wp[2];
+                    const uint2 C = make_uint2(CD.x, CD.y);
+                    // child references from the 4-bit codes: inner children are consecutive nodes from nodeBase, the
+                    // triangles of leaf children consecutive from triBase, both in slot order
+                    const uint32_t codes = (A.w >> 24) | ((CD.z >> 28) << 8) | ((CD.w >> 28) << 12);
+                    const uint32_t innerBits = codes & 0x8888u, triCounts = codes & 0x3333u; // an inner code has no count bits
+                    const uint32_t nodeBase = CD.z & kRefIndexMask, triBase = CD.w & kRefIndexMask;
+                    uint4 D;
+                    {
+                        const uint32_t c0 = triCounts & 15u, c1 = (triCounts >> 4) & 15u, c2 = (triCounts >> 8) & 15u, c3 = triCounts >> 12;
+                        const uint32_t r1 = innerBits & 8u ? 1u : 0u, r2 = r1 + ((innerBits >> 7) & 1u), r3 = r2 + ((innerBits >> 11) & 1u);
+                        D.x = innerBits & 0x0008u ? nodeBase : makeRef(triBase, c0);
+                        D.y = innerBits & 0x0080u ? nodeBase + r1 : makeRef(triBase + c0, c1);
+                        D.z = innerBits & 0x0800u ? nodeBase + r2 : makeRef(triBase + c0 + c1, c2);
+                        D.w = innerBits & 0x8000u ? nodeBase + r3 : makeRef(triBase + c0 + c1 + c2, c3);
+                        // an empty slot (code 0) comes out as a reference with count 0 = "inner node triBase + ...": it is
+                        // never followed, its box is inverted and it is masked below
+                    }
+                    // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
+                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
+                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    // (origin - o) / d from the live registers: keeping -o/d around as well would cost three VGPRs, and 72 is
+                    // what 7 waves per SIMD allow
+                    const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
+                    // entry / exit planes chosen by the sign of the ray direction (whole dwords: 4 children at once)
+                    // instead of min/max per plane pair; an empty slot is an inverted box (q 255..0) and can never
+                    // satisfy exit >= entry -- and if round-off ever made it, its reference is a degenerate triangle
+                    const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                    const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
+                    const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
+                    const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
+                    const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
+                    float key[4];
+                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
+                        const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
+                        const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
+                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
+                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                        const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
+                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box
+                        const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest && ((codes >> (4 * k)) & 15u) != 0u;
+                        key[k] = vis ? tmin : INFINITY;
+                    }
+                    // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
+#define PT_CSWAP(i, j)                                   \
+    {                                                    \
+        const bool sw = key[j] < key[i];                 \
+        const float tk = sw ? key[j] : key[i];           \
+        key[j] = sw ? key[i] : key[j];                   \
+        key[i] = tk;                                     \
+        const uint32_t tr = sw ? ref[j] : ref[i];        \
+        ref[j] = sw ? ref[i] : ref[j];                   \
+        ref[i] = tr;                                     \
+    }
+#if PT_ANYHIT_SORT == 0
+                    if (ANY_HIT) { // any occluder will do: only move a visible child to the front
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2)
+                    } else
+#endif
+                    {
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+                    }
+#undef PT_CSWAP
+                    // farthest first onto the stack, continue with the nearest
+                    if (sp + 3 <= kLdsStack) {
+                        // common case, branch-free: every candidate is stored, the stack pointer only moves past the
+                        // ones that are kept (a rejected one is overwritten by the next store)
+                        ldsStack[wave][sp][lane] = ref[3];
+                        sp += key[3] < INFINITY ? 1 : 0;
+                        ldsStack[wave][sp][lane] = ref[2];
+                        sp += key[2] < INFINITY ? 1 : 0;
+                        ldsStack[wave][sp][lane] = ref[1];
+                        sp += key[1] < INFINITY ? 1 : 0;
+                    } else {
+                        if (key[3] < INFINITY) {
+                            push(sp, ref[3]);
+                            sp++;
+                        }
+                        if (key[2] < INFINITY) {
+                            push(sp, ref[2]);
+                            sp++;
+                        }
+                        if (key[1] < INFINITY) {
+                            push(sp, ref[1]);
+                            sp++;
+                        }
+                    }
+                    // no visible child => nothing was pushed => the prefetched stack top is still the top
+                    const uint32_t next = popTop(stackTop);
+                    if (key[0] < INFINITY)
+                        cur = ref[0];
+                    else
+                        cur = next, sp = max(sp - 1, 0);
+                }
+                PT_TOC(11, tInner);
+            } else {
+                PT_STAT(3, 1);
+                PT_STAT(6, nLeaf);
+                PT_TIC(tLeaf);
+                if (wantLeaf) {
+                    // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
+                    const uint32_t first = refIndex(cur), n = kindBits;
+                    bool done = false;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const TriIsect* tp = &sc.tris48[first + k];
+                        const float4 ta = tp->a, tb = tp->b;
+                        const float tcx = tp->c.x;
+                        const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
+                        const V3 P = cross(cd, e2);
+                        const float det = dot(e1, P);
+                        const float inv = rcpFast(det);
+                        const V3 T = co - v0;
+                        const float u = dot(T, P) * inv;
+                        const V3 Q = cross(T, e1);
+                        const float v = dot(cd, Q) * inv;
+                        const float t = dot(e2, Q) * inv;
+                        const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f
+                            && t < tClosest;
+                        if (hit) {
+                            if (ANY_HIT) {
+                                done = true;
+                                break;
+                            }
+                            tClosest = t;
+                            hu = u;
+                            hv = v;
+                            hprim = (int)(first + k);
+                        }
+                    }
+                    if (ANY_HIT && done) { // occluded: nothing to deposit
+                        if (a.occluded)
+                            a.occluded[rayIdx] = 1u;
+                        active = false;
+                        cur = kRefFinish;
+                    } else {
+                        cur = popTop(stackTop);
+                        sp = max(sp - 1, 0);
+                    }
+                }
+                PT_TOC(12, tLeaf);
+            }
+        }
+    }
+    PT_TOC(10, tKernel);
+#ifdef PT_TRACE_STATS
+    if (lane == 0)
+        for (int i = 0; i < 24; i++)
+            atomicAdd(&g_traceStats[i + (ANY_HIT ? 24 : 0)], statAcc[i]);
+#endif
+}
+
+#undef spill
+
+} // namespace ptd

@@ -5,6 +5,10 @@
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_trace8.h"
+#include "pt_trace48.h"
+#ifndef PT_NODE48
+#define PT_NODE48 0 // 1: 48-byte nodes (pt_wide48.h, k_trace48) for scenes without two-level instances; measured slower
+#endif
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
 #endif
@@ -71,6 +75,9 @@ struct pt_ctx {
     DevBuf<PairNode> nodes;
     DevBuf<WideNode> wide;
     DevBuf<Node8> nodes8;
+    DevBuf<Node48> nodes48;
+    DevBuf<TriIsect> tris48;
+    bool use48 = false; // the uploaded scene has a 48-byte-node tree: k_trace48 traverses it
     DevBuf<TriIsect> tris8;
     DevBuf<uint32_t> items;
     DevBuf<TriIsect> tris;
@@ -149,6 +156,8 @@ void refreshSceneView(pt_ctx* c)
     s.nodes = c->nodes.p;
     s.wide = c->wide.p;
     s.nodes8 = c->nodes8.p;
+    s.nodes48 = c->use48 ? c->nodes48.p : nullptr;
+    s.tris48 = c->use48 ? c->tris48.p : nullptr;
     s.tris8 = c->tris8.p;
     s.items = c->items.p;
     s.tris = c->tris.p;
@@ -472,7 +481,7 @@ int ensureSpill(pt_ctx* c)
 #if PT_BVH8
     const void* variants[4] = { (const void*)k_trace8<false>, (const void*)k_trace8<true>, (const void*)k_trace<false>, (const void*)k_trace<true> };
 #else
-    const void* variants[2] = { (const void*)k_trace<false>, (const void*)k_trace<true> };
+    const void* variants[4] = { (const void*)k_trace<false>, (const void*)k_trace<true>, (const void*)k_trace48<false>, (const void*)k_trace48<true> };
 #endif
     for (const void* fn : variants) {
         int b = 0;
@@ -502,7 +511,12 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
             hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
     }
 #else
-    if (anyHit)
+    if (c->use48) {
+        if (anyHit)
+            hipLaunchKernelGGL(k_trace48<true>, grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(k_trace48<false>, grid, block, 0, c->stream, a);
+    } else if (anyHit)
         hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
     else
         hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
@@ -803,7 +817,7 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->wide.release(), c->nodes8.release(), c->tris8.release(), c->items.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->wide.release(), c->nodes48.release(), c->tris48.release(), c->nodes8.release(), c->tris8.release(), c->items.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
@@ -1292,6 +1306,19 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     }
 #else
     packed = hWide;
+#endif
+    // ---- 48-byte-node tree when nothing two-level is left (pt_wide48.h) ---------------------------------
+    c->use48 = false;
+#if PT_NODE48
+    {
+        const pt_top_bvh_node& tr = topNodes[topRoot];
+        Wide48 w48 = buildWide48(hNodes, allTris, topRef[topRoot], tr.min, tr.max, (uint32_t)c->hostTris.size());
+        if (w48.usable && w48.stackNeed <= (uint32_t)(kLdsStack + kSpillStack)) {
+            if ((rc = uploadVec(c, c->nodes48, w48.nodes)) || (rc = uploadVec(c, c->tris48, w48.tris)))
+                return rc;
+            c->use48 = true;
+        }
+    }
 #endif
     if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
