@@ -145,11 +145,13 @@ enum : uint32_t { FLAG_FINISHED = 1, FLAG_LASTSPECULAR = 2 }; // shading.cl:11-1
 __host__ __device__ inline uint32_t packState(uint32_t flags, uint32_t bounce, uint32_t plane) { return (flags & 0xFFu) | ((bounce & 0xFFu) << 8) | (plane << 16); }
 struct AccumView {
     float4* plane0; // the HDR accumulator proper (width*height float4)
-    float4* extra; // planes 1.. (scratch, folded into plane0 after every batch)
-    uint32_t stride; // width*height
+    float4* extra; // planes 1.. (scratch, folded into plane0 after every batch): [pixel][plane - 1]
+    uint32_t perPixel; // extra planes per pixel = samples in flight - 1
+    // The planes of one pixel are adjacent: k_gen hands consecutive queue entries consecutive samples of the SAME
+    // pixel, so the lanes of a wave deposit into one run of memory.
     __device__ inline float4* at(uint32_t plane, uint32_t pixel) const
     {
-        return plane == 0u ? plane0 + pixel : extra + (size_t)(plane - 1u) * stride + pixel;
+        return plane == 0u ? plane0 + pixel : extra + (size_t)pixel * perPixel + (plane - 1u);
     }
 };
 
@@ -164,6 +166,10 @@ struct CameraDev { // Camera, camera.cl:7-26
 // same sample still reads (the reference needs a dedicated updateKernelData launch for that,
 // kernel.cl:303-317).
 constexpr int kMaxPasses = 16;
+#ifndef PT_GEN_INTERLEAVE
+#define PT_GEN_INTERLEAVE 64 // samples of one pixel that are neighbours in the primary-ray queue (power of two; 1: sample-major order)
+#endif
+constexpr uint32_t kGenInterleave = PT_GEN_INTERLEAVE;
 struct Control {
     uint32_t extCount[kMaxPasses + 1]; // rays in the extension queue at pass p
     uint32_t shadowCount[kMaxPasses + 1];

@@ -419,11 +419,13 @@ struct FrameParams {
     uint32_t parity; // LFSR113 streams per slot + reference queue semantics
     uint32_t numOwned; // pixels owned by this context
     uint32_t planes; // samples in flight (fixed schedule only; 1 otherwise)
+    uint32_t interleave; // k_gen: samples of one pixel in consecutive queue entries (a power of two dividing planes)
 };
 
 // generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th (pixel, sample) pair to
-// issue into queue slot slotBase + i: pixel = pixelList[first + i % numOwned] (or the index itself when
-// no list is set), sample = fp.sample + i / numOwned (that sample's accumulator plane).
+// issue into queue slot slotBase + i.  With one sample in flight: pixel = pixelList[first + i] (or the index itself
+// when no list is set).  With several: the samples of a pixel are neighbours in the queue (a wave of 64 primary rays
+// then walks the tree almost in lock-step, and so do the shadow rays its hits spawn): sample = fp.sample + plane.
 __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const uint32_t* __restrict__ pixelList, uint32_t first,
     uint32_t n, uint32_t slotBase, uint4* __restrict__ streams, uint32_t* __restrict__ queueCount, uint32_t* __restrict__ generated)
 {
@@ -436,8 +438,12 @@ __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const u
         return;
     uint32_t plane = 0, k = first + i;
     if (fp.planes > 1u) {
-        plane = k / fp.numOwned;
-        k -= plane * fp.numOwned;
+        // consecutive entries = `interleave` samples of ONE pixel, then the next pixel; after every owned pixel, the
+        // next group of samples
+        const uint32_t S = fp.interleave, span = S * fp.numOwned;
+        const uint32_t grp = k / span, r = k - grp * span;
+        plane = grp * S + r % S;
+        k = r / S;
     }
     const uint32_t pixel = pixelList ? pixelList[k] : k;
     Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
@@ -659,21 +665,33 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accu
 }
 
 // fold the extra accumulator planes of a batch into the accumulator and clear them; only the pixels this
-// context owns were written (pixels == nullptr: all of them), so a rank of an N-GPU job reads 1/N of every plane
+// context owns were written (pixels == nullptr: all of them), so a rank of an N-GPU job reads 1/N of the planes.
+// Sixteen lanes share a pixel: its planes are adjacent in memory, so they read whole cache lines.
+constexpr uint32_t kFoldLanes = 16;
 __global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes, const uint32_t* pixels, uint32_t numOwned)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= numOwned)
-        return;
-    const uint32_t i = pixels ? pixels[k] : k;
-    float4 s = acc.plane0[i];
-    for (uint32_t p = 1; p < planes; p++) {
-        float4* e = acc.extra + (size_t)(p - 1u) * acc.stride + i;
-        const float4 v = *e;
-        s.x += v.x, s.y += v.y, s.z += v.z;
-        *e = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = t / kFoldLanes, part = t % kFoldLanes;
+    const bool live = k < numOwned; // numOwned * kFoldLanes need not fill the last wave; its lanes still take part in the shuffles
+    const uint32_t i = live ? (pixels ? pixels[k] : k) : 0u;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (live)
+        for (uint32_t p = 1u + part; p < planes; p += kFoldLanes) {
+            float4* e = acc.at(p, i);
+            const float4 v = *e;
+            sx += v.x, sy += v.y, sz += v.z;
+            *e = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    for (int o = kFoldLanes / 2; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, kFoldLanes);
+        sy += __shfl_xor(sy, o, kFoldLanes);
+        sz += __shfl_xor(sz, o, kFoldLanes);
     }
-    acc.plane0[i] = s;
+    if (live && part == 0u) {
+        float4 s = acc.plane0[i];
+        s.x += sx, s.y += sy, s.z += sz;
+        acc.plane0[i] = s;
+    }
 }
 
 __global__ void k_set_word(uint32_t* p, uint32_t v)

@@ -146,7 +146,7 @@ int fail(pt_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->cfg.width * c->cfg.height }; }
+inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->planes - 1u }; }
 inline uint32_t maxBounces(const pt_ctx* c) { return c->cfg.max_bounces ? c->cfg.max_bounces : 4u; }
 inline bool parityMode(const pt_ctx* c) { return c->cfg.rng_mode == PT_RNG_LFSR113_PARITY; }
 
@@ -545,6 +545,7 @@ FrameParams frameParams(const pt_ctx* c, uint32_t sample)
     fp.parity = parityMode(c) ? 1u : 0u;
     fp.numOwned = c->numOwned;
     fp.planes = 1;
+    fp.interleave = 1;
     return fp;
 }
 
@@ -654,6 +655,9 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 {
     FrameParams fp = frameParams(c, sample);
     fp.planes = batch;
+    fp.interleave = 1;
+    while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
+        fp.interleave *= 2u;
     const uint32_t bounces = maxBounces(c);
     const uint32_t entries = c->numOwned * batch;
     prof.begin(0);
@@ -675,7 +679,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
     if (batch > 1) {
         const uint32_t n = c->numOwned;
-        hipLaunchKernelGGL(k_fold_planes, dim3((n + 255) / 256), dim3(256), 0, c->stream, accumView(c), batch,
+        hipLaunchKernelGGL(k_fold_planes, dim3((uint32_t)(((uint64_t)n * kFoldLanes + 255) / 256)), dim3(256), 0, c->stream, accumView(c), batch,
             c->identityPixels ? nullptr : c->pixelList.p, n);
     }
     HIPCHK(c, hipGetLastError());
@@ -1644,7 +1648,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         TraceArgs a = traceArgsBase(c);
         a.parityShadow = 0;
         a.rayO = dO.p, a.rayD = dD.p, a.rayC = dC.p;
-        a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 1u }, a.occluded = dOcc.p;
+        a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 0u }, a.occluded = dOcc.p;
         a.count = dCtl.p, a.cursor = dCtl.p + 1;
         chk(hipEventRecord(e0, c->stream));
         launchTrace(c, any_hit != 0, a);
@@ -1788,7 +1792,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.hits = { dH.p + i, dI.p + i };
         a.out = { out.o.p + i, out.d.p + i, out.thr.p + i };
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
-        a.accum = AccumView { dAcc.p, nullptr, (uint32_t)npix };
+        a.accum = AccumView { dAcc.p, nullptr, 0u };
         a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3;
         hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
         uint32_t back[4];
