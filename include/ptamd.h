@@ -137,6 +137,8 @@ typedef struct {
 #define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */
 #define PT_FLAG_NO_BAKED_INSTANCES 2u /* keep every instance two-level: no world-space copies at all (diagnostics) */
 #define PT_FLAG_TWO_LEVEL_ONLY 4u /* copy only single-leaf instances (quads, lights) to world space, not whole meshes */
+#define PT_FLAG_NO_PACKETS 8u /* never use the packet traversal kernel (primary rays then go through the per-ray kernel) */
+#define PT_FLAG_PACKET_INTERSECT 16u /* pt_intersect (test hook) uses the packet kernel where the scene allows it */
 
 typedef struct { uint32_t x0, y0, x1, y1; } pt_rect; /* [x0,x1) x [y0,y1) */
 
@@ -150,6 +152,7 @@ typedef struct {
     double ms_last_render; /* device time of the last pt_render (hipEvent, whole call) */
     double ms_intersect, ms_shade, ms_shadow, ms_gen; /* per-kernel-family device ms of the last pt_render
                                                         (only when PT_PROFILE_KERNELS was requested) */
+    uint64_t packet_launches; /* launches of the packet traversal kernel (primary rays of a world-space scene) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

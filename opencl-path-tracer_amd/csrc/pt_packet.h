@@ -1,0 +1,219 @@
+// Packet traversal: one wave walks the tree ONCE for the 64 consecutive queue entries it holds.
+//
+// k_gen hands consecutive queue entries the samples of one pixel (pt_shade.h), so the 64 primary rays of a wave are
+// almost the same ray, and the shadow rays their hits spawn leave from one spot.  k_trace (pt_trace.h) would walk
+// them in lock-step anyway but pays for 64 private traversals: a per-lane stack, a per-lane sort of the children, a
+// vote per iteration.  Here the traversal state is wave-uniform:
+//   * the current node reference lives in an SGPR, the node's origin / exponents / child references arrive through
+//     the scalar cache (one s_load instead of 64 lanes x 4 vector loads);
+//   * the stack is three VGPRs: entry e is LANE e of them (v_writelane / v_readlane): the child reference and the
+//     64-bit mask of lanes whose ray saw that child's box;
+//   * a lane only takes part in a node or leaf whose box its own ray passed, with the same accept test and the same
+//     arithmetic as k_trace, so every ray tests exactly the boxes and triangles it would test there (the order can
+//     differ, which matters for exact-t ties only);
+//   * the nearest child (entry distance of the first lane that sees it) is descended into, the others are pushed.
+// Correct for any 64 rays; fast when they are coherent.  Used for the first pass of the fixed schedule when the
+// scene is one world-space tree (every instance copied at upload, ptamd.hip) whose worst-case stack fits 64 entries.
+//
+// Reference semantics: traceRay, scene.cl:61-271 (closest hit, and hitAny :181-185); slab accept test bvh.cl:72,114;
+// Moeller-Trumbore shapes.cl:20-72.
+#pragma once
+#include "pt_trace.h"
+
+#ifndef PT_PACKET_MIN_WAVES
+#define PT_PACKET_MIN_WAVES 8
+#endif
+
+namespace ptd {
+
+constexpr int kPacketBlock = 256;
+constexpr uint32_t kPacketStack = 64; // one lane per entry
+
+__device__ inline uint32_t laneWrite(uint32_t v, uint32_t value, uint32_t laneIndex) // v[laneIndex] = value (both wave-uniform)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(laneIndex));
+    return v;
+}
+__device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// one stack entry: lane `laneIndex` of the three stack registers (all operands wave-uniform)
+__device__ inline void lanePush(uint32_t& r, uint32_t& lo, uint32_t& hi, uint32_t ref, uint32_t mlo, uint32_t mhi, uint32_t laneIndex)
+{
+    asm volatile("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                 : "+v"(r), "+v"(lo), "+v"(hi)
+                 : "s"(ref), "s"(mlo), "s"(mhi), "s"(laneIndex));
+}
+constexpr uint32_t kKeyNone = 0x7F800000u; // +inf: no lane sees the child
+
+template <bool ANY_HIT>
+__global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_packet(TraceArgs a)
+{
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef const u4v __attribute__((address_space(4)))* ScalarU4; // uniform address + constant space = scalar loads
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gwave = (blockIdx.x * kPacketBlock + threadIdx.x) >> 6;
+    const uint32_t totalWaves = (gridDim.x * kPacketBlock) >> 6;
+    const uint32_t count = *a.count;
+    const SceneDev& sc = a.sc;
+    const uint32_t packets = (count + 63u) >> 6;
+    const uint32_t rootRef = uni(sc.rootRef);
+    const ScalarU4 wideS = (ScalarU4)(unsigned long long)sc.wide;
+    const ScalarU4 trisS = (ScalarU4)(unsigned long long)sc.tris;
+
+    // packets are dealt round-robin: every wave sees the whole queue, so the load evens out without a shared cursor
+    for (uint32_t p = uni(gwave); p < packets; p += totalWaves) {
+        const uint32_t idx = p * 64u + lane;
+        bool active = idx < count;
+        float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 1);
+        if (active) {
+            ro = a.rayO[idx];
+            rd = a.rayD[idx];
+        }
+        float tClosest = ANY_HIT ? ro.w : INFINITY;
+        if (!ANY_HIT && active && (asU(rd.w) & FLAG_FINISHED)) {
+            a.hit[idx] = make_float4(INFINITY, 0.f, 0.f, asF(0xFFFFFFFFu));
+            a.inst[idx] = -1;
+            active = false;
+        }
+        // zero components are nudged as at k_trace's hand-out (NO_PARALLEL_RAYS, scene.cl:123-137)
+        if (rd.x == 0.0f) rd.x = FLT_MIN;
+        if (rd.y == 0.0f) rd.y = FLT_MIN;
+        if (rd.z == 0.0f) rd.z = FLT_MIN;
+        if (ro.x == 0.0f) ro.x = -FLT_MIN;
+        if (ro.y == 0.0f) ro.y = -FLT_MIN;
+        if (ro.z == 0.0f) ro.z = -FLT_MIN;
+        const V3 co = xyz(ro), cd = xyz(rd);
+        const V3 cid = mk(rcpSlab(cd.x), rcpSlab(cd.y), rcpSlab(cd.z));
+        const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+        float hu = 0.f, hv = 0.f;
+        int hprim = -1;
+
+        uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
+        uint32_t sp = 0u; // wave-uniform
+        uint32_t cur = rootRef;
+        unsigned long long curMask = __builtin_amdgcn_ballot_w64(active);
+        if (curMask != 0ull)
+            while (true) {
+                const bool here = __builtin_amdgcn_inverse_ballot_w64(curMask) && (!ANY_HIT || active);
+                if (refCount(cur) == 0u) {
+                    // -------- inner node: four quantised child boxes (scene.cl:197-231 / bvh.cl:76-115) ----------
+                    const uint32_t ni = refIndex(cur);
+                    const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u]; // scalar: origin + exponents, child references
+                    const uint4* wp = (const uint4*)&sc.wide[ni]; // the plane bytes are selected per lane: vector registers
+                    const uint4 B = wp[1];
+                    const uint2 C = *(const uint2*)&wp[2];
+                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
+                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
+                    const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
+                    const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
+                    const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
+                    const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
+                    const float tLimit = here ? tClosest : -INFINITY; // a lane that is not in this node sees no child
+                    unsigned long long m[4];
+                    uint32_t key[4]; // entry distance of the first lane that sees the child (float bits, >= 0: ordered as integers), slot in the low bits
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
+                        const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
+                        const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
+                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
+                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                        const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
+                        // tmax >= tmin && tmax >= 0 && tmin < closest (bvh.cl:72,114), the first two folded into one compare
+                        const float tlo = fmaxf(tmin, 0.f);
+                        const bool vis = tmax >= tlo && tmin < tLimit;
+                        m[k] = __builtin_amdgcn_ballot_w64(vis);
+                        // s_ff1 of an empty mask is -1 = lane 63, which then holds +inf like every other lane
+                        const uint32_t pick = (uint32_t)(__builtin_ffsll((long long)m[k]) - 1) & 63u;
+                        key[k] = (__builtin_amdgcn_readlane(asU(vis ? tlo : INFINITY), pick) & ~3u) | (uint32_t)k;
+                    }
+                    // nearest visible child: a tournament on (key, reference, lane mask), all in scalar registers
+                    const bool s01 = key[0] < key[1], s23 = key[2] < key[3];
+                    const uint32_t k01 = s01 ? key[0] : key[1], k23 = s23 ? key[2] : key[3];
+                    const uint32_t r01 = s01 ? D.x : D.y, r23 = s23 ? D.z : D.w;
+                    const unsigned long long m01 = s01 ? m[0] : m[1], m23 = s23 ? m[2] : m[3];
+                    const bool sl = k01 < k23;
+                    const uint32_t best = sl ? k01 : k23;
+                    if (best < kKeyNone) {
+                        // the other visible children onto the stack (slot order), the nearest is next.
+                        // key > best always; (key - best - 1) < (none - best - 1) <=> key != best && key < none
+                        const uint32_t refs[4] = { D.x, D.y, D.z, D.w };
+                        const uint32_t limit = kKeyNone - best - 1u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (key[k] - best - 1u < limit) {
+                                lanePush(stRef, stLo, stHi, uni(refs[k]), uni((uint32_t)m[k]), uni((uint32_t)(m[k] >> 32)), uni(sp));
+                                sp++;
+                            }
+                        cur = sl ? r01 : r23;
+                        curMask = sl ? m01 : m23;
+                        continue;
+                    }
+                } else {
+                    // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
+                    const uint32_t first = refIndex(cur), n = refCount(cur);
+                    for (uint32_t k = 0; k < n; k++) {
+                        const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
+                        const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
+                        const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
+                        const V3 P = cross(cd, e2);
+                        const float det = dot(e1, P);
+                        const float inv = rcpFast(det);
+                        const V3 T = co - v0;
+                        const float u = dot(T, P) * inv;
+                        const V3 Q = cross(T, e1);
+                        const float v = dot(cd, Q) * inv;
+                        const float t = dot(e2, Q) * inv;
+                        const bool hit = here && !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f
+                            && t < tClosest;
+                        if (hit) {
+                            if (ANY_HIT) {
+                                active = false; // occluded: nothing to deposit
+                                if (a.occluded)
+                                    a.occluded[idx] = 1u;
+                            } else {
+                                tClosest = t;
+                                hu = u;
+                                hv = v;
+                                hprim = (int)(first + k);
+                            }
+                        }
+                    }
+                    if (ANY_HIT && __builtin_amdgcn_ballot_w64(active) == 0ull)
+                        break; // every ray of the packet is occluded
+                }
+                if (sp == 0u)
+                    break;
+                sp--;
+                cur = __builtin_amdgcn_readlane(stRef, sp);
+                curMask = (unsigned long long)__builtin_amdgcn_readlane(stLo, sp) | ((unsigned long long)__builtin_amdgcn_readlane(stHi, sp) << 32);
+            }
+
+        // -------- results: consecutive lanes write consecutive records (scene.cl:257) --------------------------
+        if (ANY_HIT) {
+            if (active) {
+                if (a.occluded)
+                    a.occluded[idx] = 0u;
+                const float4 contrib = a.rayC[idx];
+                const uint32_t pixel = asU(rd.w);
+                float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                float4 px = *ap;
+                px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                *ap = px;
+            }
+        } else if (active) {
+            int hinst = -1;
+            if (hprim >= 0) { // a world-space copy of an instance: back to (original triangle, instance)
+                const float4 tc = sc.tris[hprim].c;
+                hprim = (int)asU(tc.y);
+                hinst = (int)asU(tc.z);
+            }
+            a.hit[idx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+            a.inst[idx] = hinst;
+        }
+    }
+}
+
+} // namespace ptd

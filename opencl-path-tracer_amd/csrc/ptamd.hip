@@ -4,6 +4,7 @@
 #include "../../include/ptamd.h"
 #include "pt_shade.h"
 #include "pt_trace.h"
+#include "pt_packet.h"
 #include "pt_trace8.h"
 #include "pt_trace48.h"
 #ifndef PT_NODE48
@@ -103,6 +104,10 @@ struct pt_ctx {
     uint32_t capacity = 0;
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
+    bool packetOk = false; // the scene is one world-space tree whose stack fits k_trace_packet
+    uint32_t packetBlocks = 0;
+    uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
+    uint64_t packetLaunches = 0;
     float4* accum = nullptr;
     uint32_t planes = 1; // samples in flight (fixed schedule)
     uint32_t spp = 0;
@@ -490,6 +495,12 @@ int ensureSpill(pt_ctx* c)
     }
     blocksPerCU = std::max(1, blocksPerCU);
     c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
+    {
+        int b0 = 0, b1 = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, (const void*)k_trace_packet<false>, kPacketBlock, 0));
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (const void*)k_trace_packet<true>, kPacketBlock, 0));
+        c->packetBlocks = (uint32_t)(std::max(1, std::min(b0, b1)) * c->numCUs);
+    }
     const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
     HIPCHK(c, c->spill.alloc(threads * kSpillStack));
     return PT_OK;
@@ -583,7 +594,23 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
-void launchIntersect(pt_ctx* c, int q, uint32_t pass)
+#ifndef PT_PACKET_USE
+#define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
+#endif
+constexpr uint32_t kPacketUseDefault = PT_PACKET_USE;
+
+void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
+{
+    const dim3 grid(c->packetBlocks), block(kPacketBlock);
+    c->packetLaunches++;
+    if (anyHit)
+        hipLaunchKernelGGL(k_trace_packet<true>, grid, block, 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_trace_packet<false>, grid, block, 0, c->stream, a);
+}
+
+// `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
+void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
@@ -593,10 +620,13 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass)
     a.inst = c->hitInst.p;
     a.count = &ctl->extCount[pass];
     a.cursor = &ctl->extCursor[pass];
-    launchTrace(c, false, a);
+    if (coherent && c->packetOk && (c->packetUse & 1u))
+        launchPacket(c, false, a);
+    else
+        launchTrace(c, false, a);
 }
 
-void launchShadow(pt_ctx* c, uint32_t pass)
+void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
@@ -606,7 +636,10 @@ void launchShadow(pt_ctx* c, uint32_t pass)
     a.accum = accumView(c);
     a.count = &ctl->shadowCount[pass];
     a.cursor = &ctl->shadowCursor[pass];
-    launchTrace(c, true, a);
+    if (coherent && c->packetOk && (c->packetUse & 2u))
+        launchPacket(c, true, a);
+    else
+        launchTrace(c, true, a);
 }
 
 // shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
@@ -666,13 +699,14 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
-        launchIntersect(c, in, b);
+        const bool coherent = b == 0 && fp.interleave >= 16u;
+        launchIntersect(c, in, b, coherent);
         prof.end();
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries);
         prof.end();
         prof.begin(3);
-        launchShadow(c, b);
+        launchShadow(c, b, coherent);
         prof.end();
         std::swap(in, out);
     }
@@ -772,6 +806,11 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         return fail(nullptr, PT_ERR_INVALID, "pt_create: device %d out of range (%d devices)", cfg->device, count);
     pt_ctx* c = new pt_ctx();
     c->cfg = *cfg;
+    c->packetUse = (cfg->flags & PT_FLAG_NO_PACKETS) ? 0u : kPacketUseDefault;
+    if (cfg->flags & PT_FLAG_PACKET_INTERSECT)
+        c->packetUse |= 4u;
+    if (const char* pk = getenv("PTAMD_PACKET")) // diagnostics: which launches may use k_trace_packet (bit 0 primary, 1 shadow, 2 pt_intersect)
+        c->packetUse = (uint32_t)atoi(pk);
     c->device = cfg->device;
     auto bail = [&](hipError_t err, const char* what) {
         int rc = fail(nullptr, PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(err));
@@ -1254,6 +1293,12 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     const uint32_t stackNeed = wideStackNeed(hWide, hInst, topRef[topRoot], emptyRef);
     if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
         return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
+    // k_trace_packet walks one world-space tree: no instance left to enter, the root an inner node, 64 stack entries
+    c->packetOk = stackNeed <= kPacketStack && refCount(topRef[topRoot]) == 0u;
+    for (const WideNode& w : hWide)
+        for (int k = 0; k < 4; k++)
+            if (refCount(w.child[k]) == kRefSpecial)
+                c->packetOk = false;
 #if PT_BVH8
     // ---- 8-wide compressed tree over the same pair nodes (pt_wide8.h) --------------------------------
     {
@@ -1547,11 +1592,14 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess)
         c->msLastRender = ms;
+    else
+        (void)hipGetLastError(); // nothing rendered yet: the events were never recorded; do not leave that error for the next call to find
     out->ms_last_render = c->msLastRender;
     out->ms_intersect = c->msIntersect;
     out->ms_shade = c->msShade;
     out->ms_shadow = c->msShadow;
     out->ms_gen = c->msGen;
+    out->packet_launches = c->packetLaunches;
     return PT_OK;
 }
 
@@ -1561,6 +1609,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
+    c->packetLaunches = 0;
     return PT_OK;
 }
 
@@ -1651,7 +1700,10 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 0u }, a.occluded = dOcc.p;
         a.count = dCtl.p, a.cursor = dCtl.p + 1;
         chk(hipEventRecord(e0, c->stream));
-        launchTrace(c, any_hit != 0, a);
+        if (c->packetOk && (c->packetUse & 4u))
+            launchPacket(c, any_hit != 0, a);
+        else
+            launchTrace(c, any_hit != 0, a);
         chk(hipEventRecord(e1, c->stream));
         chk(hipStreamSynchronize(c->stream));
         chk(hipGetLastError());

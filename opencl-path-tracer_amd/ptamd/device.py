@@ -12,6 +12,8 @@ RNG_COUNTER, RNG_LFSR113_PARITY = 0, 1
 FLAG_ROWMAJOR_PIXELS = 1
 FLAG_NO_BAKED_INSTANCES = 2  # every instance stays two-level
 FLAG_TWO_LEVEL_ONLY = 4  # only single-leaf instances are copied to world space
+FLAG_NO_PACKETS = 8  # primary rays through the per-ray kernel too
+FLAG_PACKET_INTERSECT = 16  # the pt_intersect hook uses the packet kernel where the scene allows it
 
 
 class Config(C.Structure):
@@ -28,7 +30,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_generated", C.c_uint64),
                 ("shade_hits", C.c_uint64), ("deposits", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
-                ("ms_shadow", C.c_double), ("ms_gen", C.c_double)]
+                ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64)]
 
 
 class RaysSoA(C.Structure):

@@ -12,15 +12,30 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("two_level", [True, False])
+MODES = ["two_level", "baked", "packet"]
+
+
+def _flags(gpu, mode):
+    """two_level: instances are entered like the reference does; baked: copied to world space (the default);
+    packet: baked, and pt_intersect runs the packet traversal kernel (one wave walks the tree once for 64 rays)."""
+    return {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "baked": 0, "packet": gpu.FLAG_PACKET_INTERSECT}[mode]
+
+
+def _check_kernel_used(ctx, mode):
+    assert (ctx.stats()["packet_launches"] > 0) == (mode == "packet"), "wrong traversal kernel ran"
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["mixed", "inst"])
-def test_golden_closest_and_any_hit(gpu, golden, name, two_level):
+def test_golden_closest_and_any_hit(gpu, golden, name, mode):
     """two_level: instances are entered like the reference does (ray transformed into instance space) -> hit/miss
     identical to the reference kernels.  Default: instances baked to world space while the byte budget lasts; a
     triangle edge is then rounded in world space, so a ray within round-off of an edge may change sides -- at most
-    5e-4 of the rays, each verified to graze an edge."""
+    5e-4 of the rays, each verified to graze an edge.  The packet kernel tests, per ray, the same boxes and triangles
+    with the same arithmetic as the per-ray kernel on the baked tree."""
+    two_level = mode == "two_level"
     flat, cam, sky, tex = golden_io.scene_inputs(golden, name)
-    ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex, flags=gpu.FLAG_TWO_LEVEL_ONLY if two_level else 0)
+    ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex, flags=_flags(gpu, mode))
     o, d = golden[f"isect_{name}_o"], golden[f"isect_{name}_d"]
     got = ctx.intersect(o, d)
     want = dict(t=golden[f"isect_{name}_t"], u=golden[f"isect_{name}_uv"][:, 0], v=golden[f"isect_{name}_uv"][:, 1],
@@ -31,14 +46,16 @@ def test_golden_closest_and_any_hit(gpu, golden, name, two_level):
     g = golden[f"shadow_{name}_occluded"]
     # segments cut 0.1 % before / after the first hit are decided by the same fp32 t on both sides
     assert (occ != g).sum() <= (2 if two_level else 2 + info["edge_flips"]), f"{(occ != g).sum()} occlusion verdicts differ"
+    _check_kernel_used(ctx, mode)
     ctx.close()
 
 
 @pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
-@pytest.mark.parametrize("two_level", [True, False])
-def test_random_rays_two_level(gpu, builder, two_level):
+@pytest.mark.parametrize("mode", MODES)
+def test_random_rays_two_level(gpu, builder, mode):
+    two_level = mode == "two_level"
     b = scenes.instanced_grid(64, 36, level=4, builder=builder, sky_size=(16, 8))
-    ctx = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_TWO_LEVEL_ONLY if two_level else 0)
+    ctx = U.make_ctx(gpu, b, 64, 36, flags=_flags(gpu, mode))
     sc = U.oracle_scene(b)
     o, d = U.random_rays(60000, 5, (-4, 0.05, -4), (4, 3, 4))
     got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
@@ -48,14 +65,16 @@ def test_random_rays_two_level(gpu, builder, two_level):
     occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
     ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
     assert (occ != ref).sum() <= 3 + info["edge_flips"]
+    _check_kernel_used(ctx, mode)
     ctx.close()
 
 
-def test_edge_cases(gpu):
+@pytest.mark.parametrize("mode", ["baked", "packet"])
+def test_edge_cases(gpu, mode):
     """empty queue tail / ragged sizes, axis-parallel rays (zero components), origins exactly on box faces
     and at 0, rays starting inside a box, rays that miss everything, degenerate zero-length shadow rays."""
     b = scenes.cornell_box(32, 32)
-    ctx = U.make_ctx(gpu, b, 32, 32)
+    ctx = U.make_ctx(gpu, b, 32, 32, flags=_flags(gpu, mode))
     sc = U.oracle_scene(b)
     for n in (1, 63, 64, 65, 1000):  # ragged wave fills
         o, d = U.random_rays(n, n, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
@@ -151,6 +170,29 @@ def _chain_scene(n):
     nodes[1] = nodes[last]  # never referenced
     flat.sub_nodes = nodes
     return flat, z
+
+
+def test_packet_kernel_stack_limit_and_fallback(gpu):
+    """The packet kernel keeps at most 64 pending entries (one per lane of its stack registers): a 40-level chain
+    fits, a 100-level chain does not and the per-ray kernel runs instead -- same answers either way."""
+    for n, fits in ((40, True), (100, False)):
+        flat, z = _chain_scene(n)
+        ctx = gpu.Context(8, 8, flags=gpu.FLAG_PACKET_INTERSECT)
+        ctx.upload_scene(flat)
+        m = 1000
+        rng = np.random.default_rng(n)
+        xy = rng.uniform(0.05, 0.45, (m, 2)).astype(np.float32)
+        o = np.concatenate([np.c_[xy, np.full(m, 100.0, np.float32)], np.c_[xy, np.full(m, -100.0, np.float32)]]).astype(np.float32)
+        d = np.concatenate([np.tile([0, 0, -1], (m, 1)), np.tile([0, 0, 1], (m, 1))]).astype(np.float32)
+        got = ctx.intersect(o, d)
+        assert (got["prim"][:m] == n - 1).all() and (got["prim"][m:] == 0).all()
+        assert np.allclose(got["t"][:m], 100.0 - z[n - 1], rtol=1e-5) and np.allclose(got["t"][m:], 100.0 + z[0], rtol=1e-5)
+        occ = ctx.intersect(o[:m], d[:m], tmax=np.full(m, 100.0 - z[n - 1] - 0.05, np.float32), any_hit=True)["prim"]
+        assert not occ.any()
+        occ = ctx.intersect(o[:m], d[:m], tmax=np.full(m, 100.0 - z[n - 1] + 0.05, np.float32), any_hit=True)["prim"]
+        assert occ.all()
+        assert (ctx.stats()["packet_launches"] > 0) == fits
+        ctx.close()
 
 
 def test_deep_trees_use_the_spilled_stack_and_too_deep_ones_are_rejected(gpu):

@@ -130,6 +130,13 @@ def test_determinism_batching_refill_and_tiles(gpu):
     assert not (t0.any(axis=1) & t1.any(axis=1)).any(), "ranks wrote the same pixel"
     assert st0["rays_generated"] + st1["rays_generated"] == 96 * 54 * 8
     assert np.allclose(t0 + t1, a1, rtol=1e-5, atol=1e-5 * a1.max())
+    # 64 samples of a pixel in consecutive queue entries: the packet kernel traces the primary rays -- the same
+    # paths as with the per-ray kernel
+    ap, stp = run(spp=64, samples_in_flight=64)
+    an, stn = run(spp=64, samples_in_flight=64, flags=gpu.FLAG_NO_PACKETS)
+    assert stp["packet_launches"] > 0 and stn["packet_launches"] == 0
+    assert stp["rays_extension"] == stn["rays_extension"] and stp["rays_shadow"] == stn["rays_shadow"]
+    assert np.allclose(ap, an, rtol=1e-5, atol=1e-5 * an.max())
 
 
 def test_clear_accumulate_and_spp_bookkeeping(gpu):
