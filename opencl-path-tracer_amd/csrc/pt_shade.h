@@ -454,7 +454,8 @@ __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const u
     const uint32_t slot = slotBase + i;
     q.o[slot] = make_float4(o.x, o.y, o.z, asF(pixel));
     q.d[slot] = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, plane)));
-    q.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+    if (fp.parity) // production mode: a primary ray's throughput is 1 by definition, k_shade does not read it (16 B per ray less each way)
+        q.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
 }
 
 struct ShadeArgs {
@@ -477,7 +478,7 @@ struct ShadeArgs {
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
 // output queues, finished or not (kernel.cl:292-300), at the SAME index, in slot order.
 #ifndef PT_SHADE_BLOCK
-#define PT_SHADE_BLOCK 256
+#define PT_SHADE_BLOCK 512
 #endif
 #ifndef PT_SHADE_MIN_WAVES
 #define PT_SHADE_MIN_WAVES 4
@@ -502,7 +503,9 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
         plane = fb >> 16;
         if (!(fb & FLAG_FINISHED)) {
             const float4 h = a.hits.h[i];
-            const float4 thr = a.in.thr[i];
+            float4 thr = make_float4(1.f, 1.f, 1.f, 0.f);
+            if (PARITY || bounce != 0u) // primary rays: 1, not stored (k_gen)
+                thr = a.in.thr[i];
             const V3 o = xyz(ro), d = xyz(rd), throughput = xyz(thr);
             const int prim = (int)asU(h.w);
             if (prim >= 0) {
@@ -550,8 +553,9 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     // their counts through LDS, and ONE lane per queue issues the atomicAdd for the whole block.  One atomic
     // per wave was not enough: a single device-scope word sustains ~90-100 atomics/us, so the 1 M waves of a
     // first-bounce launch would spend > 10 ms on it.  The block size trades that atomic rate (one per
-    // kShadeBlock entries) against waves idling at the two barriers: measured 1024 / 512 / 256 / 128 / 64
-    // threads -> 7.0 / 5.4 / 5.0 / 7.5 / 13.8 ms of k_shade per 32-sample batch.
+    // kShadeBlock entries) against waves idling at the two barriers: 1024 / 768 / 640 / 512 / 384 / 256 threads ->
+    // 17.8 / 20.1 / 22.3 / 14.3 / 17.4 / 16.3 ms of k_shade per 128-sample batch at 1080p (256-thread blocks sit
+    // exactly on the atomic rate: 1.36 M blocks per word in 16 ms = 85 atomics/us).
     __shared__ uint32_t sCount[kShadeBlock / 64][3];
     __shared__ uint32_t sBase[3];
     const unsigned long long mRay = __ballot(emitRay);

@@ -29,13 +29,18 @@ def build_host(force=False):
     return out
 
 
+# Division and square root as v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded expansions (~10
+# instructions each): a quarter of k_shade's instructions were those expansions.  The reference builds its kernels
+# with -cl-fast-relaxed-math (raytracer.cpp:819); every parity test passes either way.
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+
+
 def build_device(force=False):
     out = os.path.join(CSRC_DIR, "libptamd.so")
     deps = _all_files(CSRC_DIR, (".hip", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "ptamd.hip", "-o", out],
-                       cwd=CSRC_DIR, check=True)
+        subprocess.run([hipcc] + DEVICE_FLAGS + ["ptamd.hip", "-o", out], cwd=CSRC_DIR, check=True)
     return out
 
 
