@@ -13,8 +13,9 @@ RCCL reduce of the HDR accumulator at the end of the job (torch.distributed, bac
 timed region.  A ray = one traceRay invocation on a live queue entry (extension or shadow), counted by the
 device queues.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live for the dominant kernel (k_trace<false>,
-closest-hit traversal) with HIP events on the render stream in a separate, profiled pass;
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the render stream in a separate,
+profiled pass, for every kernel of the path (`roofline.kernels`); its top-level fields are those of the kernel
+with the largest share of device time (k_trace<true>, the any-hit traversal of the shadow rays);
 `cpu_baseline` times the oracle (our CPU restatement of the reference's path -- the reference has no CPU
 traversal code) on this box's host cores over a bounded sample of the same frame.
 """
@@ -31,6 +32,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
 BYTES_PER_EXT_RAY = 48  # closest-hit intersect reads 28 B ray, writes 20 B hit record
+BYTES_PER_SHADOW_RAY = 44  # 28 B ray + 12 B contribution + 4 B pixel (the 24-B deposit of an unoccluded ray is left out)
+BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
+BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
 
 
 def tile_rects(width, height, rank, world, tile=32):
@@ -227,20 +231,43 @@ def main():
         ctx.render(spp_step, sync=True)
         ps = ctx.stats()
         ctx.profile_kernels(False)
-        launches = 4 * (spp_step // in_flight)  # closest-hit launches: one per bounce per batch
-        rays_per_launch = ps["rays_extension"] / launches
-        avg_ms = ps["ms_intersect"] / launches
-        achieved = BYTES_PER_EXT_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_note = None, None  # HBM bytes per launch from the committed PMC profile of this exact configuration
+        # per kernel: units processed, launches and device time of the profiled pass; algorithmic bytes per unit are
+        # SURVEY.md 8(d)'s figures.  HBM traffic per unit comes from the committed PMC passes of this exact configuration.
+        batches = spp_step // in_flight
+        packets = ps["packet_launches"] > 0  # primary rays went through k_trace_packet
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic_k_trace_closest.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic.json")))
             cfgt = tj["config"]
-            if (cfgt["width"], cfgt["height"], cfgt["level"], cfgt["samples_in_flight"], cfgt["n_gpus"]) == (W, Hh, args.level, in_flight, world):
-                traffic = round(tj["bytes_per_ray"]["total"] * rays_per_launch)
-                traffic_note = (f"bytes per launch = {tj['bytes_per_ray']['total']} B/ray (FETCH_SIZE / WRITE_SIZE PMC passes of this exact "
-                                "configuration, corrected as profiles/round1/traffic_k_trace_closest.json states) x rays per launch")
+            if (cfgt["width"], cfgt["height"], cfgt["level"], cfgt["samples_in_flight"], cfgt["n_gpus"]) != (W, Hh, args.level, in_flight, world):
+                tj = None
         except (OSError, KeyError, ValueError):
-            pass
+            tj = None
+        kernels = {}
+
+        def add(name, what, ms, launches, units, bytes_per_unit):
+            if launches <= 0 or ms <= 0 or units <= 0:
+                return
+            gbs = bytes_per_unit * units / (ms * 1e-3) / 1e9
+            k = {"computes": what, "ms_per_step": round(ms, 3), "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                 "units_per_launch": int(units / launches), "algorithmic_bytes_per_unit": bytes_per_unit,
+                 "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "munits_per_s": round(units / ms / 1e3, 1),
+                 "traffic": None}
+            if tj and name in tj.get("kernels", {}):
+                k["traffic_bytes_per_unit"] = tj["kernels"][name]["bytes_per_unit"]["total"]
+                k["traffic"] = round(k["traffic_bytes_per_unit"] * units / launches)
+            kernels[name] = k
+
+        primary = ps["rays_generated"] if packets else 0
+        add("k_trace<true>", "any-hit traversal of the shadow rays", ps["ms_shadow"], 4 * batches, ps["rays_shadow"], BYTES_PER_SHADOW_RAY)
+        add("k_trace<false>", "closest-hit traversal, one ray per lane (bounce rays%s)" % ("" if packets else " and primary rays"),
+            ps["ms_intersect"] - ps["ms_packet"], (3 if packets else 4) * batches, ps["rays_extension"] - primary, BYTES_PER_EXT_RAY)
+        add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave", ps["ms_packet"], batches, primary,
+            BYTES_PER_EXT_RAY)
+        add("k_shade<false>", "shade + NEE + continuation + compaction", ps["ms_shade"], 4 * batches, ps["shade_hits"], BYTES_PER_SHADED_HIT)
+        add("k_gen", "primary rays", ps["ms_gen"], batches, ps["rays_generated"], BYTES_PER_GEN_RAY)
+        dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+        dk = kernels[dominant]
+        achieved = dk["achieved"]
         # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
         src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
         dst = torch.empty_like(src)
@@ -256,15 +283,18 @@ def main():
         # SURVEY 8(d) formula over the whole step (deposits are not counted on device and left out)
         path_bytes = 48.0 * ps["rays_generated"] + 48.0 * ps["rays_extension"] + 160.0 * ps["shade_hits"] + 44.0 * ps["rays_shadow"]
         path_ms = ps["ms_gen"] + ps["ms_intersect"] + ps["ms_shade"] + ps["ms_shadow"]
-        roofline = {"bound": "hbm", "kernel": "k_trace<false> (closest-hit two-level BVH traversal)",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        roofline = {"bound": "hbm", "kernel": f"{dominant} ({dk['computes']}; largest share of device time)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": dk["traffic"],
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
                     "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
-                    "traffic_note": traffic_note,
-                    "algorithmic_bytes_per_ray": BYTES_PER_EXT_RAY, "rays_per_launch": int(rays_per_launch),
-                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                    "mrays_per_s_in_kernel": round(rays_per_launch / avg_ms / 1e3, 1),
+                    "traffic_note": ("HBM bytes per launch = bytes per unit from the FETCH_SIZE / WRITE_SIZE PMC passes of this exact configuration "
+                                     "(profiles/round1/traffic.json states the corrections) x units per launch") if dk["traffic"] else None,
+                    "algorithmic_bytes_per_unit": dk["algorithmic_bytes_per_unit"], "units_per_launch": dk["units_per_launch"],
+                    "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
+                    "issue_limit": (tj or {}).get("issue_limit"),
+                    "mrays_per_s_in_kernel": round(ps["rays_extension"] / ps["ms_intersect"] / 1e3, 1),
+                    "kernels": kernels,
                     "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),
                                   "shade": round(ps["ms_shade"], 3), "shadow": round(ps["ms_shadow"], 3)}}
 
@@ -290,7 +320,7 @@ def main():
                 "workload": f"configs[3]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
                             f"SBVH meshes = {flat.instanced_triangles} instanced triangles, PBR metal/dielectric, procedural HDR sky + "
                             f"emissive quad), two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG",
-                "spp_per_step": spp_step, "samples_in_flight": in_flight,
+                "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight,
                 "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
                 "pixels_per_rank": W * Hh // world, "paths_per_step_per_rank": W * Hh // world * spp_step,
                 "collective": "none" if world == 1 else "1 x reduce(SUM) of the HDR accumulator (RCCL) per job",

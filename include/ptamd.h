@@ -153,6 +153,7 @@ typedef struct {
     double ms_intersect, ms_shade, ms_shadow, ms_gen; /* per-kernel-family device ms of the last pt_render
                                                         (only when PT_PROFILE_KERNELS was requested) */
     uint64_t packet_launches; /* launches of the packet traversal kernel (primary rays of a world-space scene) */
+    double ms_packet; /* the part of ms_intersect spent in the packet traversal kernel */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

@@ -125,7 +125,7 @@ struct pt_ctx {
     uint32_t traceBlocks = 0;
     bool queuesReady = false;
 
-    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0;
+    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0;
 };
 
 namespace {
@@ -700,6 +700,8 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
         const bool coherent = b == 0 && fp.interleave >= 16u;
+        if (c->profile && coherent && c->packetOk && (c->packetUse & 1u))
+            prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
         launchIntersect(c, in, b, coherent);
         prof.end();
         prof.begin(2);
@@ -1510,13 +1512,13 @@ int pt_render(pt_ctx* c, uint32_t spp)
     HIPCHK(c, hipEventRecord(c->evStop, c->stream));
     if (c->profile) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        double fam[4] = { 0, 0, 0, 0 };
+        double fam[5] = { 0, 0, 0, 0, 0 };
         for (auto& m : prof.marks) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, c->profEvents[m.second], c->profEvents[m.second + 1]);
             fam[m.first] += ms;
         }
-        c->msGen = fam[0], c->msIntersect = fam[1], c->msShade = fam[2], c->msShadow = fam[3];
+        c->msGen = fam[0], c->msIntersect = fam[1] + fam[4], c->msShade = fam[2], c->msShadow = fam[3], c->msPacket = fam[4];
     }
     return PT_OK;
 }
@@ -1600,6 +1602,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->ms_shadow = c->msShadow;
     out->ms_gen = c->msGen;
     out->packet_launches = c->packetLaunches;
+    out->ms_packet = c->msPacket;
     return PT_OK;
 }
 

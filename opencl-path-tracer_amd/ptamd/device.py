@@ -30,7 +30,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_generated", C.c_uint64),
                 ("shade_hits", C.c_uint64), ("deposits", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
-                ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64)]
+                ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double)]
 
 
 class RaysSoA(C.Structure):

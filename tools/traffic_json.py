@@ -1,0 +1,69 @@
+"""Turn the PMC passes of tools/final_profiles.sh into profiles/roundN/traffic.json (read by bench.py):
+
+    python tools/traffic_json.py gpurun_out/final profiles/round1/traffic.json
+
+Per kernel: HBM bytes per unit of work from FETCH_SIZE / WRITE_SIZE (own --pmc passes, unit KB), corrected as
+MI355X_MICROARCH.md prescribes for gfx950 -- FETCH_SIZE counts 16-B-per-lane coalesced reads at one half, which
+k_fold_planes (a pure stream of such reads, known size) confirms in the same runs -- and how busy the vector and
+scalar issue ports were (SQ_INSTS_VALU / SQ_INSTS_SALU x 4 cycles per wave64 instruction over SIMD-cycles)."""
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def table(name):
+    out = {}
+    for line in open(f"{src}/pmc_{name}.txt"):
+        m = re.match(r"(?:void )?ptd::(\S+)\s+(\S+)\s+(\d+)\s+per-dispatch\s+(\d+)\s+\((\d+) dispatches\)", line)
+        if m:
+            out.setdefault(m.group(1), {})[m.group(2)] = (float(m.group(3)), int(m.group(5)))
+    return out
+
+
+bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
+kern = bench["roofline"]["kernels"]
+fetch, write = table("FETCH_SIZE"), table("WRITE_SIZE")
+insts, act = table("SQ_INSTS_VALU"), table("GRBM_GUI_ACTIVE")
+STEPS = 2  # the PMC passes run --warmup 1 --steps 1
+# bytes per unit that FETCH_SIZE misses: the 16-B-per-lane reads of consecutive queue entries, counted at 1/2
+HALF_COUNTED = {
+    "k_trace<true>": (16.0, "ray origin+length and direction+pixel, 2 x 16 B per ray at hand-out"),
+    "k_trace<false>": (16.0, "ray origin and direction, 2 x 16 B per ray at hand-out"),
+    "k_trace_packet<false>": (16.0, "ray origin and direction, 2 x 16 B per ray"),
+    "k_shade<false>": (24.0, "ray origin, direction and hit record, 3 x 16 B per entry (a bounce ray's throughput adds 8 B)"),
+    "k_gen": (0.0, "writes only"),
+}
+out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["height"], "level": bench["config"]["level"],
+                  "samples_in_flight": bench["config"]["samples_in_flight"], "n_gpus": bench["n_gpus"]},
+       "calibration": "FETCH_SIZE / WRITE_SIZE in KB, summed over the dispatches of one bench step; FETCH_SIZE counts 16 B/lane coalesced "
+                      "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- 127 planes x 2073600 px x 16 B per launch -- reads back at x0.50 in "
+                      "the same passes), everything else 1:1; WRITE_SIZE exact (k_gen: rays x 32 B).",
+       "kernels": {}, "issue_limit": {},
+       "source": [f"profiles/round1/{p}" for p in ("r1h_pmc_FETCH_SIZE.txt", "r1h_pmc_WRITE_SIZE.txt", "r1h_pmc_SQ_INSTS_VALU.txt",
+                                                   "r1h_pmc_GRBM_GUI_ACTIVE.txt", "r1h_bench.json")]}
+for name, k in kern.items():
+    if name not in fetch and name not in write:
+        continue
+    units = k["units_per_launch"] * k["launches"]  # per step
+    rd = fetch.get(name, {}).get("FETCH_SIZE", (0, 0))[0] * 1024 / STEPS / units
+    wr = write.get(name, {}).get("WRITE_SIZE", (0, 0))[0] * 1024 / STEPS / units
+    add, why = HALF_COUNTED.get(name, (0.0, ""))
+    out["kernels"][name] = {"units_per_step": units, "raw_KB_per_step": {"FETCH_SIZE": round(fetch.get(name, {}).get("FETCH_SIZE", (0, 0))[0] / STEPS),
+                                                                          "WRITE_SIZE": round(write.get(name, {}).get("WRITE_SIZE", (0, 0))[0] / STEPS)},
+                            "correction": f"+{add:g} B per unit read ({why})" if add else why,
+                            "bytes_per_unit": {"read": round(rd + add, 1), "write": round(wr, 1), "total": round(rd + add + wr, 1)},
+                            "algorithmic_bytes_per_unit": k["algorithmic_bytes_per_unit"]}
+    if name in insts and name in act:
+        cycles = act[name]["GRBM_GUI_ACTIVE"][0] / 8.0  # summed over the 8 XCDs
+        simd_cycles = 1024.0 * cycles
+        i = insts[name]
+        e = {"valu_issue_busy": round(i["SQ_INSTS_VALU"][0] * 4.0 / simd_cycles, 3), "salu_issue_busy": round(i["SQ_INSTS_SALU"][0] * 4.0 / simd_cycles, 3)}
+        if "SQ_THREAD_CYCLES_VALU" in act[name] and "SQ_ACTIVE_INST_VALU" in act[name]:
+            e["valu_lane_utilisation"] = round(act[name]["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * act[name]["SQ_ACTIVE_INST_VALU"][0]), 3)
+        out["issue_limit"][name] = e
+out["issue_limit"]["note"] = ("a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles: busy = instructions x 4 / (1024 SIMDs x kernel cycles); "
+                              "the traversal kernels sit at the vector issue limit, not at HBM")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
