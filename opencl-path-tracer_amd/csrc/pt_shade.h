@@ -420,6 +420,8 @@ struct FrameParams {
     uint32_t numOwned; // pixels owned by this context
     uint32_t planes; // samples in flight (fixed schedule only; 1 otherwise)
     uint32_t interleave; // k_gen: samples of one pixel in consecutive queue entries (a power of two dividing planes)
+    uint32_t interleaveShift; // log2 of it
+    float invWidth;
 };
 
 // generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th (pixel, sample) pair to
@@ -429,26 +431,38 @@ struct FrameParams {
 __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const uint32_t* __restrict__ pixelList, uint32_t first,
     uint32_t n, uint32_t slotBase, uint4* __restrict__ streams, uint32_t* __restrict__ queueCount, uint32_t* __restrict__ generated)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // With several samples in flight the grid is 2-D: blockIdx.y = group of `interleave` samples, x over that group's
+    // `interleave * numOwned` entries -- the index arithmetic is shifts and masks (five 32-bit divisions were two
+    // thirds of this kernel's instructions).
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = r, plane = 0, k = first + r;
+    if (fp.planes > 1u) {
+        // consecutive entries = `interleave` (a power of two) samples of ONE pixel, then the next pixel; after every
+        // owned pixel, the next group of samples
+        const uint32_t span = fp.numOwned << fp.interleaveShift;
+        if (r >= span)
+            return;
+        i = blockIdx.y * span + r;
+        plane = (blockIdx.y << fp.interleaveShift) + (r & ((1u << fp.interleaveShift) - 1u));
+        k = first + (r >> fp.interleaveShift);
+    }
     if (i == 0) { // the queue now holds the surviving rays [0, slotBase) plus n new ones
         *queueCount = slotBase + n;
         *generated += n;
     }
     if (i >= n)
         return;
-    uint32_t plane = 0, k = first + i;
-    if (fp.planes > 1u) {
-        // consecutive entries = `interleave` samples of ONE pixel, then the next pixel; after every owned pixel, the
-        // next group of samples
-        const uint32_t S = fp.interleave, span = S * fp.numOwned;
-        const uint32_t grp = k / span, r = k - grp * span;
-        plane = grp * S + r % S;
-        k = r / S;
-    }
     const uint32_t pixel = pixelList ? pixelList[k] : k;
+    // pixel -> (x, y) without an integer division: float estimate, then exact correction (pixel < 2^31)
+    uint32_t py = (uint32_t)((float)pixel * fp.invWidth);
+    if (py * fp.width > pixel)
+        py--;
+    if ((py + 1u) * fp.width <= pixel)
+        py++;
+    const uint32_t px = pixel - py * fp.width;
     Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
     V3 o, d;
-    cameraRay(fp.cam, (int)(pixel % fp.width), (int)(pixel / fp.width), (float)fp.width, (float)fp.height, rng, &o, &d);
+    cameraRay(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, &o, &d);
     if (fp.parity)
         rngLfsrStore(streams, i, rng);
     const uint32_t slot = slotBase + i;

@@ -42,7 +42,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_TRACE_MIN_WAVES 7
 #endif
 #ifndef PT_PARKED_BREAK
-#define PT_PARKED_BREAK 16
+#define PT_PARKED_BREAK 24
 #endif
 #ifndef PT_ANYHIT_SORT
 #define PT_ANYHIT_SORT 0
@@ -57,6 +57,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 constexpr int kSpillStack = 100; // further entries in global memory
 constexpr int kTraceBlock = 256;
+#ifndef PT_PARKED_BREAK_ANY
+#define PT_PARKED_BREAK_ANY 40
+#endif
+constexpr int kParkedBreakAny = PT_PARKED_BREAK_ANY; // same, any-hit traversal (only unoccluded rays park: they have a deposit to make)
 constexpr int kParkedBreak = PT_PARKED_BREAK; // leave the hot loop once this many lanes are parked on a special step or idle
 constexpr int kRefillIdleLanes = PT_REFILL_IDLE; // hand out new rays once this many lanes are idle
 
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             // enough lanes are idle for a hand-out (and the queue still has rays)
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
             const int nWork = nInner + nLeaf;
-            if (nWork == 0 || nSpecial >= kParkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
+            if (nWork == 0 || nSpecial >= (ANY_HIT ? kParkedBreakAny : kParkedBreak) || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
             if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
                 PT_STAT(2, 1);

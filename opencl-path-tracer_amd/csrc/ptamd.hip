@@ -557,6 +557,8 @@ FrameParams frameParams(const pt_ctx* c, uint32_t sample)
     fp.numOwned = c->numOwned;
     fp.planes = 1;
     fp.interleave = 1;
+    fp.interleaveShift = 0;
+    fp.invWidth = 1.0f / (float)c->cfg.width;
     return fp;
 }
 
@@ -589,8 +591,10 @@ struct Prof {
 void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t n, uint32_t slotBase, uint32_t pass)
 {
     Control* ctl = c->control.p;
-    const uint32_t blocks = (std::max(n, 1u) + 255u) / 256u;
-    hipLaunchKernelGGL(k_gen, dim3(blocks), dim3(256), 0, c->stream, fp, c->rays[q].view(), c->identityPixels ? nullptr : c->pixelList.p,
+    // several samples in flight: one grid row per group of `interleave` samples (k_gen)
+    const uint32_t span = fp.planes > 1u ? fp.numOwned * fp.interleave : std::max(n, 1u);
+    const uint32_t blocks = (span + 255u) / 256u, rows = fp.planes > 1u ? fp.planes / fp.interleave : 1u;
+    hipLaunchKernelGGL(k_gen, dim3(blocks, rows), dim3(256), 0, c->stream, fp, c->rays[q].view(), c->identityPixels ? nullptr : c->pixelList.p,
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
@@ -690,7 +694,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     fp.planes = batch;
     fp.interleave = 1;
     while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
-        fp.interleave *= 2u;
+        fp.interleave *= 2u, fp.interleaveShift++;
     const uint32_t bounces = maxBounces(c);
     const uint32_t entries = c->numOwned * batch;
     prof.begin(0);
