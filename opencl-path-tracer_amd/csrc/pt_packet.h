@@ -20,6 +20,9 @@
 #pragma once
 #include "pt_trace.h"
 
+#ifndef PT_PACKET_DYNAMIC
+#define PT_PACKET_DYNAMIC 16 // > 0: packets per claim of the queue cursor; 0: static round-robin.  4 / 8 / 16 / 32 / 64 / 128: 27.2 / 25.4 / 25.0 / 25.7 / 26.1 / 28.2 ms of closest-hit traversal per batch (27.3 static)
+#endif
 #ifndef PT_PACKET_MIN_WAVES
 #define PT_PACKET_MIN_WAVES 8
 #endif
@@ -60,8 +63,32 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
     const ScalarU4 wideS = (ScalarU4)(unsigned long long)sc.wide;
     const ScalarU4 trisS = (ScalarU4)(unsigned long long)sc.tris;
 
+#if PT_PACKET_DYNAMIC
+    // The first PT_PACKET_DYNAMIC packets of a wave are static (wave w: [w * n, w * n + n)), later spans of the same
+    // size come from the queue cursor: one atomic per span, well under what a device-scope word sustains (pt_trace.h).
+    // Consecutive packets are neighbouring pixels, so a wave keeps finding its nodes in the scalar cache and L2, and
+    // no wave is left with a long static tail while others idle.
+    constexpr uint32_t kSpan = PT_PACKET_DYNAMIC;
+    uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
+    for (;;) {
+        if (spanLeft == 0u) {
+            uint32_t b = 0;
+            if (lane == 0)
+                b = atomicAdd(a.cursor, kSpan);
+            spanBase = totalWaves * kSpan + uni(b);
+            spanLeft = kSpan;
+        }
+        if (spanBase >= packets)
+            break;
+        const uint32_t p = spanBase;
+        spanBase++;
+        spanLeft--;
+        {
+#else
     // packets are dealt round-robin: every wave sees the whole queue, so the load evens out without a shared cursor
     for (uint32_t p = uni(gwave); p < packets; p += totalWaves) {
+        {
+#endif
         const uint32_t idx = p * 64u + lane;
         bool active = idx < count;
         float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 1);
@@ -212,6 +239,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
             }
             a.hit[idx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
             a.inst[idx] = hinst;
+        }
         }
     }
 }
