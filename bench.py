@@ -2,10 +2,10 @@
 """Headline benchmark: Mrays/s of the ray-queue render path on the ~1M-triangle two-level-BVH scene at
 1080p (BASELINE.json metric), one process per GPU.
 
-A *step* is one pass of the hot path over one batch: `128*N*R` samples per pixel for the pixels this rank
-owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~265 M path
+A *step* is one pass of the hot path over one batch: `256*N*R` samples per pixel for the pixels this rank
+owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~531 M path
 segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
-large batches matter (16 / 32 / 64 / 128 samples in flight differ by ~15 %); 128 in flight keep ~48 GB of
+large batches matter (64 / 128 / 256 samples in flight: 7.8 / 8.1 / 8.3 Grays/s); 256 in flight keep ~100 GB of
 queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
 shard across ranks, every rank traces the same number of paths per step whatever N is (weak scaling: the image
 simply receives N x more samples per step), and there is no data-path collective: the only exchange is ONE
@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=1, help="batches per step")
-    ap.add_argument("--in-flight", type=int, default=128, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
+    ap.add_argument("--in-flight", type=int, default=256, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")
@@ -170,7 +170,7 @@ def main():
     W, Hh = args.width, args.height
     bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT)
     flat = bundle.flat
-    in_flight = min(args.in_flight * world, 1024)
+    in_flight = min(args.in_flight * world, 4096)
     ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight)
     ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
     ctx.set_camera(bundle.camera)

@@ -434,8 +434,8 @@ int ensureQueues(pt_ctx* c)
     if (!parityMode(c) && c->cfg.max_active_rays == 0) {
         uint32_t want = c->cfg.samples_in_flight;
         if (want == 0) // auto: keep ~32M path segments per launch (the latency-bound tail of every launch is then a few % of it)
-            want = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, (32u << 20) / std::max(c->numOwned, 1u)));
-        c->planes = std::min(want, 1024u);
+            want = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (32u << 20) / std::max(c->numOwned, 1u)));
+        c->planes = std::min(want, 4096u);
     }
     uint64_t cap64 = c->cfg.max_active_rays ? c->cfg.max_active_rays : (uint64_t)c->numOwned * c->planes;
     if (cap64 > 0x7FFFFFC0ull)

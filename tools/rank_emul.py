@@ -1,4 +1,4 @@
-"""GPU box: per-rank throughput of an N-GPU job, emulated on one GPU (rank 0's tile share, 128*N samples in flight)."""
+"""GPU box: per-rank throughput of an N-GPU job, emulated on one GPU (rank 0's tile share, 256*N samples in flight)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd")); sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ from ptamd import scenes, host as H, device as D
 W, Hh = 1920, 1080
 b = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=6, builder=H.BVH_SPATIAL_SPLIT)
 for world in (int(x) for x in (sys.argv[1:] or ["1", "2", "8"])):
-    infl = min(128 * world, 1024)
+    infl = min(256 * world, 4096)
     ctx = D.Context(W, Hh, seed=1, samples_in_flight=infl)
     ctx.upload_scene(b.flat, sky=b.sky)
     ctx.set_camera(b.camera)
