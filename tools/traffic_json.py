@@ -41,8 +41,8 @@ out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["
                       "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- 127 planes x 2073600 px x 16 B per launch -- reads back at x0.50 in "
                       "the same passes), everything else 1:1; WRITE_SIZE exact (k_gen: rays x 32 B).",
        "kernels": {}, "issue_limit": {},
-       "source": [f"profiles/round1/{p}" for p in ("r1h_pmc_FETCH_SIZE.txt", "r1h_pmc_WRITE_SIZE.txt", "r1h_pmc_SQ_INSTS_VALU.txt",
-                                                   "r1h_pmc_GRBM_GUI_ACTIVE.txt", "r1h_bench.json")]}
+       "source": [f"profiles/round1/{p}" for p in ("r1i_pmc_FETCH_SIZE.txt", "r1i_pmc_WRITE_SIZE.txt", "r1i_pmc_SQ_INSTS_VALU.txt",
+                                                   "r1i_pmc_GRBM_GUI_ACTIVE.txt", "r1i_bench.json")]}
 for name, k in kern.items():
     if name not in fetch and name not in write:
         continue
