@@ -48,7 +48,7 @@ def build_raytracer(force=False):
     """libptamd_raytracer.so: the C++ RayTracer class (host/raytracer.cpp) on top of both libraries,
     and the examples/render_cornell demo that drives it."""
     out = os.path.join(HOST_DIR, "libptamd_raytracer.so")
-    deps = _all_files(HOST_DIR, (".cpp", ".h"))
+    deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))  # pt_stats etc. are part of its ABI
     if force or _newer(out, deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "raytracer.cpp", "-o", out, "-L.", "-lptamd_host",
                         "-L../csrc", "-lptamd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc"], cwd=HOST_DIR, check=True)

@@ -44,10 +44,10 @@ report("shadow-like", read()[24:], len(p))
 
 # the real pipeline: one 32-sample batch, per bounce depth limit (difference between rows = that bounce)
 for mb in (1, 2, 4):
-    c2 = D.Context(W, Hh, seed=1, samples_in_flight=32, max_bounces=mb)
+    c2 = D.Context(W, Hh, seed=1, samples_in_flight=64, max_bounces=mb)
     c2.upload_scene(b.flat, sky=b.sky); c2.set_camera(b.camera)
-    c2.render(32); read(); c2.reset_stats()
-    c2.render(32); st = c2.stats(); s = read()
+    c2.render(64); read(); c2.reset_stats()
+    c2.render(64); st = c2.stats(); s = read()
     report(f"render b<{mb} ext", s[:24], st["rays_extension"])
     report(f"render b<{mb} shd", s[24:], st["rays_shadow"])
     c2.close()
