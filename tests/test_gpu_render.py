@@ -137,6 +137,13 @@ def test_determinism_batching_refill_and_tiles(gpu):
     assert stp["packet_launches"] > 0 and stn["packet_launches"] == 0
     assert stp["rays_extension"] == stn["rays_extension"] and stp["rays_shadow"] == stn["rays_shadow"]
     assert np.allclose(ap, an, rtol=1e-5, atol=1e-5 * an.max())
+    # ... also when the frame is sharded into tiles (what a rank of a multi-GPU job does)
+    p0, sp0 = run(spp=64, tiles=rects[0::2], samples_in_flight=64)
+    p1, sp1 = run(spp=64, tiles=rects[1::2], samples_in_flight=64)
+    assert sp0["packet_launches"] > 0 and sp1["packet_launches"] > 0
+    assert sp0["rays_extension"] + sp1["rays_extension"] == stp["rays_extension"]
+    assert not (p0.any(axis=1) & p1.any(axis=1)).any()
+    assert np.allclose(p0 + p1, ap, rtol=1e-5, atol=1e-5 * ap.max())
 
 
 def test_clear_accumulate_and_spp_bookkeeping(gpu):
