@@ -74,6 +74,13 @@ int pth_camera_data(const pth_camera_params* p, pt_camera* out);
  * rows bottom-up (FreeImage order).  rgba_out: width*height*4 floats = what pt_upload_texture_array takes. */
 int pth_image_hdr_info(const char* path, uint32_t* width, uint32_t* height);
 int pth_image_load_hdr(const char* path, uint32_t width, uint32_t height, float brightnessMultiplier, float* rgba_out);
+/* PNG -> one layer of the 8-bit material texture array, as CLTextureArray::loadImage prepares it
+ * (src/opencl/texture.cpp:72-92,112-131: rescale to the layer size, FreeImage_AdjustGamma(1/2.2) unless isLinear, 32 bits
+ * per texel, rows bottom-up), returned as the RGBA floats read_imagef yields (byte / 255) for pt_upload_texture_array
+ * kind 0.  width / height 0 = keep the file's size.  pth_image_load_png_rgba8: the decoded file itself, top-down. */
+int pth_image_png_info(const char* path, uint32_t* width, uint32_t* height);
+int pth_image_load_png_rgba8(const char* path, uint8_t* rgba_out);
+int pth_image_load_material_png(const char* path, uint32_t width, uint32_t height, int isLinear, float* rgba_out);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,30 @@ int pth_image_load_hdr(const char* path, uint32_t width, uint32_t height, float 
     });
 }
 
+int pth_image_png_info(const char* path, uint32_t* width, uint32_t* height)
+{
+    return guarded([&] {
+        const ImageRGBA8 img = loadPNG(path);
+        *width = img.width, *height = img.height;
+    });
+}
+
+int pth_image_load_png_rgba8(const char* path, uint8_t* rgba_out)
+{
+    return guarded([&] {
+        const ImageRGBA8 img = loadPNG(path);
+        std::memcpy(rgba_out, img.rgba.data(), img.rgba.size());
+    });
+}
+
+int pth_image_load_material_png(const char* path, uint32_t width, uint32_t height, int isLinear, float* rgba_out)
+{
+    return guarded([&] {
+        const ImageRGBAF img = loadMaterialLayer(path, width, height, isLinear != 0);
+        std::memcpy(rgba_out, img.rgba.data(), img.rgba.size() * sizeof(float));
+    });
+}
+
 void pth_mesh_destroy(pth_mesh* m) { delete (MeshHandle*)m; }
 
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out)

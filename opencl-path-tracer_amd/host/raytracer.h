@@ -39,6 +39,12 @@ struct TextureArray {
         img = loadSkydomeLayer(hdrFile, width, height, brightnessMultiplier);
         return add(img.rgba.data(), img.width, img.height);
     }
+    // UniqueTextureArray::add(filePath, isLinear) for the 8-bit material array (PNG files: every texture the reference ships)
+    int addMaterial(const std::string& pngFile, bool isLinear = false)
+    {
+        const ImageRGBAF img = loadMaterialLayer(pngFile, width, height, isLinear); // 0 x 0: the first file fixes the layer size
+        return add(img.rgba.data(), img.width, img.height);
+    }
 };
 
 class RayTracer {

@@ -24,7 +24,7 @@ def build_host(force=False):
     out = os.path.join(HOST_DIR, "libptamd_host.so")
     deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
     if force or _newer(out, deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + HOST_SOURCES + ["-o", out],
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + HOST_SOURCES + ["-o", out, "-lz"],  # zlib: PNG inflate
                        cwd=HOST_DIR, check=True)
     return out
 

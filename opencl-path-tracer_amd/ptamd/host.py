@@ -64,6 +64,9 @@ def lib():
         _lib.pth_camera_data.argtypes = [C.POINTER(CameraParams), C.c_void_p]
         _lib.pth_image_hdr_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib.pth_image_load_hdr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        _lib.pth_image_png_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _lib.pth_image_load_png_rgba8.argtypes = [C.c_char_p, C.c_void_p]
+        _lib.pth_image_load_material_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -281,4 +284,29 @@ def load_hdr(path, width=None, height=None, brightness=1.0):
     out = np.zeros((1, height, width, 4), np.float32)
     if lib().pth_image_load_hdr(str(path).encode(), width, height, float(brightness), _ptr(out)):
         _err("pth_image_load_hdr")
+    return out
+
+
+def load_png(path):
+    """Decoded PNG as [height][width][4] uint8 RGBA, top row first (the file itself, no resampling)."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if lib().pth_image_png_info(str(path).encode(), C.byref(w), C.byref(h)):
+        _err("pth_image_png_info")
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    if lib().pth_image_load_png_rgba8(str(path).encode(), _ptr(out)):
+        _err("pth_image_load_png_rgba8")
+    return out
+
+
+def load_material_png(path, width=None, height=None, is_linear=False):
+    """PNG -> [1][height][width][4] float32 layer of the material texture array (reference
+    CLTextureArray::loadImage for the 8-bit array, src/opencl/texture.cpp:72-92,112-131): Lanczos-3 rescale,
+    FreeImage_AdjustGamma(1/2.2) unless is_linear, byte / 255, rows bottom-up."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if lib().pth_image_png_info(str(path).encode(), C.byref(w), C.byref(h)):
+        _err("pth_image_png_info")
+    width, height = width or w.value, height or h.value
+    out = np.zeros((1, height, width, 4), np.float32)
+    if lib().pth_image_load_material_png(str(path).encode(), width, height, int(is_linear), _ptr(out)):
+        _err("pth_image_load_material_png")
     return out

@@ -1,6 +1,8 @@
 """Host-side scene library: BVH builder invariants (the reference's BvhTester checks,
 src/bvh/bvh_test.cpp:117-139, as real tests), top-level BVH, flattening with index rebasing
 (src/raytracer.cpp:244-270) and camera derivation (src/camera.cpp:18-58)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -265,3 +267,136 @@ def test_radiance_hdr_layers_are_prepared_like_the_reference_texture_array(tmp_p
     (tmp_path / "bad.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n\x01\x02")
     with pytest.raises(RuntimeError, match="truncated"):
         H.load_hdr(tmp_path / "bad.hdr")
+
+
+def _png_chunk(tag, data):
+    import struct, zlib
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def _write_png(path, rows_of_bytes_per_pass, width, height, depth, colour, interlace=0, plte=None, trns=None, filters=(0, 1, 2, 3, 4), idat_split=3):
+    """Hand-rolled PNG writer for what PIL cannot produce: chosen scanline filters, Adam7, split IDAT.
+    rows_of_bytes_per_pass: per pass, a list of raw (unfiltered) scanlines as bytes; bpp from depth/colour."""
+    import struct, zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    bpp = max(1, channels * depth // 8)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    raw = bytearray()
+    for rows in rows_of_bytes_per_pass:
+        prev = None
+        for y, row in enumerate(rows):
+            f = filters[y % len(filters)]
+            out = bytearray([f])
+            for i, v in enumerate(row):
+                a = row[i - bpp] if i >= bpp else 0
+                b = prev[i] if prev is not None else 0
+                c = prev[i - bpp] if (prev is not None and i >= bpp) else 0
+                pred = (0, a, b, (a + b) // 2, paeth(a, b, c))[f]
+                out.append((v - pred) & 0xFF)
+            raw += out
+            prev = row
+    comp = zlib.compress(bytes(raw), 6)
+    n = max(1, len(comp) // idat_split)
+    body = b"".join(_png_chunk(b"IDAT", comp[i:i + n]) for i in range(0, len(comp), n))
+    ihdr = struct.pack(">IIBBBBB", width, height, depth, colour, 0, 0, interlace)
+    extra = (_png_chunk(b"PLTE", plte) if plte else b"") + (_png_chunk(b"tRNS", trns) if trns else b"") + _png_chunk(b"tEXt", b"Comment\x00hand made")
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", ihdr) + extra + body + _png_chunk(b"IEND", b""))
+
+
+def test_png_decoder_against_pil_and_hand_made_files(tmp_path):
+    """PNG files (the only texture format the reference ships: 51 of them) decode to the same RGBA8 as PIL: every
+    colour type, sub-byte and 16-bit depths, palette + tRNS, all five scanline filters, Adam7, split IDAT, CRC."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    h, w = 37, 53
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba[5:9, 3:20] = rgba[5, 3]  # flat runs so that the encoder picks different filters
+    cases = {"RGBA": Image.fromarray(rgba), "RGB": Image.fromarray(rgba[..., :3]), "L": Image.fromarray(rgba[..., 0]),
+             "LA": Image.fromarray(rgba[..., :2]), "1": Image.fromarray((rgba[..., 0] > 127)), "I16": Image.fromarray(rgba[..., 0].astype(np.uint16) * 257)}
+    pal = Image.fromarray(rgba[..., :3]).quantize(31)
+    cases["P"] = pal
+    for name, im in cases.items():
+        f = tmp_path / f"{name}.png"
+        im.save(f)
+        want = np.asarray(Image.open(f).convert("RGBA"))
+        if name == "I16":  # PIL maps 16-bit grey to 8 bits by clipping; PNG semantics (and FreeImage) keep the high byte
+            want = np.stack([rgba[..., 0]] * 3 + [np.full((h, w), 255, np.uint8)], -1)
+        got = H.load_png(f)
+        assert got.shape == (h, w, 4) and np.array_equal(got, want), name
+    pal.save(tmp_path / "Pt.png", transparency=bytes(rng.integers(0, 256, 31, dtype=np.uint8)))
+    assert np.array_equal(H.load_png(tmp_path / "Pt.png"), np.asarray(Image.open(tmp_path / "Pt.png").convert("RGBA")))
+    Image.fromarray(rgba[..., :3]).save(tmp_path / "key.png", transparency=tuple(int(v) for v in rgba[2, 2, :3]))
+    got = H.load_png(tmp_path / "key.png")
+    key = (rgba[..., :3] == rgba[2, 2, :3]).all(-1)
+    assert np.array_equal(got[..., 3], np.where(key, 0, 255)) and np.array_equal(got[..., :3], rgba[..., :3])
+    # hand-made: every filter type row by row, IDAT in pieces, an ancillary chunk to skip
+    rows = [bytes(rgba[y].reshape(-1)) for y in range(h)]
+    _write_png(tmp_path / "filters.png", [rows], w, h, 8, 6)
+    assert np.array_equal(H.load_png(tmp_path / "filters.png"), rgba)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "filters.png").convert("RGBA")), rgba)  # the writer itself is sane
+    # Adam7, RGB 8 bit and 2-bit grey
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    sub = [[bytes(rgba[y, x0::dx, :3].reshape(-1)) for y in range(y0, h, dy)] if x0 < w and y0 < h else [] for (x0, y0, dx, dy) in passes]
+    _write_png(tmp_path / "adam7.png", sub, w, h, 8, 2, interlace=1)
+    assert np.array_equal(H.load_png(tmp_path / "adam7.png")[..., :3], rgba[..., :3])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "adam7.png").convert("RGB")), rgba[..., :3])
+    g2 = rgba[..., 0] >> 6
+
+    def pack2(v):
+        v = np.concatenate([v, np.zeros((-len(v)) % 4, np.uint8)])
+        return bytes((v[0::4] << 6) | (v[1::4] << 4) | (v[2::4] << 2) | v[3::4])
+    _write_png(tmp_path / "grey2i.png", [[pack2(g2[y, x0::dx]) for y in range(y0, h, dy)] for (x0, y0, dx, dy) in passes], w, h, 2, 0, interlace=1)
+    assert np.array_equal(H.load_png(tmp_path / "grey2i.png")[..., 0], g2 * 85)
+    # damage: a flipped byte inside IDAT breaks its CRC; a truncated file is refused
+    data = bytearray(open(tmp_path / "filters.png", "rb").read())
+    data[len(data) // 2] ^= 0x40
+    open(tmp_path / "bad.png", "wb").write(data)
+    with pytest.raises(RuntimeError, match="CRC|inflate"):
+        H.load_png(tmp_path / "bad.png")
+    open(tmp_path / "short.png", "wb").write(bytes(data[:200]))
+    with pytest.raises(RuntimeError, match="truncated|IHDR|CRC"):
+        H.load_png(tmp_path / "short.png")
+    with pytest.raises(RuntimeError, match="not a PNG"):
+        open(tmp_path / "no.png", "wb").write(b"GIF89a" + bytes(40))
+        H.load_png(tmp_path / "no.png")
+
+
+def test_material_texture_layers_are_prepared_like_the_reference_texture_array(tmp_path):
+    """CLTextureArray::loadImage for the 8-bit material array (reference src/opencl/texture.cpp:84-92,112-131): rescale to
+    the layer size, FreeImage_AdjustGamma(1/2.2) on the colour channels unless linear, alpha kept, rows bottom-up, and
+    read_imagef's byte / 255."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    h, w = 16, 24
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba[:4, :, 3] = 0  # a cut-out band (alpha-0 texels pass rays through, shading.cl:587-601)
+    Image.fromarray(rgba).save(tmp_path / "t.png")
+    lin = H.load_material_png(tmp_path / "t.png", is_linear=True)
+    assert lin.shape == (1, h, w, 4) and np.array_equal(lin[0, ::-1], rgba.astype(np.float32) / 255.0)
+    srgb = H.load_material_png(tmp_path / "t.png")
+    lut = np.minimum(255, np.floor(255.0 * (np.arange(256) / 255.0) ** 2.2 + 0.5)).astype(np.uint8)
+    assert np.array_equal(srgb[0, ::-1, :, :3], lut[rgba[..., :3]].astype(np.float32) / 255.0)
+    assert np.array_equal(srgb[0, ::-1, :, 3], rgba[..., 3].astype(np.float32) / 255.0)
+    # rescale: sizes as asked, a constant picture stays constant, values stay bytes / 255
+    const = np.tile(np.array([200, 100, 50, 255], np.uint8), (8, 8, 1))
+    Image.fromarray(const).save(tmp_path / "c.png")
+    big = H.load_material_png(tmp_path / "c.png", 32, 16, is_linear=True)
+    assert big.shape == (1, 16, 32, 4) and np.array_equal(big[0, 0, 0], np.array([200, 100, 50, 255], np.float32) / 255.0) and (big == big[0, 0, 0]).all()
+    small = H.load_material_png(tmp_path / "t.png", 12, 8, is_linear=True)
+    assert np.array_equal(small * 255.0, np.round(small * 255.0)) and abs(small[..., :3].mean() - lin[..., :3].mean()) < 0.03
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/assets"), reason="the reference's assets are only present in the build container")
+def test_every_png_the_reference_ships_decodes_like_pil():
+    from PIL import Image
+    import glob
+    files = sorted(glob.glob("/root/reference/assets/**/*.png", recursive=True))
+    assert len(files) >= 40
+    for f in files:
+        want = np.asarray(Image.open(f).convert("RGBA"))
+        assert np.array_equal(H.load_png(f), want), f
