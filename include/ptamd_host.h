@@ -54,6 +54,18 @@ pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int b
  * or one override material for everything (null = use the MTL). */
 pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
     const float scale[3], int builder, const char* bvhCacheFile);
+/* UniqueTextureArray (src/opencl/texture.h:18-31): the texture files a scene's materials use, each once; the index is the
+ * material's tex_id = the layer of the material texture array.  pth_mesh_from_obj_textured registers the map_Kd file of
+ * every non-emissive MTL material there and makes it Material::Diffuse(tex_id, Kd) (src/model/mesh.cpp:61-66); load the
+ * layers with pth_image_load_material_png at the array's size (1024 x 1024 in the reference, src/raytracer.cpp:284). */
+typedef struct pth_texture_files pth_texture_files;
+pth_texture_files* pth_texture_files_create(void);
+void pth_texture_files_destroy(pth_texture_files* t);
+int pth_texture_files_add(pth_texture_files* t, const char* path, int isLinear, float brightnessMultiplier); /* the id; same file, same id */
+int pth_texture_files_count(const pth_texture_files* t);
+const char* pth_texture_files_path(const pth_texture_files* t, int index, int* isLinear, float* brightnessMultiplier);
+pth_mesh* pth_mesh_from_obj_textured(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
+    const float scale[3], int builder, const char* bvhCacheFile, pth_texture_files* textures);
 void pth_mesh_destroy(pth_mesh* m);
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out);
 int pth_mesh_copy_bvh(const pth_mesh* m, pt_sub_bvh_node* nodes, pt_triangle* triangles, uint32_t* originalTriangle);

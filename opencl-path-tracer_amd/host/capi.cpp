@@ -91,8 +91,35 @@ pth_mesh* pth_mesh_from_ply(const char* path, const pt_material* material, int b
     return rc == 0 ? (pth_mesh*)h : nullptr;
 }
 
+pth_texture_files* pth_texture_files_create(void) { return (pth_texture_files*)new UniqueTextureFiles(); }
+void pth_texture_files_destroy(pth_texture_files* t) { delete (UniqueTextureFiles*)t; }
+int pth_texture_files_add(pth_texture_files* t, const char* path, int isLinear, float brightnessMultiplier)
+{
+    int id = -1;
+    guarded([&] { id = ((UniqueTextureFiles*)t)->add(path, isLinear != 0, brightnessMultiplier); });
+    return id;
+}
+int pth_texture_files_count(const pth_texture_files* t) { return t ? (int)((const UniqueTextureFiles*)t)->files().size() : 0; }
+const char* pth_texture_files_path(const pth_texture_files* t, int index, int* isLinear, float* brightnessMultiplier)
+{
+    const auto& files = ((const UniqueTextureFiles*)t)->files();
+    if (!t || index < 0 || (size_t)index >= files.size())
+        return nullptr;
+    if (isLinear)
+        *isLinear = files[index].isLinear ? 1 : 0;
+    if (brightnessMultiplier)
+        *brightnessMultiplier = files[index].brightnessMultiplier;
+    return files[index].path.c_str();
+}
+
 pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
     const float scale[3], int builder, const char* bvhCacheFile)
+{
+    return pth_mesh_from_obj_textured(path, overrideMaterial, location, orientation_wxyz, scale, builder, bvhCacheFile, nullptr);
+}
+
+pth_mesh* pth_mesh_from_obj_textured(const char* path, const pt_material* overrideMaterial, const float location[3], const float orientation_wxyz[4],
+    const float scale[3], int builder, const char* bvhCacheFile, pth_texture_files* textures)
 {
     MeshHandle* h = nullptr;
     int rc = guarded([&] {
@@ -106,7 +133,8 @@ pth_mesh* pth_mesh_from_obj(const char* path, const pt_material* overrideMateria
             t.orientation = quat { orientation_wxyz[0], orientation_wxyz[1], orientation_wxyz[2], orientation_wxyz[3] };
         if (scale)
             t.scale = vec3(scale[0], scale[1], scale[2]);
-        h = new MeshHandle { Mesh::fromOBJ(path, overrideMaterial ? &m : nullptr, t, (BvhBuilder)builder, bvhCacheFile ? std::string(bvhCacheFile) : std::string()) };
+        h = new MeshHandle { Mesh::fromOBJ(path, overrideMaterial ? &m : nullptr, t, (BvhBuilder)builder, bvhCacheFile ? std::string(bvhCacheFile) : std::string(),
+            (UniqueTextureFiles*)textures) };
     });
     return rc == 0 ? (pth_mesh*)h : nullptr;
 }

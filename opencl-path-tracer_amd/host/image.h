@@ -7,6 +7,7 @@
 // same-size images pass through exactly.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -37,5 +38,29 @@ ImageRGBA8 loadPNG(const std::string& path);
 // alpha kept (alpha-0 texels are cut-outs, shading.cl:587-601).  Returns what read_imagef yields for those bytes
 // (value / 255), rows bottom-up.
 ImageRGBAF loadMaterialLayer(const std::string& path, uint32_t width, uint32_t height, bool isLinear);
+
+// UniqueTextureArray (src/opencl/texture.h:18-31, texture.cpp:9-24): the files a scene's materials refer to, each
+// once, in first-use order; the index is the material's tex_id = the layer of the texture array.
+struct TextureFile {
+    std::string path;
+    bool isLinear = false;
+    float brightnessMultiplier = 1.0f;
+};
+class UniqueTextureFiles {
+public:
+    int add(const std::string& path, bool isLinear = false, float brightnessMultiplier = 1.0f)
+    {
+        auto it = m_lookup.find(path);
+        if (it != m_lookup.end())
+            return it->second;
+        m_files.push_back({ path, isLinear, brightnessMultiplier });
+        return m_lookup[path] = (int)m_files.size() - 1;
+    }
+    const std::vector<TextureFile>& files() const { return m_files; }
+
+private:
+    std::vector<TextureFile> m_files;
+    std::map<std::string, int> m_lookup;
+};
 
 } // namespace raytracer

@@ -171,6 +171,7 @@ namespace {
 struct MtlEntry {
     vec3 kd { 0.6f, 0.6f, 0.6f }; // Assimp's default diffuse colour
     vec3 ke { 0.0f, 0.0f, 0.0f };
+    std::string mapKd; // diffuse texture, as written in the file
 };
 
 std::map<std::string, MtlEntry> readMtl(const std::string& path)
@@ -190,6 +191,14 @@ std::map<std::string, MtlEntry> readMtl(const std::string& path)
             vec3 c;
             if (ls >> c.x >> c.y >> c.z)
                 (tag == "Kd" ? out[cur].kd : out[cur].ke) = c;
+        } else if (!cur.empty() && tag == "map_Kd") {
+            std::string rest, word; // options (-s, -o, -bm ...) come first, the file name last
+            while (ls >> word)
+                rest = word;
+            for (char& ch : rest)
+                if (ch == '\\')
+                    ch = '/';
+            out[cur].mapKd = rest;
         }
     }
     return out;
@@ -197,7 +206,7 @@ std::map<std::string, MtlEntry> readMtl(const std::string& path)
 } // namespace
 
 std::shared_ptr<Mesh> Mesh::fromOBJ(const std::string& path, const Material* overrideMaterial, const Transform& offset, BvhBuilder builder,
-    const std::string& bvhCacheFile)
+    const std::string& bvhCacheFile, UniqueTextureFiles* textures)
 {
     std::ifstream in(path);
     if (!in)
@@ -220,7 +229,12 @@ std::shared_ptr<Mesh> Mesh::fromOBJ(const std::string& path, const Material* ove
             if (it == materialOf.end()) {
                 const MtlEntry e = mtl.count(name) ? mtl[name] : MtlEntry {};
                 const bool emissive = e.ke.x != 0.0f || e.ke.y != 0.0f || e.ke.z != 0.0f; // mesh.cpp:58
-                materials.push_back(emissive ? Material::Emissive(e.ke) : Material::Diffuse(e.kd));
+                if (emissive)
+                    materials.push_back(Material::Emissive(e.ke));
+                else if (textures && !e.mapKd.empty()) // mesh.cpp:61-66
+                    materials.push_back(Material::Diffuse(textures->add(folder + e.mapKd), e.kd));
+                else
+                    materials.push_back(Material::Diffuse(e.kd));
                 it = materialOf.emplace(name, (uint32_t)materials.size() - 1).first;
             }
             curMaterial = it->second;

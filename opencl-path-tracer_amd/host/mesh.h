@@ -4,6 +4,7 @@
 #pragma once
 #include "aabb.h"
 #include "bvh_build.h"
+#include "image.h"
 #include "material.h"
 #include "transform.h"
 #include <memory>
@@ -44,10 +45,11 @@ public:
     // polygons are triangulated, points and lines dropped, identical (position, uv, normal) corners welded,
     // `offset` is baked into the positions and its inverse-transpose into the normals (mesh.cpp:76-82), missing
     // normals are generated smooth.  Materials: `overrideMaterial` for everything, else per `usemtl` group
-    // Ke != 0 -> Material::Emissive(Ke), otherwise Material::Diffuse(Kd) (mesh.cpp:51-70; a map_Kd texture needs an
-    // image decoder and is ignored: the colour stays Kd).  `bvhCacheFile`: see storeBvh.
+    // Ke != 0 -> Material::Emissive(Ke), otherwise Material::Diffuse(Kd), or Material::Diffuse(textures->add(map_Kd file), Kd)
+    // when the material has a diffuse map and a texture registry is given (mesh.cpp:51-70; paths relative to the OBJ's
+    // folder).  `bvhCacheFile`: see storeBvh.
     static std::shared_ptr<Mesh> fromOBJ(const std::string& path, const Material* overrideMaterial = nullptr, const Transform& offset = Transform(),
-        BvhBuilder builder = BvhBuilder::SpatialSplit, const std::string& bvhCacheFile = "");
+        BvhBuilder builder = BvhBuilder::SpatialSplit, const std::string& bvhCacheFile = "", UniqueTextureFiles* textures = nullptr);
 
     const std::vector<VertexSceneData>& getVertices() const override { return m_vertices; }
     const std::vector<TriangleSceneData>& getTriangles() const override { return m_bvh.triangles; }

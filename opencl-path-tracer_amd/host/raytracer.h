@@ -39,6 +39,15 @@ struct TextureArray {
         img = loadSkydomeLayer(hdrFile, width, height, brightnessMultiplier);
         return add(img.rgba.data(), img.width, img.height);
     }
+    // CLTextureArray(files, ..., width, height, storeAsFloat = false): every registered file as a layer of that size
+    static TextureArray fromFiles(const UniqueTextureFiles& files, uint32_t w, uint32_t h)
+    {
+        TextureArray t;
+        t.width = w, t.height = h;
+        for (const TextureFile& f : files.files())
+            t.addMaterial(f.path, f.isLinear);
+        return t;
+    }
     // UniqueTextureArray::add(filePath, isLinear) for the 8-bit material array (PNG files: every texture the reference ships)
     int addMaterial(const std::string& pngFile, bool isLinear = false)
     {

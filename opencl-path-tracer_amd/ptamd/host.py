@@ -51,6 +51,14 @@ def lib():
         _lib.pth_mesh_from_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
         _lib.pth_mesh_from_obj.restype = C.c_void_p
         _lib.pth_mesh_from_obj.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        _lib.pth_mesh_from_obj_textured.restype = C.c_void_p
+        _lib.pth_mesh_from_obj_textured.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+        _lib.pth_texture_files_create.restype = C.c_void_p
+        _lib.pth_texture_files_destroy.argtypes = [C.c_void_p]
+        _lib.pth_texture_files_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float]
+        _lib.pth_texture_files_count.argtypes = [C.c_void_p]
+        _lib.pth_texture_files_path.restype = C.c_char_p
+        _lib.pth_texture_files_path.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         _lib.pth_mesh_copy_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         _lib.pth_mesh_destroy.argtypes = [C.c_void_p]
         _lib.pth_mesh_info.argtypes = [C.c_void_p, C.POINTER(MeshStats)]
@@ -115,12 +123,13 @@ class Mesh:
         return Mesh(None, None, None, builder=builder, _handle=h)
 
     @staticmethod
-    def from_obj(path, material=None, location=None, orientation_wxyz=None, scale=None, builder=BVH_SPATIAL_SPLIT, bvh_cache=None):
-        """Wavefront OBJ (+ MTL) import with the reference's material mapping (src/model/mesh.cpp:36-200)."""
+    def from_obj(path, material=None, location=None, orientation_wxyz=None, scale=None, builder=BVH_SPATIAL_SPLIT, bvh_cache=None, textures=None):
+        """Wavefront OBJ (+ MTL) import with the reference's material mapping (src/model/mesh.cpp:36-200); `textures`: a
+        TextureFiles registry that receives the map_Kd files (their index becomes the material's tex_id)."""
         mat = None if material is None else np.ascontiguousarray(np.asarray(material, dtype=L.MATERIAL).reshape(1))
         loc, rot, scl = _f32(location, (3,)), _f32(orientation_wxyz, (4,)), _f32(scale, (3,))
-        h = lib().pth_mesh_from_obj(str(path).encode(), _ptr(mat), _ptr(loc), _ptr(rot), _ptr(scl), builder,
-                                    None if bvh_cache is None else str(bvh_cache).encode())
+        h = lib().pth_mesh_from_obj_textured(str(path).encode(), _ptr(mat), _ptr(loc), _ptr(rot), _ptr(scl), builder,
+                                             None if bvh_cache is None else str(bvh_cache).encode(), None if textures is None else textures._h)
         if not h:
             _err("pth_mesh_from_obj")
         return Mesh(None, None, None, builder=builder, _handle=h)
@@ -310,3 +319,33 @@ def load_material_png(path, width=None, height=None, is_linear=False):
     if lib().pth_image_load_material_png(str(path).encode(), width, height, int(is_linear), _ptr(out)):
         _err("pth_image_load_material_png")
     return out
+
+
+class TextureFiles:
+    """UniqueTextureArray (reference src/opencl/texture.h:18-31): texture files, each once; index = material tex_id."""
+
+    def __init__(self):
+        self._h = lib().pth_texture_files_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().pth_texture_files_destroy(self._h)
+            self._h = None
+
+    def add(self, path, is_linear=False, brightness=1.0):
+        return lib().pth_texture_files_add(self._h, str(path).encode(), int(is_linear), float(brightness))
+
+    def files(self):
+        out = []
+        for i in range(lib().pth_texture_files_count(self._h)):
+            lin, br = C.c_int(0), C.c_float(0)
+            out.append((lib().pth_texture_files_path(self._h, i, C.byref(lin), C.byref(br)).decode(), bool(lin.value), br.value))
+        return out
+
+    def load(self, width=1024, height=1024):
+        """[layers][height][width][4] float32 for pt_upload_texture_array kind 0 (CLTextureArray ctor, 1024x1024 in the
+        reference, src/raytracer.cpp:284); one zero layer when there is no file (std::max(1, arrayLength), texture.cpp:141)."""
+        fs = self.files()
+        if not fs:
+            return np.zeros((1, height, width, 4), np.float32)
+        return np.concatenate([load_material_png(p, width, height, lin) for p, lin, _ in fs])

@@ -100,6 +100,38 @@ def test_production_render_matches_oracle(gpu, case):
     ctx.close()
 
 
+def test_obj_with_png_diffuse_map_renders_like_the_oracle(gpu, tmp_path):
+    """The asset path end to end: Wavefront OBJ + MTL with a map_Kd PNG (alpha cut-out band included) through
+    Mesh.from_obj / TextureFiles.load into the Cornell room, rendered on the GPU and by the oracle from the same arrays."""
+    from PIL import Image
+    from ptamd import host as H
+    rng = np.random.default_rng(8)
+    tex = rng.integers(40, 255, (32, 32, 4), dtype=np.uint8)
+    tex[..., 3] = 255
+    tex[12:20, :, 3] = 0  # rays pass straight through this band (shading.cl:587-601)
+    Image.fromarray(tex).save(tmp_path / "card.png")
+    (tmp_path / "card.mtl").write_text("newmtl card\nKd 1 1 1\nmap_Kd card.png\n")
+    (tmp_path / "card.obj").write_text("mtllib card.mtl\nv -0.6 0.4 0\nv 0.6 0.4 0\nv 0.6 1.6 0\nv -0.6 1.6 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 -1\n"
+                                       "usemtl card\nf 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    tf = H.TextureFiles()
+    card = H.Mesh.from_obj(tmp_path / "card.obj", builder=H.BVH_BINNED_SAH, textures=tf)
+    b = scenes.cornell_box(96, 54)
+    b.scene.add_node(card, location=(0.0, 0.0, -0.6))
+    b = scenes.SceneBundle(b.scene, b.camera, 96, 54, material_textures=tf.load(64, 64), name="card")
+    spp = 32
+    ctx = U.make_ctx(gpu, b, 96, 54, seed=4, samples_in_flight=1)
+    ctx.render(spp)
+    a, st = ctx.read_accum()[:, :3], ctx.stats()
+    ref, cnt = O.render(U.oracle_scene(b), b.camera, 96, 54, spp, seed=4, threads=8)
+    ref = ref[:, :3]
+    for k, ck in (("rays_extension", "raysExtension"), ("rays_shadow", "raysShadow"), ("shade_hits", "shadeHits")):
+        assert abs(st[k] - cnt[ck]) <= 1e-3 * cnt[ck] + 2, (k, st[k], cnt[ck])
+    assert abs(a.mean() - ref.mean()) / ref.mean() < 1e-3
+    assert np.isclose(a, ref, rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1).mean() > 0.97
+    assert U.rmse(U.tonemap(a, spp, b.camera), U.tonemap(ref, spp, b.camera)) < 5e-3
+    ctx.close()
+
+
 def test_determinism_batching_refill_and_tiles(gpu):
     b = scenes.instanced_grid(96, 54, level=3, sky_size=(64, 32))
 

@@ -400,3 +400,41 @@ def test_every_png_the_reference_ships_decodes_like_pil():
     for f in files:
         want = np.asarray(Image.open(f).convert("RGBA"))
         assert np.array_equal(H.load_png(f), want), f
+
+
+def test_obj_diffuse_maps_register_texture_files_like_the_reference(tmp_path):
+    """addSubMesh (reference src/model/mesh.cpp:61-66): a non-emissive material with a diffuse map becomes
+    Material::Diffuse(textureArray.add(folder / map_Kd), Kd); UniqueTextureArray::add gives one id per file
+    (src/opencl/texture.cpp:9-19); the array is then loaded at one fixed layer size."""
+    from PIL import Image
+    (tmp_path / "tex").mkdir()
+    a = np.zeros((8, 8, 3), np.uint8)
+    a[..., 0] = 255
+    Image.fromarray(a).save(tmp_path / "tex" / "red.png")
+    b = np.zeros((4, 16, 4), np.uint8)
+    b[..., 1] = 128
+    b[..., 3] = 255
+    b[0, :, 3] = 0
+    Image.fromarray(b).save(tmp_path / "green.png")
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd tex\\red.png\nnewmtl b\nKd 0.5 0.5 0.5\nmap_Kd -s 1 1 1 green.png\n"
+                                    "newmtl c\nKd 0.2 0.2 0.2\nnewmtl d\nmap_Kd tex/red.png\nnewmtl lamp\nKe 1 1 1\nmap_Kd green.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
+                                    + "".join(f"usemtl {n}\nf 1/1 2/2 3/3\n" for n in "abcd") + "usemtl lamp\nf 1/1 2/2 3/3\n")
+    tf = H.TextureFiles()
+    m = H.Mesh.from_obj(tmp_path / "m.obj", builder=H.BVH_BINNED_SAH, textures=tf)
+    mats = m.geometry()[1]
+    assert [int(x) for x in mats["textureId"][:4]] == [0, 1, -1, 0] and mats[4]["type"] == L.MAT_EMISSIVE
+    assert np.allclose(mats[1]["colour"][:3], 0.5)
+    files = tf.files()
+    assert [os.path.basename(p) for p, _, _ in files] == ["red.png", "green.png"] and not files[0][1]
+    assert tf.add(files[0][0]) == 0 and tf.add(tmp_path / "other.png", is_linear=True) == 2  # same file, same id
+    tf2 = H.TextureFiles()
+    H.Mesh.from_obj(tmp_path / "m.obj", builder=H.BVH_BINNED_SAH, textures=tf2)
+    layers = tf2.load(16, 8)
+    assert layers.shape == (2, 8, 16, 4)
+    assert np.allclose(layers[0, ..., 0], 1.0) and np.allclose(layers[0, ..., 1:3], 0.0) and np.allclose(layers[0, ..., 3], 1.0)
+    g = np.floor(255.0 * (128 / 255.0) ** 2.2 + 0.5) / 255.0  # FreeImage_AdjustGamma(1 / 2.2) on the rescaled bytes
+    assert np.allclose(layers[1, 0, :, 1], g) and layers[1, -1, :, 3].max() < 0.5 and np.allclose(layers[1, 0, :, 3], 1.0)  # bottom-up: the cut-out row is last
+    assert H.TextureFiles().load(4, 4).shape == (1, 4, 4, 4)  # an empty registry still makes one layer
+    # without a registry the map is ignored and the colour stays Kd
+    assert (H.Mesh.from_obj(tmp_path / "m.obj", builder=H.BVH_BINNED_SAH).geometry()[1]["textureId"][:4] == -1).all()
