@@ -438,3 +438,23 @@ def test_obj_diffuse_maps_register_texture_files_like_the_reference(tmp_path):
     assert H.TextureFiles().load(4, 4).shape == (1, 4, 4, 4)  # an empty registry still makes one layer
     # without a registry the map is ignored and the colour stays Kd
     assert (H.Mesh.from_obj(tmp_path / "m.obj", builder=H.BVH_BINNED_SAH).geometry()[1]["textureId"][:4] == -1).all()
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/assets/3dmodels/plane/plane.obj"), reason="the reference's assets are only present in the build container")
+def test_the_reference_light_plane_imports_as_main_cpp_uses_it():
+    """main.cpp:131: Mesh(assets/3dmodels/plane/plane.obj, Material::Emissive(5500 K, 1000 lm), textureArray) -- two
+    emissive triangles; without the override its `usemtl Material.001` is not in plane.mtl, i.e. the default grey."""
+    f = "/root/reference/assets/3dmodels/plane/plane.obj"
+    m = H.Mesh.from_obj(f, material=L.material_emissive((1.0, 0.9, 0.8), 1000.0), builder=H.BVH_BINNED_SAH)
+    st = m.stats()
+    assert st["num_input_triangles"] == 2 and st["num_vertices"] == 4 and st["all_triangles_referenced"]
+    verts, mats = m.geometry()
+    assert len(mats) == 1 and mats[0]["type"] == L.MAT_EMISSIVE
+    assert np.allclose(np.abs(verts["vertex"][:, [0, 2]]), 1.0) and np.abs(verts["vertex"][:, 1]).max() < 1e-4
+    sc = H.Scene()
+    sc.add_node(m, location=(0.0, 3.0, 0.0))
+    flat = sc.flatten()
+    assert len(flat.lights) == 2 and np.allclose(flat.lights["vertices"][..., 1], 3.0, atol=1e-4)
+    tf = H.TextureFiles()
+    plain = H.Mesh.from_obj(f, builder=H.BVH_BINNED_SAH, textures=tf).geometry()[1]
+    assert plain[0]["type"] == L.MAT_DIFFUSE and np.allclose(plain[0]["colour"][:3], 0.6) and tf.files() == []
