@@ -72,11 +72,16 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
     uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
     for (;;) {
         if (spanLeft == 0u) {
+            uint32_t claim = kSpan;
+#if PT_GUIDED_SPANS
+            const uint32_t left = packets > spanBase ? packets - spanBase : 0u; // spanBase lags the cursor: an upper bound
+            claim = min(kSpan, max(1u, left / (totalWaves * PT_GUIDED_SPANS)));
+#endif
             uint32_t b = 0;
             if (lane == 0)
-                b = atomicAdd(a.cursor, kSpan);
+                b = atomicAdd(a.cursor, claim);
             spanBase = totalWaves * kSpan + uni(b);
-            spanLeft = kSpan;
+            spanLeft = claim;
         }
         if (spanBase >= packets)
             break;

@@ -41,6 +41,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_TRACE_MIN_WAVES
 #define PT_TRACE_MIN_WAVES 7
 #endif
+#ifndef PT_GUIDED_SPANS
+#define PT_GUIDED_SPANS 1 // > 0: a claim takes at most (entries left) / (waves x this); 0 / 1 / 2 / 4: 8.47 / 8.52 / 8.50 / 8.43 Grays/s
+#endif
 #ifndef PT_PARKED_BREAK
 #define PT_PARKED_BREAK 24
 #endif
@@ -169,13 +172,21 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     auto requestPacket = [&]() {
         if (spanNext >= spanEnd) {
             uint32_t base = 0xFFFFFFC0u; // "nothing left"
+            uint32_t claim = spanSize;
+#if PT_GUIDED_SPANS
+            // guided self-scheduling: towards the end of the queue claim less, so that no wave is left with a long
+            // span while the others have run dry (`spanEnd`, this wave's previous claim, lags the cursor: an upper
+            // bound of what is left)
+            const uint32_t left = count > spanEnd ? count - spanEnd : 0u;
+            claim = min(spanSize, max(64u, (left / (totalWaves * PT_GUIDED_SPANS)) & ~63u));
+#endif
             if (gwave * 64u < count) { // otherwise even the static packets were not all needed: no dynamic part
                 if (lane == 0)
-                    base = atomicAdd(a.cursor, spanSize);
+                    base = atomicAdd(a.cursor, claim);
                 base = totalWaves * 64u + __shfl(base, 0);
             }
             spanNext = base;
-            spanEnd = base + spanSize;
+            spanEnd = base + claim;
         }
         const uint32_t base = spanNext;
         spanNext += 64u;
