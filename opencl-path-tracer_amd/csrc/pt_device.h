@@ -77,8 +77,7 @@ struct Instance {
     float4 r0, r1, r2; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major matrix
     uint32_t rootRef; // makeRef
     uint32_t topNode; // index of the top-level leaf (reported as `inst` in hit records)
-    uint32_t root8; // node index of the mesh root in the 8-wide tree (pt_wide8.h)
-    uint32_t _p1;
+    uint32_t _p0, _p1;
 };
 
 struct Material { // the reference's 48-byte record, read as 3 x float4
@@ -98,16 +97,9 @@ struct Texture {
     int32_t width, height, layers, _pad;
 };
 
-struct Node8;
-struct Node48;
 struct SceneDev {
     const PairNode* nodes; // the reference's binary tree, both boxes per node: host-side intermediate, not uploaded (null)
     const WideNode* wide; // 4-wide tree (k_trace)
-    const Node8* nodes8; // 8-wide compressed tree (k_trace8), its triangles in node order and its top-level items
-    const TriIsect* tris8;
-    const uint32_t* items;
-    const Node48* nodes48; // 48-byte-node tree (k_trace48) and its triangles in node order; null when the scene keeps instances
-    const TriIsect* tris48;
     const TriIsect* tris; // caller's triangle numbering (shading re-reads v0/e1/e2 from here)
     const TriShade* triShade;
     const VertexShade* verts;
@@ -119,7 +111,7 @@ struct SceneDev {
     uint32_t numLights;
     uint32_t rootRef; // reference of the top-level root: a PairNode, or an instance when there is only one
     uint32_t numTriangles;
-    uint32_t root8; // node index of the top-level root in the 8-wide tree
+    uint32_t _pad;
 };
 
 // ---- queues ---------------------------------------------------------------------------------
@@ -144,15 +136,22 @@ enum : uint32_t { FLAG_FINISHED = 1, FLAG_LASTSPECULAR = 2 }; // shading.cl:11-1
 // that there is still exactly one live path per accumulator entry (no atomics, deterministic sums).
 __host__ __device__ inline uint32_t packState(uint32_t flags, uint32_t bounce, uint32_t plane) { return (flags & 0xFFu) | ((bounce & 0xFFu) << 8) | (plane << 16); }
 struct AccumView {
-    float4* plane0; // the HDR accumulator proper (width*height float4)
-    float4* extra; // planes 1.. (scratch, folded into plane0 after every batch): [pixel][plane - 1]
+    float4* plane0; // the HDR accumulator proper (width*height float4, indexed by global pixel)
+    float4* extra; // planes 1.. (scratch, folded into plane0 after every batch): [owned-pixel ordinal][plane - 1]
+    const uint32_t* ordinal; // global pixel -> ordinal among the pixels this context owns; null: the identity (whole frame owned)
     uint32_t perPixel; // extra planes per pixel = samples in flight - 1
-    // The planes of one pixel are adjacent: k_gen hands consecutive queue entries consecutive samples of the SAME
-    // pixel, so the lanes of a wave deposit into one run of memory.
+    // The extra planes exist only for the pixels a context owns (a rank of an N-GPU job holds 1/N of them) and the
+    // planes of one pixel are adjacent: k_gen hands consecutive queue entries consecutive samples of the SAME
+    // pixel, so the lanes of a wave deposit into one run of memory (and read one ordinal).
     __device__ inline float4* at(uint32_t plane, uint32_t pixel) const
     {
-        return plane == 0u ? plane0 + pixel : extra + (size_t)pixel * perPixel + (plane - 1u);
+        if (plane == 0u)
+            return plane0 + pixel;
+        const uint32_t slot = ordinal ? ordinal[pixel] : pixel;
+        return extra + (size_t)slot * perPixel + (plane - 1u);
     }
+    // same, for a caller that already knows the ordinal (k_fold_planes walks the owned pixels in order)
+    __device__ inline float4* atOrdinal(uint32_t plane, uint32_t slot) const { return extra + (size_t)slot * perPixel + (plane - 1u); }
 };
 
 struct CameraDev { // Camera, camera.cl:7-26
@@ -176,7 +175,7 @@ struct Control {
     uint32_t extCursor[kMaxPasses + 1]; // persistent-kernel fetch cursors
     uint32_t shadowCursor[kMaxPasses + 1];
     uint32_t shadeHits[kMaxPasses + 1];
-    uint32_t deposits;
+    uint32_t deposits; // accumulator updates of the sample (k_shade: emissive hits and sky misses; k_trace<true>: unoccluded shadow rays)
     uint32_t generated;
     uint32_t _pad[2];
 };

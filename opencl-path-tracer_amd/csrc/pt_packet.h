@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gwave = (blockIdx.x * kPacketBlock + threadIdx.x) >> 6;
     const uint32_t totalWaves = (gridDim.x * kPacketBlock) >> 6;
-    const uint32_t count = *a.count;
+    const uint32_t count = ANY_HIT ? a.ctl->shadowCount[a.pass] : a.ctl->extCount[a.pass];
     const SceneDev& sc = a.sc;
     const uint32_t packets = (count + 63u) >> 6;
     const uint32_t rootRef = uni(sc.rootRef);
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
 #endif
             uint32_t b = 0;
             if (lane == 0)
-                b = atomicAdd(a.cursor, claim);
+                b = atomicAdd(ANY_HIT ? &a.ctl->shadowCursor[a.pass] : &a.ctl->extCursor[a.pass], claim);
             spanBase = totalWaves * kSpan + uni(b);
             spanLeft = claim;
         }
@@ -225,6 +225,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
 
         // -------- results: consecutive lanes write consecutive records (scene.cl:257) --------------------------
         if (ANY_HIT) {
+            const uint32_t nDep = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));
+            if (lane == 0 && nDep)
+                atomicAdd(&a.ctl->deposits, nDep);
             if (active) {
                 if (a.occluded)
                     a.occluded[idx] = 0u;

@@ -484,6 +484,7 @@ struct ShadeArgs {
     uint32_t* outCount;
     uint32_t* shadowCount;
     uint32_t* shadeHits;
+    uint32_t* deposits; // accumulator updates made here (emissive hits seen through a specular chain, sky misses)
     uint4* streams; // parity mode
     // parity mode: un-compacted staging + active flags for the stable compaction pass
     uint32_t* activeFlag;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t count = *a.inCount;
-    bool emitRay = false, emitShadow = false, shaded = false;
+    bool emitRay = false, emitShadow = false, shaded = false, deposited = false;
     ShadeResult r;
     uint32_t pixel = 0, bounce = 0, plane = 0;
     if (i < count) {
@@ -534,6 +535,7 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
                     float4 px = *ap;
                     px.x += r.radiance.x, px.y += r.radiance.y, px.z += r.radiance.z;
                     *ap = px;
+                    deposited = true;
                 }
                 bounce += 1;
                 if (bounce >= a.fp.maxBounces) // kernel.cl:295-296
@@ -546,10 +548,14 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
                 float4 px = *ap;
                 px.x += c.x, px.y += c.y, px.z += c.z;
                 *ap = px;
+                deposited = true;
             }
         }
     }
     if (PARITY) {
+        const uint32_t nDep = (uint32_t)__popcll(__ballot(deposited));
+        if (lane == 0 && nDep)
+            atomicAdd(a.deposits, nDep);
         // stage at the input slot; k_compact_stable assigns output indices in slot order
         if (i < count)
             a.activeFlag[i] = shaded ? 1u : 0u;
@@ -570,26 +576,28 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     // kShadeBlock entries) against waves idling at the two barriers: 1024 / 768 / 640 / 512 / 384 / 256 threads ->
     // 17.8 / 20.1 / 22.3 / 14.3 / 17.4 / 16.3 ms of k_shade per 128-sample batch at 1080p (256-thread blocks sit
     // exactly on the atomic rate: 1.36 M blocks per word in 16 ms = 85 atomics/us).
-    __shared__ uint32_t sCount[kShadeBlock / 64][3];
-    __shared__ uint32_t sBase[3];
+    __shared__ uint32_t sCount[kShadeBlock / 64][4];
+    __shared__ uint32_t sBase[4];
     const unsigned long long mRay = __ballot(emitRay);
     const unsigned long long mSh = __ballot(emitShadow);
     const unsigned long long mHit = __ballot(shaded);
+    const unsigned long long mDep = __ballot(deposited);
     const uint32_t wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
     if (lane == 0) {
         sCount[wave][0] = (uint32_t)__popcll(mRay);
         sCount[wave][1] = (uint32_t)__popcll(mSh);
         sCount[wave][2] = (uint32_t)__popcll(mHit);
+        sCount[wave][3] = (uint32_t)__popcll(mDep);
     }
     __syncthreads();
-    if (threadIdx.x < 3) { // thread q: exclusive prefix of queue q over the waves + the block's atomic
+    if (threadIdx.x < 4) { // thread q: exclusive prefix of queue q over the waves + the block's atomic
         uint32_t sum = 0;
         for (uint32_t w = 0; w < nWaves; w++) {
             const uint32_t n = sCount[w][threadIdx.x];
             sCount[w][threadIdx.x] = sum;
             sum += n;
         }
-        uint32_t* counter = threadIdx.x == 0 ? a.outCount : (threadIdx.x == 1 ? a.shadowCount : a.shadeHits);
+        uint32_t* counter = threadIdx.x == 0 ? a.outCount : (threadIdx.x == 1 ? a.shadowCount : (threadIdx.x == 2 ? a.shadeHits : a.deposits));
         sBase[threadIdx.x] = sum ? atomicAdd(counter, sum) : 0u;
     }
     __syncthreads();
@@ -693,9 +701,10 @@ __global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t pla
     const bool live = k < numOwned; // numOwned * kFoldLanes need not fill the last wave; its lanes still take part in the shuffles
     const uint32_t i = live ? (pixels ? pixels[k] : k) : 0u;
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    const uint32_t slot = acc.ordinal ? k : i; // the ordinal of the k-th owned pixel is k
     if (live)
         for (uint32_t p = 1u + part; p < planes; p += kFoldLanes) {
-            float4* e = acc.at(p, i);
+            float4* e = acc.atOrdinal(p, slot);
             const float4 v = *e;
             sx += v.x, sy += v.y, sz += v.z;
             *e = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -736,7 +745,9 @@ __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
     tot->raysShadow += sh;
     tot->shadeHits += hits;
     tot->raysGenerated += ctl->generated;
+    tot->deposits += ctl->deposits;
     ctl->generated = 0;
+    ctl->deposits = 0;
 }
 
 } // namespace ptd

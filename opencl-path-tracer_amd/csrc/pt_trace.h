@@ -78,8 +78,12 @@ struct TraceArgs {
     int32_t* inst;
     AccumView accum;
     uint32_t* occluded; // optional (test hook): 1/0 per shadow ray
-    const uint32_t* count; // number of queue entries (device word)
-    uint32_t* cursor; // fetch cursor (device word, zero at launch)
+    // queue words of this launch, all in the sample's control block (one pointer + the pass index instead of three
+    // pointers: the any-hit kernel sits at the scalar-register limit of 7 waves per SIMD):
+    //   entries in the queue  ctl->extCount[pass] / shadowCount[pass]; fetch cursor (zero at launch)  ctl->extCursor[pass] /
+    //   shadowCursor[pass]; any-hit launches add their unoccluded rays (= accumulator updates) to ctl->deposits
+    Control* ctl;
+    uint32_t pass;
     uint32_t* spill; // kSpillStack * totalThreads dwords
     uint32_t totalThreads;
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
@@ -109,13 +113,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
     __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
+    // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
+    // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
+    __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
 #define spill (a.spill + gtid) /* entry e at spill[e * totalThreads]; recomputed where used (rare) to save two registers */
     const uint32_t total = a.totalThreads;
-    const uint32_t count = *a.count;
+    const uint32_t count = ANY_HIT ? a.ctl->shadowCount[a.pass] : a.ctl->extCount[a.pass];
     const SceneDev& sc = a.sc;
+    if (ANY_HIT && lane == 0)
+        ldsDeposits[wave] = 0u;
 
     auto push = [&](int slot, uint32_t v) {
         if (slot < kLdsStack)
@@ -182,7 +191,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 #endif
             if (gwave * 64u < count) { // otherwise even the static packets were not all needed: no dynamic part
                 if (lane == 0)
-                    base = atomicAdd(a.cursor, claim);
+                    base = atomicAdd(ANY_HIT ? &a.ctl->shadowCursor[a.pass] : &a.ctl->extCursor[a.pass], claim);
                 base = totalWaves * 64u + __shfl(base, 0);
             }
             spanNext = base;
@@ -223,7 +232,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     if (!active && rank < avail) {
                         const uint32_t idx = poolBase + (uint32_t)e;
                         float tMax = ANY_HIT ? ro.w : INFINITY;
-                        asm volatile("" : "+v"(tMax)); // own register (see the note in k_trace8 about the flag load below)
+                        asm volatile("" : "+v"(tMax)); // own register: hipcc 7.2 otherwise lets the flag load below alias ro.w and drops the tClosest assignment
                         uint32_t state = asU(rd.w); // closest-hit: parity mode keeps finished rays in the queue
                         if (ANY_HIT) // contribution and pixel stay in the queue until the ray turns out unoccluded
                             state = a.parityShadow ? asU(a.rayC[idx].w) : 0u;
@@ -282,6 +291,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 break;
             PT_STAT(4, 1);
             PT_STAT(7, __popcll(m));
+            if (ANY_HIT) { // a shadow ray only gets here unoccluded (an occluded one retires in its leaf step)
+                const uint32_t nFin = (uint32_t)__popcll(__ballot(wantSpecial && refIndex(cur) == kSpecialFinish));
+                if (lane == 0)
+                    ldsDeposits[wave] += nFin;
+            }
             if (wantSpecial) {
                 const uint32_t what = refIndex(cur);
                 if (what == kSpecialFinish) {
@@ -512,6 +526,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             }
         }
     }
+    if (ANY_HIT && lane == 0 && ldsDeposits[wave])
+        atomicAdd(&a.ctl->deposits, ldsDeposits[wave]);
     PT_TOC(10, tKernel);
 #ifdef PT_TRACE_STATS
     if (lane == 0)

@@ -5,11 +5,6 @@
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_packet.h"
-#include "pt_trace8.h"
-#include "pt_trace48.h"
-#ifndef PT_NODE48
-#define PT_NODE48 0 // 1: 48-byte nodes (pt_wide48.h, k_trace48) for scenes without two-level instances; measured slower
-#endif
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
 #endif
@@ -20,6 +15,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -75,12 +72,6 @@ struct pt_ctx {
     // scene (HBM)
     DevBuf<PairNode> nodes;
     DevBuf<WideNode> wide;
-    DevBuf<Node8> nodes8;
-    DevBuf<Node48> nodes48;
-    DevBuf<TriIsect> tris48;
-    bool use48 = false; // the uploaded scene has a 48-byte-node tree: k_trace48 traverses it
-    DevBuf<TriIsect> tris8;
-    DevBuf<uint32_t> items;
     DevBuf<TriIsect> tris;
     DevBuf<TriShade> triShade;
     DevBuf<VertexShade> verts;
@@ -100,6 +91,8 @@ struct pt_ctx {
     // frame state
     CameraDev camera {};
     DevBuf<uint32_t> pixelList;
+    DevBuf<uint32_t> pixelOrdinal; // global pixel -> position in pixelList (only when the context owns part of the frame)
+    DevBuf<float4> resolveTmp; // pt_resolve's output staging (allocated at first use)
     uint32_t numOwned = 0;
     uint32_t capacity = 0;
     bool identityPixels = true;
@@ -151,7 +144,24 @@ int fail(pt_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->planes - 1u }; }
+// The bodies below build std::vectors and call std::function; nothing may escape across the C ABI, so every entry
+// point that can allocate runs inside this guard and reports a failure like any other (the host library's capi.cpp
+// does the same).
+template <typename F>
+int guarded(pt_ctx* c, const char* what, F&& body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(c, PT_ERR_UNSUPPORTED, "%s: out of host memory", what);
+    } catch (const std::exception& e) {
+        return fail(c, PT_ERR_INVALID, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(c, PT_ERR_INVALID, "%s: unknown exception", what);
+    }
+}
+
+inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->pixelOrdinal.p, c->planes - 1u }; }
 inline uint32_t maxBounces(const pt_ctx* c) { return c->cfg.max_bounces ? c->cfg.max_bounces : 4u; }
 inline bool parityMode(const pt_ctx* c) { return c->cfg.rng_mode == PT_RNG_LFSR113_PARITY; }
 
@@ -160,11 +170,6 @@ void refreshSceneView(pt_ctx* c)
     SceneDev& s = c->scene;
     s.nodes = c->nodes.p;
     s.wide = c->wide.p;
-    s.nodes8 = c->nodes8.p;
-    s.nodes48 = c->use48 ? c->nodes48.p : nullptr;
-    s.tris48 = c->use48 ? c->tris48.p : nullptr;
-    s.tris8 = c->tris8.p;
-    s.items = c->items.p;
     s.tris = c->tris.p;
     s.triShade = c->triShade.p;
     s.verts = c->verts.p;
@@ -439,10 +444,24 @@ int ensureQueues(pt_ctx* c)
     }
     uint64_t cap64 = c->cfg.max_active_rays ? c->cfg.max_active_rays : (uint64_t)c->numOwned * c->planes;
     if (cap64 > 0x7FFFFFC0ull)
-        return fail(c, PT_ERR_UNSUPPORTED, "queue capacity too large");
+        return fail(c, PT_ERR_UNSUPPORTED, "%llu queue entries (%u owned pixels x %u samples in flight) exceed the 2^31 entries a queue can index: lower samples_in_flight",
+            (unsigned long long)cap64, c->numOwned, c->planes);
     uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;
+    {
+        // Memory budget, checked before anything is allocated so that an oversized configuration fails HERE with a
+        // message instead of somewhere in a later hipMalloc: per queue entry two extension queues (3 x 16 B each), the
+        // shadow queue (3 x 16 B) and the hit records (20 B); per owned pixel one 16-byte accumulator plane for every
+        // extra sample in flight.  (BASELINE config 5 -- 4K, 8 ranks -- at 2 048 samples in flight would be 2.1 G entries.)
+        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0);
+        const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4);
+        size_t freeB = 0, totalB = 0;
+        HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+        if (need > (uint64_t)freeB)
+            return fail(c, PT_ERR_UNSUPPORTED, "queues and accumulator planes need %.1f GB (%u owned pixels x %u samples in flight), %.1f GB of device memory are free: lower samples_in_flight or set max_active_rays",
+                need / 1e9, c->numOwned, c->planes, freeB / 1e9);
+    }
     if (c->planes > 1) {
-        const size_t n = (size_t)(c->planes - 1) * c->cfg.width * c->cfg.height;
+        const size_t n = (size_t)(c->planes - 1) * c->numOwned; // [owned-pixel ordinal][plane - 1]
         HIPCHK(c, c->accumPlanes.alloc(n));
         // stream-ordered: the context's stream is non-blocking, a null-stream memset could still be running (or not
         // have started) when the first kernels of the render write these buffers
@@ -483,11 +502,7 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     int blocksPerCU = 0;
     blocksPerCU = 8;
-#if PT_BVH8
-    const void* variants[4] = { (const void*)k_trace8<false>, (const void*)k_trace8<true>, (const void*)k_trace<false>, (const void*)k_trace<true> };
-#else
-    const void* variants[4] = { (const void*)k_trace<false>, (const void*)k_trace<true>, (const void*)k_trace48<false>, (const void*)k_trace48<true> };
-#endif
+    const void* variants[2] = { (const void*)k_trace<false>, (const void*)k_trace<true> };
     for (const void* fn : variants) {
         int b = 0;
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
@@ -509,29 +524,10 @@ int ensureSpill(pt_ctx* c)
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
     const dim3 grid(c->traceBlocks), block(kTraceBlock);
-#if PT_BVH8
-    if (anyHit) {
-        if (PT_BVH8 & 2)
-            hipLaunchKernelGGL(k_trace8<true>, grid, block, 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
-    } else {
-        if (PT_BVH8 & 1)
-            hipLaunchKernelGGL(k_trace8<false>, grid, block, 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
-    }
-#else
-    if (c->use48) {
-        if (anyHit)
-            hipLaunchKernelGGL(k_trace48<true>, grid, block, 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(k_trace48<false>, grid, block, 0, c->stream, a);
-    } else if (anyHit)
+    if (anyHit)
         hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
     else
         hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
-#endif
 }
 
 TraceArgs traceArgsBase(pt_ctx* c)
@@ -622,8 +618,8 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false)
     a.rayD = c->rays[q].d.p;
     a.hit = c->hitH.p;
     a.inst = c->hitInst.p;
-    a.count = &ctl->extCount[pass];
-    a.cursor = &ctl->extCursor[pass];
+    a.ctl = ctl;
+    a.pass = pass;
     if (coherent && c->packetOk && (c->packetUse & 1u))
         launchPacket(c, false, a);
     else
@@ -638,8 +634,8 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false)
     a.rayD = c->shadow.d.p;
     a.rayC = c->shadow.c.p;
     a.accum = accumView(c);
-    a.count = &ctl->shadowCount[pass];
-    a.cursor = &ctl->shadowCursor[pass];
+    a.ctl = ctl;
+    a.pass = pass;
     if (coherent && c->packetOk && (c->packetUse & 2u))
         launchPacket(c, true, a);
     else
@@ -660,6 +656,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.outCount = &ctl->extCount[pass + 1];
     a.shadowCount = &ctl->shadowCount[pass];
     a.shadeHits = &ctl->shadeHits[pass];
+    a.deposits = &ctl->deposits;
     a.streams = c->streams.p;
     const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock;
     if (parityMode(c)) {
@@ -798,6 +795,7 @@ const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() :
 
 int pt_create(const pt_config* cfg, pt_ctx** out)
 {
+    return guarded(nullptr, "pt_create", [&]() -> int {
     if (!cfg || !out)
         return fail(nullptr, PT_ERR_INVALID, "pt_create: null argument");
     if (cfg->width == 0 || cfg->height == 0 || (uint64_t)cfg->width * cfg->height > 0x7FFFFFFFull)
@@ -851,6 +849,7 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         return rc;
     }
     return PT_OK;
+    });
 }
 
 void pt_destroy(pt_ctx* c)
@@ -866,8 +865,8 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->wide.release(), c->nodes48.release(), c->tris48.release(), c->nodes8.release(), c->tris8.release(), c->items.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
-    c->accumPlanes.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
+    c->wide.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -898,6 +897,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream)
 int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
     uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
 {
+    return guarded(c, "pt_upload_static", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     if (!verts || !tris || !mats || !nodes || nV == 0 || nT == 0 || nM == 0 || nN == 0)
@@ -1042,10 +1042,12 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
     c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
     refreshSceneView(c);
     return PT_OK;
+    });
 }
 
 int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
 {
+    return guarded(c, "pt_upload_dynamic", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     if (!c->haveStatic)
@@ -1305,27 +1307,6 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         for (int k = 0; k < 4; k++)
             if (refCount(w.child[k]) == kRefSpecial)
                 c->packetOk = false;
-#if PT_BVH8
-    // ---- 8-wide compressed tree over the same pair nodes (pt_wide8.h) --------------------------------
-    {
-        std::vector<uint32_t> bottomRoots;
-        for (const Instance& in : hInst)
-            bottomRoots.push_back(in.rootRef);
-        const pt_top_bvh_node& tr = topNodes[topRoot];
-        const Wide8 w8 = buildWide8(hNodes, allTris, bottomRoots, topRef[topRoot], tr.min, tr.max, (uint32_t)c->hostTris.size());
-        std::vector<uint32_t> instRootNode(hInst.size());
-        for (size_t k = 0; k < hInst.size(); k++)
-            instRootNode[k] = hInst[k].root8 = w8.rootOf.at(hInst[k].rootRef);
-        const uint32_t need8 = wide8StackNeed(w8, instRootNode);
-        if (need8 > (uint32_t)(kLdsStack8 + kSpillStack8))
-            return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack groups, %d are available", need8, kLdsStack8 + kSpillStack8);
-        if (w8.nodes.size() > 0x7FFFFFFFu || w8.tris.size() > 0x7FFFFFFFu)
-            return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
-        if ((rc = uploadVec(c, c->nodes8, w8.nodes)) || (rc = uploadVec(c, c->tris8, w8.tris)) || (rc = uploadVec(c, c->items, w8.items)))
-            return rc;
-        c->scene.root8 = w8.topRoot;
-    }
-#endif
     // ---- pack the 4-wide nodes: only the ones the collapse kept (about half of the pair-node indices), each node's
     // children next to each other, level by level from every root -- half the footprint in the 4 MB-per-XCD L2 and
     // sibling nodes share 128-byte lines
@@ -1362,19 +1343,6 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
 #else
     packed = hWide;
 #endif
-    // ---- 48-byte-node tree when nothing two-level is left (pt_wide48.h) ---------------------------------
-    c->use48 = false;
-#if PT_NODE48
-    {
-        const pt_top_bvh_node& tr = topNodes[topRoot];
-        Wide48 w48 = buildWide48(hNodes, allTris, topRef[topRoot], tr.min, tr.max, (uint32_t)c->hostTris.size());
-        if (w48.usable && w48.stackNeed <= (uint32_t)(kLdsStack + kSpillStack)) {
-            if ((rc = uploadVec(c, c->nodes48, w48.nodes)) || (rc = uploadVec(c, c->tris48, w48.tris)))
-                return rc;
-            c->use48 = true;
-        }
-    }
-#endif
     if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
         return rc;
     c->scene.numLights = nL;
@@ -1382,10 +1350,12 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     c->haveDynamic = true;
     refreshSceneView(c);
     return PT_OK;
+    });
 }
 
 int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height, uint32_t layers, const float* rgba)
 {
+    return guarded(c, "pt_upload_texture_array", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     if ((kind != 0 && kind != 1) || !rgba || width == 0 || height == 0 || layers == 0)
@@ -1402,6 +1372,7 @@ int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height
     t.layers = (int)layers;
     refreshSceneView(c);
     return PT_OK;
+    });
 }
 
 int pt_set_camera(pt_ctx* c, const pt_camera* cam)
@@ -1427,6 +1398,7 @@ int pt_set_camera(pt_ctx* c, const pt_camera* cam)
 
 int pt_set_tiles(pt_ctx* c, const pt_rect* rects, uint32_t n)
 {
+    return guarded(c, "pt_set_tiles", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1438,34 +1410,50 @@ int pt_set_tiles(pt_ctx* c, const pt_rect* rects, uint32_t n)
     }
     const bool rowMajor = (c->cfg.flags & PT_FLAG_ROWMAJOR_PIXELS) || parityMode(c);
     std::vector<uint32_t> list;
+    // position of every pixel in the list; doubles as the overlap check: the kernels deposit with a plain
+    // read-modify-write that relies on ONE live path per (plane, pixel), so a pixel listed twice would race
+    constexpr uint32_t kUnowned = 0xFFFFFFFFu;
+    std::vector<uint32_t> ordinal((size_t)W * H, kUnowned);
+    auto add = [&](uint32_t x, uint32_t y) {
+        const uint32_t px = y * W + x;
+        if (ordinal[px] != kUnowned)
+            return false;
+        ordinal[px] = (uint32_t)list.size();
+        list.push_back(px);
+        return true;
+    };
     for (uint32_t r = 0; r < n; r++) {
         const pt_rect& q = rects[r];
         if (q.x0 >= q.x1 || q.y0 >= q.y1 || q.x1 > W || q.y1 > H)
             return fail(c, PT_ERR_INVALID, "pt_set_tiles: rect %u out of bounds", r);
+        bool ok = true;
         if (rowMajor) {
             for (uint32_t y = q.y0; y < q.y1; y++)
                 for (uint32_t x = q.x0; x < q.x1; x++)
-                    list.push_back(y * W + x);
+                    ok = add(x, y) && ok;
         } else { // 8x8 pixel blocks: a 64-lane wave starts on a compact screen-space tile
             for (uint32_t by = q.y0; by < q.y1; by += 8)
                 for (uint32_t bx = q.x0; bx < q.x1; bx += 8)
                     for (uint32_t y = by; y < std::min(by + 8, q.y1); y++)
                         for (uint32_t x = bx; x < std::min(bx + 8, q.x1); x++)
-                            list.push_back(y * W + x);
+                            ok = add(x, y) && ok;
         }
+        if (!ok)
+            return fail(c, PT_ERR_INVALID, "pt_set_tiles: rect %u overlaps an earlier one", r);
     }
-    if (list.size() > (size_t)W * H)
-        return fail(c, PT_ERR_INVALID, "pt_set_tiles: rectangles overlap");
     c->identityPixels = rowMajor && n == 1 && rects[0].x0 == 0 && rects[0].y0 == 0 && rects[0].x1 == W && rects[0].y1 == H;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc = uploadVec(c, c->pixelList, list);
     if (rc)
         return rc;
-    if ((uint32_t)list.size() != c->numOwned || !c->queuesReady) {
-        c->numOwned = (uint32_t)list.size();
-        c->queuesReady = false; // re-size queues lazily
-    }
+    if (list.size() == (size_t)W * H) { // whole frame: the extra accumulator planes are indexed by the pixel itself
+        c->pixelOrdinal.release();
+    } else if ((rc = uploadVec(c, c->pixelOrdinal, ordinal)))
+        return rc;
+    c->numOwned = (uint32_t)list.size();
+    c->queuesReady = false; // the ordinal of a pixel may have changed: queues and planes are re-made lazily (ensureQueues)
     return PT_OK;
+    });
 }
 
 int pt_set_accum_buffer(pt_ctx* c, void* device_float4)
@@ -1479,6 +1467,7 @@ int pt_set_accum_buffer(pt_ctx* c, void* device_float4)
 
 int pt_clear(pt_ctx* c)
 {
+    return guarded(c, "pt_clear", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1490,10 +1479,12 @@ int pt_clear(pt_ctx* c)
             return rc;
     }
     return PT_OK;
+    });
 }
 
 int pt_render(pt_ctx* c, uint32_t spp)
 {
+    return guarded(c, "pt_render", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     if (!c->haveStatic || !c->haveDynamic || !c->haveCamera)
@@ -1525,6 +1516,7 @@ int pt_render(pt_ctx* c, uint32_t spp)
         c->msGen = fam[0], c->msIntersect = fam[1] + fam[4], c->msShade = fam[2], c->msShadow = fam[3], c->msPacket = fam[4];
     }
     return PT_OK;
+    });
 }
 
 int pt_synchronize(pt_ctx* c)
@@ -1537,22 +1529,21 @@ int pt_synchronize(pt_ctx* c)
 
 int pt_resolve(pt_ctx* c, float* rgba_out)
 {
+    return guarded(c, "pt_resolve", [&]() -> int {
     if (!c || !rgba_out)
         return PT_ERR_INVALID;
     if (!c->haveCamera || c->spp == 0)
         return fail(c, PT_ERR_STATE, "pt_resolve: nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n = c->cfg.width * c->cfg.height;
-    DevBuf<float4> tmp;
-    HIPCHK(c, tmp.alloc(n));
-    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, tmp.p, n, (float)c->spp,
+    if (c->resolveTmp.n != n) // once per context: this is the interactive getOutput() path
+        HIPCHK(c, c->resolveTmp.alloc(n));
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, c->resolveTmp.p, n, (float)c->spp,
         c->camera.relativeAperture, c->camera.shutterTime, c->camera.ISO);
-    hipError_t e = hipMemcpyAsync(rgba_out, tmp.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(c->stream);
-    tmp.release();
-    HIPCHK(c, e);
+    HIPCHK(c, hipMemcpyAsync(rgba_out, c->resolveTmp.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
+    });
 }
 
 int pt_read_accum(pt_ctx* c, float* out)
@@ -1664,6 +1655,7 @@ int pt_reduce_accum(pt_ctx* c, void* nccl_comm, int root)
 
 int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt_hits_soa* hits, uint32_t repeat, float* ms_out)
 {
+    return guarded(c, "pt_intersect", [&]() -> int {
     if (!c || !rays || !hits || n == 0)
         return PT_ERR_INVALID;
     if (!c->haveStatic || !c->haveDynamic)
@@ -1680,13 +1672,14 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     }
     DevBuf<float4> dO, dD, dC, dH, dAcc;
     DevBuf<int32_t> dI;
-    DevBuf<uint32_t> dOcc, dCtl;
+    DevBuf<uint32_t> dOcc;
+    DevBuf<Control> dCtl;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) {
         if (e == hipSuccess)
             e = x;
     };
-    chk(dO.alloc(n)), chk(dD.alloc(n)), chk(dC.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dOcc.alloc(n)), chk(dAcc.alloc(1)), chk(dCtl.alloc(2));
+    chk(dO.alloc(n)), chk(dD.alloc(n)), chk(dC.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dOcc.alloc(n)), chk(dAcc.alloc(1)), chk(dCtl.alloc(1));
     if (e == hipSuccess) {
         chk(hipMemcpy(dO.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         chk(hipMemcpy(dD.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -1699,13 +1692,15 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     chk(hipEventCreate(&e0));
     chk(hipEventCreate(&e1));
     for (uint32_t r = 0; r < repeat && e == hipSuccess; r++) {
-        uint32_t ctl[2] = { n, 0 };
-        chk(hipMemcpyAsync(dCtl.p, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+        Control ctl {}; // a control block of its own: n entries in pass 0's queue, cursors at zero
+        ctl.extCount[0] = ctl.shadowCount[0] = n;
+        chk(hipMemcpyAsync(dCtl.p, &ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+        chk(hipStreamSynchronize(c->stream)); // `ctl` is a stack object
         TraceArgs a = traceArgsBase(c);
         a.parityShadow = 0;
         a.rayO = dO.p, a.rayD = dD.p, a.rayC = dC.p;
-        a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, 0u }, a.occluded = dOcc.p;
-        a.count = dCtl.p, a.cursor = dCtl.p + 1;
+        a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u }, a.occluded = dOcc.p;
+        a.ctl = dCtl.p, a.pass = 0;
         chk(hipEventRecord(e0, c->stream));
         if (c->packetOk && (c->packetUse & 4u))
             launchPacket(c, any_hit != 0, a);
@@ -1745,10 +1740,12 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         *ms_out = msTotal / (float)repeat;
     HIPCHK(c, e);
     return PT_OK;
+    });
 }
 
 int pt_gen_rays(pt_ctx* c, uint32_t sample, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel)
 {
+    return guarded(c, "pt_gen_rays", [&]() -> int {
     if (!c || n == 0)
         return PT_ERR_INVALID;
     if (!c->haveCamera)
@@ -1779,10 +1776,12 @@ int pt_gen_rays(pt_ctx* c, uint32_t sample, uint32_t n, float* ox, float* oy, fl
             std::memcpy(&pixel[i], &o[i].w, 4);
     }
     return PT_OK;
+    });
 }
 
 int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
 {
+    return guarded(c, "pt_shade_batch", [&]() -> int {
     if (!c || !io || io->n == 0)
         return PT_ERR_INVALID;
     if (!c->haveStatic || !c->haveDynamic)
@@ -1851,7 +1850,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.hits = { dH.p + i, dI.p + i };
         a.out = { out.o.p + i, out.d.p + i, out.thr.p + i };
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
-        a.accum = AccumView { dAcc.p, nullptr, 0u };
+        a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u };
         a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3;
         hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
         uint32_t back[4];
@@ -1891,6 +1890,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
     sh.o.release(), sh.d.release(), sh.c.release(), dH.release(), dI.release(), dCtl.release(), dAcc.release();
     HIPCHK(c, e);
     return PT_OK;
+    });
 }
 
 } // extern "C"

@@ -33,8 +33,11 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
     }
     m_inputTriangles.resize(numTriangles);
     for (size_t t = 0; t < numTriangles; t++) {
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 3; k++) {
+            if (indices[3 * t + k] >= numVertices) // the smooth-normal pass and the builders index m_vertices with these
+                throw std::invalid_argument("Mesh: vertex index out of range");
             m_inputTriangles[t].indices[k] = indices[3 * t + k];
+        }
         uint32_t mi = materialIndex ? materialIndex[t] : 0;
         if (mi >= materials.size())
             throw std::invalid_argument("Mesh: material index out of range");

@@ -21,6 +21,17 @@ RayTracer::RayTracer(int width, int height, std::shared_ptr<Scene> scene, const 
     cfg.samples_in_flight = 1; // rayTrace() adds exactly one sample per call, like the reference
     if (pt_create(&cfg, &m_ctx) != PT_OK)
         throw std::runtime_error(std::string("pt_create: ") + pt_last_error(nullptr));
+    try {
+        upload(materialTextures, skydomeTextures);
+    } catch (...) { // the destructor does not run for a partially constructed object: release the context here
+        pt_destroy(m_ctx);
+        m_ctx = nullptr;
+        throw;
+    }
+}
+
+void RayTracer::upload(const TextureArray& materialTextures, const TextureArray& skydomeTextures)
+{
     // static geometry once (reference: initBuffersAndTransferStaticData, src/raytracer.cpp:201-287) ...
     flattenStatic(*m_scene, m_flat);
     check(pt_upload_static(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.triangles.data(), (uint32_t)m_flat.triangles.size(),

@@ -76,6 +76,7 @@ public:
 
 private:
     void check(int rc, const char* what);
+    void upload(const TextureArray& materialTextures, const TextureArray& skydomeTextures); // constructor body proper
     pt_ctx* m_ctx = nullptr;
     std::shared_ptr<Scene> m_scene;
     FlattenedScene m_flat;

@@ -169,7 +169,9 @@ inline void lfsrJump(uint32_t g[4])
 }
 
 // production PRNG: stateless hash of (pixel, sample, depth, dim, seed); identical definition in
-// opencl-path-tracer_amd/csrc (DESIGN.md "PRNG").  mix32 = 'lowbias32' finaliser (Wellons).
+// opencl-path-tracer_amd/csrc/pt_math.h (DESIGN.md "PRNG").  A stream is named by 64 bits (k0 from pixel and seed, k1 from
+// the sample index, both through the bijection mix32 = 'lowbias32' finaliser) and walks a Weyl sequence with its own odd
+// step gamma; draw number ctr = depth * 16 + dim + 1 hashes k0 + gamma * ctr with k1 injected between the two rounds.
 inline uint32_t mix32(uint32_t x)
 {
     x ^= x >> 16;
@@ -179,17 +181,34 @@ inline uint32_t mix32(uint32_t x)
     x ^= x >> 15;
     return x;
 }
-inline uint32_t counterKey(uint32_t pixel, uint32_t sample, uint32_t seed) { return mix32(pixel ^ mix32(sample ^ mix32(seed ^ 0x9E3779B9u))); }
-inline float counterU01(uint32_t key, uint32_t depth, uint32_t dim)
+struct CounterKey {
+    uint32_t k0, k1, gamma;
+};
+inline CounterKey counterKey(uint32_t pixel, uint32_t sample, uint32_t seed)
 {
-    uint32_t h = mix32(key + 0x9E3779B9u * (depth * 16u + dim + 1u));
-    return (float)(h >> 8) * (1.0f / 16777216.0f); // [0,1)
+    CounterKey k;
+    k.k0 = mix32(pixel ^ mix32(seed ^ 0x9E3779B9u));
+    k.k1 = mix32(sample ^ 0x85EBCA6Bu);
+    k.gamma = mix32(k.k0 ^ k.k1 ^ 0xC2B2AE35u) | 1u;
+    return k;
+}
+inline float counterU01(const CounterKey& k, uint32_t depth, uint32_t dim)
+{
+    uint32_t x = k.k0 + k.gamma * (depth * 16u + dim + 1u);
+    x ^= x >> 16;
+    x *= 0x21f0aaadu;
+    x ^= k.k1;
+    x ^= x >> 15;
+    x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return (float)(x >> 8) * (1.0f / 16777216.0f); // [0,1)
 }
 
 struct Rng {
     int mode;
     uint32_t g[4]; // LFSR113 state
-    uint32_t key, depth, dim; // counter mode
+    CounterKey key;
+    uint32_t depth, dim; // counter mode
     float u01()
     {
         if (mode == ORC_RNG_LFSR113) // (float)(z * 2.3283063e-10), the constant is a double literal (lfsr113.c.h:41-42,87-89)
@@ -211,7 +230,8 @@ inline Rng rngLoad(const OrcParams* p, void* streams, size_t slot, uint32_t pixe
 {
     Rng r;
     r.mode = (int)p->rngMode;
-    r.key = r.depth = r.dim = 0;
+    r.key = CounterKey { 0, 0, 0 };
+    r.depth = r.dim = 0;
     if (r.mode == ORC_RNG_LFSR113) {
         std::memcpy(r.g, ((Lfsr113Stream*)streams)[slot].current, 16); // CopyOverStreamsFromGlobal
     } else {

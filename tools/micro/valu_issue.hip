@@ -1,0 +1,156 @@
+// Micro-benchmark (diagnostic, not part of the product): how many cycles does one wave64 vector instruction
+// occupy a gfx950 SIMD for, per instruction kind, at 1 / 2 / 4 / 7 / 8 waves per SIMD?
+//
+// Why: DESIGN.md section 6 reads the traversal kernels' PMC counters as "vector issue port saturated" on the
+// assumption that the kernel's instruction mix (byte->float converts, selects, compares, min/max, integer ops)
+// issues at 4 cycles per wave64 instruction, while MI355X_MICROARCH.md gives 2 cycles for v_fma_f32 once more than
+// one wave is resident.  This program measures it.
+//
+// Method: every wave runs `iters` repetitions of a block of 32 INDEPENDENT instructions of one kind (8 destination
+// registers x 4) between two s_memtime stamps (shader clock); W waves per SIMD are made resident by launching one
+// workgroup of 4 x W waves per CU (two workgroups of 14 / 16 waves for W = 7 / 8).  Reported:
+//   cyc/inst/wave = mean over waves of (stamp difference) / (instructions per wave)
+//   cyc/inst/SIMD = that / W     -- the SIMD's issue cost of one wave64 instruction when W waves share it
+// The second number levels off at the instruction's issue cost; the first shows what ONE wave can sustain alone.
+//
+// Build:  hipcc --offload-arch=gfx950 -O2 tools/micro/valu_issue.hip -o tools/micro/valu_issue
+// Run  :  tools/micro/valu_issue [iters] > table.md
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHECK(x)                                                     \
+    do {                                                             \
+        hipError_t e = (x);                                          \
+        if (e != hipSuccess) {                                       \
+            printf("%s: %s\n", #x, hipGetErrorString(e));            \
+            exit(1);                                                 \
+        }                                                            \
+    } while (0)
+
+// 8 independent destinations r0..r7, one source operand s (and a second one t where the form needs it)
+#define REP8(fmt_a, fmt_b) \
+    fmt_a "%0" fmt_b "\n\t" fmt_a "%1" fmt_b "\n\t" fmt_a "%2" fmt_b "\n\t" fmt_a "%3" fmt_b "\n\t" fmt_a "%4" fmt_b "\n\t" fmt_a "%5" fmt_b "\n\t" fmt_a "%6" fmt_b "\n\t" fmt_a "%7" fmt_b "\n\t"
+#define REP32(a, b) REP8(a, b) REP8(a, b) REP8(a, b) REP8(a, b)
+// accumulate form: the destination is also the last source (eight independent chains)
+#define ACC8(op, mid) \
+    op "%0" mid "%0\n\t" op "%1" mid "%1\n\t" op "%2" mid "%2\n\t" op "%3" mid "%3\n\t" op "%4" mid "%4\n\t" op "%5" mid "%5\n\t" op "%6" mid "%6\n\t" op "%7" mid "%7\n\t"
+#define ACC32(op, mid) ACC8(op, mid) ACC8(op, mid) ACC8(op, mid) ACC8(op, mid)
+
+enum Kind {
+    K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_COUNT
+};
+static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
+    "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
+    "v_bfe_u32", "v_add_u32", "v_mov_b32", "v_perm_b32", "v_pk_fma_f32", "v_pk_mul_f32", "v_rcp_f32", "v_lshl_or_b32", "v_and_or_b32", "v_mad_u32_u24" };
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
+{
+    float r0 = seed + threadIdx.x, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f;
+    float s = seed * 0.5f + 0.25f, t = seed * 0.25f + 1.0f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = { r0, r1 }, p1 = { r2, r3 }, p2 = { r4, r5 }, p3 = { r6, r7 }, p4 = { r1, r0 }, p5 = { r3, r2 }, p6 = { r5, r4 }, p7 = { r7, r6 };
+    f2 ps = { s, t };
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int i = 0; i < iters; i++) {
+#define OPS "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+        if (KIND == K_FMA) asm volatile(ACC32("v_fma_f32 ", ", %8, %9, ") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MUL) asm volatile(REP32("v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_ADD) asm volatile(REP32("v_add_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MIN) asm volatile(REP32("v_min_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MAX3) asm volatile(REP32("v_max3_f32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MIN3) asm volatile(REP32("v_min3_f32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT_UB0) asm volatile(REP32("v_cvt_f32_ubyte0 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT_UB1) asm volatile(REP32("v_cvt_f32_ubyte1 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT_UB2) asm volatile(REP32("v_cvt_f32_ubyte2 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT_UB3) asm volatile(REP32("v_cvt_f32_ubyte3 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT_U32) asm volatile(REP32("v_cvt_f32_u32 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CNDMASK) asm volatile(REP32("v_cndmask_b32 ", ", %8, %9, vcc") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_CMP) asm volatile(REP32("v_cmp_lt_f32 vcc, %8, ", "") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_CMP_SGPR) asm volatile(REP32("v_cmp_lt_f32 s[20:21], %8, ", "") : OPS : "v"(s), "v"(t) : "s20", "s21");
+        if (KIND == K_AND) asm volatile(REP32("v_and_b32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_LSHR) asm volatile(REP32("v_lshrrev_b32 ", ", 8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_BFE) asm volatile(REP32("v_bfe_u32 ", ", %8, 8, 8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_ADDU) asm volatile(REP32("v_add_u32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MOV) asm volatile(REP32("v_mov_b32 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PERM) asm volatile(REP32("v_perm_b32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_RCP) asm volatile(REP32("v_rcp_f32 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_LSHLOR) asm volatile(REP32("v_lshl_or_b32 ", ", %8, 8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_ANDOR) asm volatile(REP32("v_and_or_b32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MADU24) asm volatile(REP32("v_mad_u32_u24 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+#undef OPS
+        if (KIND == K_PKFMA)
+            asm volatile(ACC32("v_pk_fma_f32 ", ", %8, %8, ")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "v"(ps));
+        if (KIND == K_PKMUL)
+            asm volatile(REP32("v_pk_mul_f32 ", ", %8, %8")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "v"(ps));
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    float sink = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y;
+    if ((threadIdx.x & 63u) == 0u)
+        out[gwave] = (t1 - t0) | (sink == 12345.678f ? 1ull << 63 : 0ull);
+}
+
+template <int KIND>
+void runKind(unsigned long long* dOut, int iters, int numCUs, const int* wavesPerSimd, int nW, double* perWave, double* wallNsPerInst)
+{
+    for (int wi = 0; wi < nW; wi++) {
+        const int W = wavesPerSimd[wi];
+        // W <= 4: one workgroup of 4W waves per CU; W = 7 / 8: two workgroups of 14 / 16 waves per CU
+        const int blocksPerCU = W > 4 ? 2 : 1;
+        const int wavesPerBlock = 4 * W / blocksPerCU;
+        const dim3 grid(numCUs * blocksPerCU), block(wavesPerBlock * 64);
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_issue<KIND>, grid, block, 0, 0, dOut, iters / 8, 1.0f); // warm-up
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_issue<KIND>, grid, block, 0, 0, dOut, iters, 1.0f);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const size_t waves = (size_t)grid.x * wavesPerBlock;
+        std::vector<unsigned long long> h(waves);
+        CHECK(hipMemcpy(h.data(), dOut, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto v : h)
+            sum += (double)(v & ~(1ull << 63));
+        perWave[wi] = sum / (double)waves / ((double)iters * 32.0);
+        wallNsPerInst[wi] = (double)ms * 1e6 / ((double)iters * 32.0 * W); // wall ns per instruction per SIMD
+        CHECK(hipEventDestroy(e0));
+        CHECK(hipEventDestroy(e1));
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 4096;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int numCUs = prop.multiProcessorCount;
+    const int W[5] = { 1, 2, 4, 7, 8 };
+    unsigned long long* dOut = nullptr;
+    CHECK(hipMalloc((void**)&dOut, (size_t)numCUs * 32 * sizeof(unsigned long long)));
+    printf("# VALU issue cost on %s (%d CUs), %d x 32 independent instructions per wave between two s_memtime stamps\n\n", prop.gcnArchName, numCUs, iters);
+    printf("cycles per wave64 instruction: per wave (what one wave sees) / per SIMD (per-wave figure divided by the resident waves per SIMD)\n\n");
+    printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 |\n|---|---|---|---|---|---|---|\n");
+    double pw[5], ns[5];
+#define RUN(K)                                                                                                                        \
+    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns);                                                                                   \
+    printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
+        pw[3] / 7, pw[4], pw[4] / 8, ns[4]);
+    RUN(K_FMA) RUN(K_MUL) RUN(K_ADD) RUN(K_MIN) RUN(K_MAX3) RUN(K_MIN3) RUN(K_CVT_UB0) RUN(K_CVT_UB1) RUN(K_CVT_UB2) RUN(K_CVT_UB3) RUN(K_CVT_U32)
+    RUN(K_CNDMASK) RUN(K_CMP) RUN(K_CMP_SGPR) RUN(K_AND) RUN(K_LSHR) RUN(K_BFE) RUN(K_ADDU) RUN(K_MOV) RUN(K_PERM) RUN(K_PKFMA) RUN(K_PKMUL) RUN(K_RCP)
+    RUN(K_LSHLOR) RUN(K_ANDOR) RUN(K_MADU24)
+    CHECK(hipFree(dOut));
+    return 0;
+}
