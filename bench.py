@@ -3,8 +3,8 @@
 1080p (BASELINE.json metric), one process per GPU.
 
 A *step* is one pass of the hot path over one batch: `256*N*R` samples per pixel for the pixels this rank
-owns (N = ranks, R = --rounds), i.e. gen -> 4 x (intersect, shade, shadow intersect) over ~531 M path
-segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
+owns (N = ranks, R = --rounds, default 5: with the driver's 20 steps the timed region is ~12 s), i.e. R x [gen ->
+4 x (intersect, shade, shadow intersect)] over ~531 M path segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
 large batches matter (64 / 128 / 256 samples in flight: 7.8 / 8.1 / 8.3 Grays/s); 256 in flight keep ~100 GB of
 queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
 shard across ranks, every rank traces the same number of paths per step whatever N is (weak scaling: the image
@@ -12,6 +12,10 @@ simply receives N x more samples per step), and there is no data-path collective
 RCCL reduce of the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the
 timed region.  A ray = one traceRay invocation on a live queue entry (extension or shadow), counted by the
 device queues.
+
+`--mode frame` (and the `frame` object of the default line) times what the reference publishes instead (BASELINE.md 1a:
+35.6-56.8 ms per 1-spp 1280x720 frame, src/main.cpp:106-119): RayTracer::rayTrace = one sample per pixel + the
+accumulate kernel, on the 82k-triangle mesh in the five-wall room.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the render stream in a separate,
 profiled pass, for every kernel of the path (`roofline.kernels`); its top-level fields are those of the kernel
@@ -32,7 +36,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
 BYTES_PER_EXT_RAY = 48  # closest-hit intersect reads 28 B ray, writes 20 B hit record
-BYTES_PER_SHADOW_RAY = 44  # 28 B ray + 12 B contribution + 4 B pixel (the 24-B deposit of an unoccluded ray is left out)
+BYTES_PER_SHADOW_RAY = 44  # 28 B ray + 12 B contribution + 4 B pixel
+BYTES_PER_DEPOSIT = 24  # 12 B read + 12 B written per accumulator update (unoccluded shadow ray, emissive hit, sky miss)
+MAX_ENTRIES = 1920 * 1080 * 256  # path segments resident per rank (~100 GB of queues and planes): the 1080p job at any N; caps 4K
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
 
@@ -59,7 +65,7 @@ def usable_cores():
     return n
 
 
-def reference_kernels_baseline(O, sc, bundle, width, height, seconds=6.0):
+def reference_kernels_baseline(O, sc, bundle, width, height, seconds=3.0):
     """Secondary figure: assets/cl/kernel.cl itself (oracle/_ref, serial NDRange, LFSR113 streams) on a 1/10-scale
     frame of the same scene and camera.  Its traversal stack is the reference's 32 entries per ray, so it is only
     run when the scene's trees are shallower than that."""
@@ -129,21 +135,89 @@ def cpu_baseline(bundle, seconds, width, height):
                       f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
 
 
+def plan_in_flight(requested, world, owned_pixels, max_entries=MAX_ENTRIES):
+    """Samples in flight per pixel on one rank: `requested` x ranks (weak scaling: every rank keeps the same number of path
+    segments resident whatever N is), bounded by the library's 4096 planes and by the entries that fit in HBM."""
+    return max(1, min(requested * world, 4096, max_entries // max(owned_pixels, 1)))
+
+
+def reduce_accumulator(dist, accum, backend, world):
+    """The one exchange step of the job: SUM the HDR accumulator onto rank 0 (RCCL over xGMI; gloo rehearsals reduce on the
+    host).  Runs on the CURRENT torch stream -- the stream the render was enqueued on -- so it is ordered after the kernels."""
+    if world == 1:
+        return
+    if backend == "nccl":
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    else:
+        host = accum.cpu()  # synchronises with the current stream
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        accum.copy_(host)
+
+
+def aggregate(dist, torch, counts, elapsed, backend, world, device="cuda"):
+    """Whole-job figures: ray counters summed over ranks, elapsed time = the slowest rank's."""
+    dev = device if backend == "nccl" else "cpu"
+    c = torch.tensor([float(x) for x in counts], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in c.tolist()], float(t.item())
+
+
+def frame_times(D, H, scenes, L, device, frames, width=1280, height=720):
+    """What the reference publishes (BASELINE.md 1a): wall ms per interactive frame = RayTracer::rayTrace, one sample per
+    pixel through the whole queue loop + the accumulate kernel into a device image (the reference writes a GL texture),
+    stream synchronised every frame as its queue.finish() does (src/raytracer.cpp:88-151, src/main.cpp:106-119)."""
+    mats = {"glass (refractive 0.9, ior 1.5, SBVH)": L.material_refractive(0.9, 1.5, (1.0, 0.6, 0.6), 5.0),
+            "copper (PBR metal 0.8)": L.material_pbr_metal((0.955, 0.638, 0.538), 0.8),
+            "ceramic (PBR dielectric 0.7)": L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7),
+            "diffuse 0.8": L.material_diffuse((0.8, 0.8, 0.8))}
+    out = {}
+    for name, mat in mats.items():
+        b = scenes.blob_room(width, height, material=mat, builder=H.BVH_SPATIAL_SPLIT, level=6)
+        ctx = D.Context(width, height, seed=1, device=device, samples_in_flight=1)
+        ctx.upload_scene(b.flat, sky=b.sky, material_textures=b.material_textures)
+        ctx.set_camera(b.camera)
+        for _ in range(20):
+            ctx.render(1, sync=False)
+            ctx.resolve_device()
+        ctx.synchronize()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            ctx.render(1, sync=False)
+            ctx.resolve_device()
+            ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        out[name] = {"ms_per_frame": round(dt / frames * 1e3, 4), "rays_per_frame": int((st["rays_extension"] + st["rays_shadow"]) / frames),
+                     "mrays_per_s": round((st["rays_extension"] + st["rays_shadow"]) / dt / 1e6, 1)}
+        ctx.close()
+    return {"what": f"RayTracer::rayTrace: 1 spp of a {width}x{height} frame + accumulate kernel, synchronised per frame; 81 920-triangle mesh "
+                    f"(SBVH) in the five-wall room with an area light, {frames} frames each",
+            "scenes": out, "reference_published_ms_per_frame": "35.6 - 56.8 (images/*.png overlays, hardware not stated; BASELINE.md 1a)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rounds", type=int, default=1, help="batches per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=5, help="batches per step (5: the driver's 20 steps time ~12 s of rendering)")
     ap.add_argument("--in-flight", type=int, default=256, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-frame", action="store_true", help="skip the 1-spp 720p frame-time figure")
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "frame"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--dump-accum", default=None, help="rank 0 saves the (reduced) HDR accumulator as .npy (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,13 +228,24 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ptamd import device as D, host as H, scenes
+    from ptamd import device as D, host as H, layout as L, scenes
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+
+    if args.mode == "frame":
+        if world != 1:
+            raise SystemExit("--mode frame is a single-GPU measurement")
+        fr = frame_times(D, H, scenes, L, local_rank, args.frames)
+        best = min(v["ms_per_frame"] for v in fr["scenes"].values())
+        print(json.dumps({"metric": "ms per 1-spp 1280x720 frame (RayTracer::rayTrace + accumulate)", "value": best, "unit": "ms", "n_gpus": 1,
+                          "steps": args.frames, "warmup": 20, "ms_per_step": best, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "config": {"workload": fr["what"]}, "frame": fr}), flush=True)
+        return
+
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -170,137 +255,70 @@ def main():
     W, Hh = args.width, args.height
     bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT)
     flat = bundle.flat
-    in_flight = min(args.in_flight * world, 4096)
-    ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight)
-    ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
-    ctx.set_camera(bundle.camera)
-    if world > 1:
-        ctx.set_tiles(tile_rects(W, Hh, rank, world))
-    # torch owns the accumulator and the stream: device memory + streams + collectives are its job here
-    accum = torch.zeros(W * Hh, 4, device="cuda", dtype=torch.float32)
-    ctx.set_accum_buffer(accum.data_ptr())
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    spp_step = in_flight * args.rounds
-
-    def barrier():
-        torch.cuda.synchronize()
+    rects = tile_rects(W, Hh, rank, world) if world > 1 else []
+    owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
+    in_flight = plan_in_flight(args.in_flight, world, owned)
+    if world > 1:  # every rank must use the same batch: the smallest share decides
+        t = torch.tensor([in_flight], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        in_flight = int(t.item())
+    # torch owns the stream and the accumulator: everything below -- render kernels, the reduce, the statistics -- is enqueued
+    # on ONE explicit stream.  (torch's default stream is the legacy null stream, whose handle is 0; pt_set_stream(NULL)
+    # would mean "the library's own non-blocking stream", which the collective would NOT be ordered after.)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight)
+        ctx.set_stream(stream.cuda_stream)
+        ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
+        ctx.set_camera(bundle.camera)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            ctx.set_tiles(rects)
+        accum = torch.zeros(W * Hh, 4, device="cuda", dtype=torch.float32)
+        ctx.set_accum_buffer(accum.data_ptr())
+        spp_step = in_flight * args.rounds
 
-    def on_comm_device(t):  # gloo rehearsals reduce on the host
-        return t if args.backend == "nccl" else t.cpu()
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ctx.render(spp_step, sync=False)
-    barrier()
-    ctx.clear()
-    ctx.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.render(spp_step, sync=False)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # the one exchange step: HDR accumulator over xGMI
-        else:
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            accum.copy_(host)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    st = ctx.stats()
-    counts = on_comm_device(torch.tensor([st["rays_extension"], st["rays_shadow"], st["rays_generated"], st["shade_hits"]],
-                                         dtype=torch.float64, device="cuda"))
-    tmax = on_comm_device(torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ext, shadow, gen, hits = (float(x) for x in counts.tolist())
-    elapsed = float(tmax.item())
-    total_rays = ext + shadow
-    image_mean = float(accum[:, :3].mean().item()) / max(ctx.samples_per_pixel, 1) if rank == 0 else 0.0
-
-    roofline = None
-    if not args.no_roofline:
-        # profiled pass (HIP events around every launch, on the render stream); not part of the timed steps
+        for _ in range(args.warmup):
+            ctx.render(spp_step, sync=False)
+        barrier()
+        ctx.clear()
         ctx.reset_stats()
-        ctx.profile_kernels(True)
-        ctx.render(spp_step, sync=True)
-        ps = ctx.stats()
-        ctx.profile_kernels(False)
-        # per kernel: units processed, launches and device time of the profiled pass; algorithmic bytes per unit are
-        # SURVEY.md 8(d)'s figures.  HBM traffic per unit comes from the committed PMC passes of this exact configuration.
-        batches = spp_step // in_flight
-        packets = ps["packet_launches"] > 0  # primary rays went through k_trace_packet
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic.json")))
-            cfgt = tj["config"]
-            if (cfgt["width"], cfgt["height"], cfgt["level"], cfgt["samples_in_flight"], cfgt["n_gpus"]) != (W, Hh, args.level, in_flight, world):
-                tj = None
-        except (OSError, KeyError, ValueError):
-            tj = None
-        kernels = {}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.render(spp_step, sync=False)
+        reduce_accumulator(dist, accum, args.backend, world)  # inside the timed region, ordered after the kernels (same stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
 
-        def add(name, what, ms, launches, units, bytes_per_unit):
-            if launches <= 0 or ms <= 0 or units <= 0:
-                return
-            gbs = bytes_per_unit * units / (ms * 1e-3) / 1e9
-            k = {"computes": what, "ms_per_step": round(ms, 3), "launches": launches, "avg_launch_ms": round(ms / launches, 4),
-                 "units_per_launch": int(units / launches), "algorithmic_bytes_per_unit": bytes_per_unit,
-                 "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "munits_per_s": round(units / ms / 1e3, 1),
-                 "traffic": None}
-            if tj and name in tj.get("kernels", {}):
-                k["traffic_bytes_per_unit"] = tj["kernels"][name]["bytes_per_unit"]["total"]
-                k["traffic"] = round(k["traffic_bytes_per_unit"] * units / launches)
-            kernels[name] = k
+        st = ctx.stats()
+        (ext, shadow, gen, hits, deposits), elapsed = aggregate(
+            dist, torch, [st["rays_extension"], st["rays_shadow"], st["rays_generated"], st["shade_hits"], st["deposits"]], elapsed, args.backend, world)
+        total_rays = ext + shadow
+        total_spp = ctx.samples_per_pixel  # per owned pixel: N x more samples per step on the image at N ranks
+        image_mean = float(accum[:, :3].mean().item()) / max(total_spp, 1) if rank == 0 else 0.0
+        if rank == 0 and args.dump_accum:
+            np.save(args.dump_accum, accum.cpu().numpy())
 
-        primary = ps["rays_generated"] if packets else 0
-        add("k_trace<true>", "any-hit traversal of the shadow rays", ps["ms_shadow"], 4 * batches, ps["rays_shadow"], BYTES_PER_SHADOW_RAY)
-        add("k_trace<false>", "closest-hit traversal, one ray per lane (bounce rays%s)" % ("" if packets else " and primary rays"),
-            ps["ms_intersect"] - ps["ms_packet"], (3 if packets else 4) * batches, ps["rays_extension"] - primary, BYTES_PER_EXT_RAY)
-        add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave", ps["ms_packet"], batches, primary,
-            BYTES_PER_EXT_RAY)
-        add("k_shade<false>", "shade + NEE + continuation + compaction", ps["ms_shade"], 4 * batches, ps["shade_hits"], BYTES_PER_SHADED_HIT)
-        add("k_gen", "primary rays", ps["ms_gen"], batches, ps["rays_generated"], BYTES_PER_GEN_RAY)
-        dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
-        dk = kernels[dominant]
-        achieved = dk["achieved"]
-        # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
-        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
-        dst = torch.empty_like(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dst.copy_(src)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
-        # SURVEY 8(d) formula over the whole step (deposits are not counted on device and left out)
-        path_bytes = 48.0 * ps["rays_generated"] + 48.0 * ps["rays_extension"] + 160.0 * ps["shade_hits"] + 44.0 * ps["rays_shadow"]
-        path_ms = ps["ms_gen"] + ps["ms_intersect"] + ps["ms_shade"] + ps["ms_shadow"]
-        roofline = {"bound": "hbm", "kernel": f"{dominant} ({dk['computes']}; largest share of device time)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": dk["traffic"],
-                    "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
-                    "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
-                    "traffic_note": ("HBM bytes per launch = bytes per unit from the FETCH_SIZE / WRITE_SIZE PMC passes of this exact configuration "
-                                     "(profiles/round1/traffic.json states the corrections) x units per launch") if dk["traffic"] else None,
-                    "algorithmic_bytes_per_unit": dk["algorithmic_bytes_per_unit"], "units_per_launch": dk["units_per_launch"],
-                    "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
-                    "issue_limit": (tj or {}).get("issue_limit"),
-                    "mrays_per_s_in_kernel": round(ps["rays_extension"] / ps["ms_intersect"] / 1e3, 1),
-                    "kernels": kernels,
-                    "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),
-                                  "shade": round(ps["ms_shade"], 3), "shadow": round(ps["ms_shadow"], 3)}}
+        roofline = None
+        if not args.no_roofline:
+            roofline = measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
+    ctx.close()
+    frame = None
+    if rank == 0 and world == 1 and not args.no_frame:
+        try:
+            frame = frame_times(D, H, scenes, L, local_rank, args.frames)
+        except Exception as e:  # a secondary figure must not take the headline down
+            frame = {"error": str(e)[:300]}
 
     if rank == 0:
         out = {
@@ -320,22 +338,113 @@ def main():
                 "workload": f"configs[3]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
                             f"SBVH meshes = {flat.instanced_triangles} instanced triangles, PBR metal/dielectric, procedural HDR sky + "
                             f"emissive quad), two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG",
-                "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight,
+                "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
-                "pixels_per_rank": W * Hh // world, "paths_per_step_per_rank": W * Hh // world * spp_step,
-                "collective": "none" if world == 1 else "1 x reduce(SUM) of the HDR accumulator (RCCL) per job",
+                "pixels_per_rank": owned, "paths_per_step_per_rank": owned * spp_step,
+                "collective": "none" if world == 1 else f"1 x reduce(SUM) of the HDR accumulator ({args.backend}) per job, inside the timed region",
             },
-            "rays": {"extension": int(ext), "shadow": int(shadow), "primary": int(gen), "shade_hits": int(hits)},
+            "rays": {"extension": int(ext), "shadow": int(shadow), "primary": int(gen), "shade_hits": int(hits), "deposits": int(deposits)},
+            "timed_region_s": round(elapsed, 3),
             "image_mean_radiance": round(image_mean, 5),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "frame": frame,
         }
         if cpu:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def newest_traffic_json(W, Hh, level, in_flight, world):
+    """HBM traffic per unit from the committed PMC passes (profiles/roundN/traffic.json) of exactly this configuration."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            c = tj["config"]
+            if (c["width"], c["height"], c["level"], c["samples_in_flight"], c["n_gpus"]) == (W, Hh, level, in_flight, world):
+                tj["_path"] = os.path.relpath(path, ROOT)
+                return tj
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
+    """Profiled pass (HIP events around every launch, on the render stream); not part of the timed steps.  Per kernel: units
+    processed, launches and device time of the pass; algorithmic bytes per unit are SURVEY.md 8(d)'s figures.  HBM traffic per
+    unit and the issue-port occupancy come from the committed PMC passes of this exact configuration."""
+    ctx.reset_stats()
+    ctx.profile_kernels(True)
+    ctx.render(spp_step, sync=True)
+    ps = ctx.stats()
+    ctx.profile_kernels(False)
+    batches = spp_step // in_flight
+    packets = ps["packet_launches"] > 0  # primary rays went through k_trace_packet
+    tj = newest_traffic_json(W, Hh, args.level, in_flight, world)
+    kernels = {}
+
+    def add(name, what, ms, launches, units, bytes_per_unit, extra_bytes=0.0):
+        if launches <= 0 or ms <= 0 or units <= 0:
+            return
+        gbs = (bytes_per_unit * units + extra_bytes) / (ms * 1e-3) / 1e9
+        k = {"computes": what, "ms_per_step": round(ms, 3), "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+             "units_per_launch": int(units / launches), "algorithmic_bytes_per_unit": round(bytes_per_unit + extra_bytes / units, 2),
+             "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "munits_per_s": round(units / ms / 1e3, 1),
+             "traffic": None}
+        if tj and name in tj.get("kernels", {}):
+            k["traffic_bytes_per_unit"] = tj["kernels"][name]["bytes_per_unit"]["total"]
+            k["traffic"] = round(k["traffic_bytes_per_unit"] * units / launches)
+        if tj and name in tj.get("issue", {}):
+            k.update(tj["issue"][name])  # valu_issue_frac, active lanes (PMC)
+        kernels[name] = k
+
+    primary = ps["rays_generated"] if packets else 0
+    dep_shadow, dep_shade = ps["deposits_shadow"], ps["deposits"] - ps["deposits_shadow"]
+    add("k_trace<true>", "any-hit traversal of the shadow rays + deposit of the unoccluded ones", ps["ms_shadow"], 4 * batches, ps["rays_shadow"],
+        BYTES_PER_SHADOW_RAY, BYTES_PER_DEPOSIT * dep_shadow)
+    add("k_trace<false>", "closest-hit traversal, one ray per lane (bounce rays%s)" % ("" if packets else " and primary rays"),
+        ps["ms_intersect"] - ps["ms_packet"], (3 if packets else 4) * batches, ps["rays_extension"] - primary, BYTES_PER_EXT_RAY)
+    add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave", ps["ms_packet"], batches, primary,
+        BYTES_PER_EXT_RAY)
+    add("k_shade<false>", "shade + NEE + continuation + compaction (+ deposits of emissive hits and sky misses)", ps["ms_shade"], 4 * batches,
+        ps["shade_hits"], BYTES_PER_SHADED_HIT, BYTES_PER_DEPOSIT * dep_shade)
+    add("k_gen", "primary rays", ps["ms_gen"], batches, ps["rays_generated"], BYTES_PER_GEN_RAY)
+    dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    dk = kernels[dominant]
+    achieved = dk["achieved"]
+    # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
+    src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    # SURVEY 8(d) formula over the whole step
+    path_bytes = (48.0 * ps["rays_generated"] + 48.0 * ps["rays_extension"] + 160.0 * ps["shade_hits"] + 44.0 * ps["rays_shadow"]
+                  + 24.0 * ps["deposits"])
+    path_ms = ps["ms_gen"] + ps["ms_intersect"] + ps["ms_shade"] + ps["ms_shadow"]
+    return {"bound": "hbm", "kernel": f"{dominant} ({dk['computes']}; largest share of device time)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": dk["traffic"],
+            "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
+            "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
+            "traffic_note": (f"HBM bytes per launch = bytes per unit from the FETCH_SIZE / WRITE_SIZE PMC passes of this exact configuration "
+                             f"({tj['_path']} states the corrections) x units per launch") if dk["traffic"] else None,
+            "algorithmic_bytes_per_unit": dk["algorithmic_bytes_per_unit"], "units_per_launch": dk["units_per_launch"],
+            "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
+            "valu_issue_frac": dk.get("valu_issue_frac"), "issue_model": (tj or {}).get("issue_model"),
+            "mrays_per_s_in_kernel": round(ps["rays_extension"] / ps["ms_intersect"] / 1e3, 1),
+            "kernels": kernels,
+            "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),
+                          "shade": round(ps["ms_shade"], 3), "shadow": round(ps["ms_shadow"], 3)}}
 
 
 if __name__ == "__main__":

@@ -154,6 +154,8 @@ typedef struct {
                                                         (only when PT_PROFILE_KERNELS was requested) */
     uint64_t packet_launches; /* launches of the packet traversal kernel (primary rays of a world-space scene) */
     double ms_packet; /* the part of ms_intersect spent in the packet traversal kernel */
+    uint64_t deposits_shadow; /* the part of `deposits` made by the any-hit traversal (unoccluded shadow rays,
+                                 kernel.cl:132-135); the rest are emissive hits and sky misses in shade */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
@@ -162,7 +164,11 @@ typedef struct pt_ctx pt_ctx;
 int pt_create(const pt_config* cfg, pt_ctx** out);
 void pt_destroy(pt_ctx* ctx);
 const char* pt_last_error(const pt_ctx* ctx); /* ctx may be NULL: error of a failed pt_create */
-/* Run everything on a caller-owned HIP stream (e.g. torch's current stream); NULL = own stream. */
+/* Run everything on a caller-owned HIP stream; NULL = a non-blocking stream owned by the context (the default).
+ * NOTE: the handle of the legacy default stream IS NULL (torch.cuda.current_stream().cuda_stream == 0 unless a
+ * torch.cuda.Stream is current), so "torch's default stream" cannot be selected this way: work enqueued there by
+ * others -- a collective, a tensor copy -- is NOT ordered after the render.  Pass an explicit stream and issue the
+ * dependent work on it, or call pt_synchronize first. */
 int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 
 /* ---- uploads -- replace the enqueueWriteBuffer calls of src/raytracer.cpp:273-282 and :556-578 */
@@ -191,6 +197,9 @@ int pt_render(pt_ctx* ctx, uint32_t spp);
 int pt_synchronize(pt_ctx* ctx);
 /* accumulate kernel, assets/cl/accumulate.cl:6-34: mean -> exposure -> Reinhard -> sRGB; width*height*4 floats out (host) */
 int pt_resolve(pt_ctx* ctx, float* rgba_out);
+/* same kernel, output left in DEVICE memory (width*height float4) -- the analogue of the GL texture the reference's
+ * accumulate kernel writes (src/raytracer.cpp:432-450); NULL: a buffer owned by the context.  Asynchronous. */
+int pt_resolve_device(pt_ctx* ctx, void* device_rgba);
 int pt_read_accum(pt_ctx* ctx, float* out_float4); /* width*height*4 floats: HDR sums (host) */
 int pt_write_accum(pt_ctx* ctx, const float* in_float4, uint32_t spp); /* restore a checkpoint */
 void* pt_accum_device_ptr(pt_ctx* ctx);

@@ -175,12 +175,13 @@ struct Control {
     uint32_t extCursor[kMaxPasses + 1]; // persistent-kernel fetch cursors
     uint32_t shadowCursor[kMaxPasses + 1];
     uint32_t shadeHits[kMaxPasses + 1];
-    uint32_t deposits; // accumulator updates of the sample (k_shade: emissive hits and sky misses; k_trace<true>: unoccluded shadow rays)
+    uint32_t depositsShade; // accumulator updates of the sample made by k_shade (emissive hits, sky misses) ...
+    uint32_t depositsShadow; // ... and by the any-hit traversal (unoccluded shadow rays)
     uint32_t generated;
-    uint32_t _pad[2];
+    uint32_t _pad;
 };
 struct Totals {
-    unsigned long long raysExtension, raysShadow, raysGenerated, shadeHits, deposits;
+    unsigned long long raysExtension, raysShadow, raysGenerated, shadeHits, deposits, depositsShadow;
 };
 
 } // namespace ptd

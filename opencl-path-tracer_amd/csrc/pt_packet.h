@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         if (ANY_HIT) {
             const uint32_t nDep = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));
             if (lane == 0 && nDep)
-                atomicAdd(&a.ctl->deposits, nDep);
+                atomicAdd(&a.ctl->depositsShadow, nDep);
             if (active) {
                 if (a.occluded)
                     a.occluded[idx] = 0u;

@@ -745,9 +745,10 @@ __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
     tot->raysShadow += sh;
     tot->shadeHits += hits;
     tot->raysGenerated += ctl->generated;
-    tot->deposits += ctl->deposits;
+    tot->deposits += (unsigned long long)ctl->depositsShade + ctl->depositsShadow;
+    tot->depositsShadow += ctl->depositsShadow;
     ctl->generated = 0;
-    ctl->deposits = 0;
+    ctl->depositsShade = ctl->depositsShadow = 0;
 }
 
 } // namespace ptd

@@ -81,7 +81,7 @@ struct TraceArgs {
     // queue words of this launch, all in the sample's control block (one pointer + the pass index instead of three
     // pointers: the any-hit kernel sits at the scalar-register limit of 7 waves per SIMD):
     //   entries in the queue  ctl->extCount[pass] / shadowCount[pass]; fetch cursor (zero at launch)  ctl->extCursor[pass] /
-    //   shadowCursor[pass]; any-hit launches add their unoccluded rays (= accumulator updates) to ctl->deposits
+    //   shadowCursor[pass]; any-hit launches add their unoccluded rays (= accumulator updates) to ctl->depositsShadow
     Control* ctl;
     uint32_t pass;
     uint32_t* spill; // kSpillStack * totalThreads dwords
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         }
     }
     if (ANY_HIT && lane == 0 && ldsDeposits[wave])
-        atomicAdd(&a.ctl->deposits, ldsDeposits[wave]);
+        atomicAdd(&a.ctl->depositsShadow, ldsDeposits[wave]);
     PT_TOC(10, tKernel);
 #ifdef PT_TRACE_STATS
     if (lane == 0)

@@ -656,7 +656,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.outCount = &ctl->extCount[pass + 1];
     a.shadowCount = &ctl->shadowCount[pass];
     a.shadeHits = &ctl->shadeHits[pass];
-    a.deposits = &ctl->deposits;
+    a.deposits = &ctl->depositsShade;
     a.streams = c->streams.p;
     const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock;
     if (parityMode(c)) {
@@ -1546,6 +1546,25 @@ int pt_resolve(pt_ctx* c, float* rgba_out)
     });
 }
 
+int pt_resolve_device(pt_ctx* c, void* device_rgba)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if (!c->haveCamera || c->spp == 0)
+        return fail(c, PT_ERR_STATE, "pt_resolve_device: nothing rendered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = c->cfg.width * c->cfg.height;
+    if (!device_rgba) {
+        if (c->resolveTmp.n != n)
+            HIPCHK(c, c->resolveTmp.alloc(n));
+        device_rgba = c->resolveTmp.p;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, (float4*)device_rgba, n, (float)c->spp,
+        c->camera.relativeAperture, c->camera.shutterTime, c->camera.ISO);
+    HIPCHK(c, hipGetLastError());
+    return PT_OK;
+}
+
 int pt_read_accum(pt_ctx* c, float* out)
 {
     if (!c || !out)
@@ -1585,6 +1604,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->rays_generated = t.raysGenerated;
     out->shade_hits = t.shadeHits;
     out->deposits = t.deposits;
+    out->deposits_shadow = t.depositsShadow;
     out->samples = c->spp;
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess)
@@ -1824,7 +1844,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
             e = x;
     };
     chk(in.o.alloc(n)), chk(in.d.alloc(n)), chk(in.thr.alloc(n)), chk(out.o.alloc(n)), chk(out.d.alloc(n)), chk(out.thr.alloc(n));
-    chk(sh.o.alloc(n)), chk(sh.d.alloc(n)), chk(sh.c.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dCtl.alloc(4));
+    chk(sh.o.alloc(n)), chk(sh.d.alloc(n)), chk(sh.c.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dCtl.alloc(5));
     const size_t npix = (size_t)c->cfg.width * c->cfg.height;
     chk(dAcc.alloc(npix));
     // per-entry outputs are needed, so every entry is shaded as its own 1-entry queue slice
@@ -1840,7 +1860,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
     FrameParams fp = frameParams(c, io->sample);
     for (uint32_t i = 0; i < n && e == hipSuccess; i++) {
         // pixel-indexed accumulator: clear only the touched pixel
-        uint32_t ctl[4] = { 1, 0, 0, 0 }; // inCount, outCount, shadowCount, shadeHits
+        uint32_t ctl[5] = { 1, 0, 0, 0, 0 }; // inCount, outCount, shadowCount, shadeHits, deposits
         chk(hipMemcpyAsync(dCtl.p, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
         chk(hipMemsetAsync(dAcc.p + io->pixel[i], 0, sizeof(float4), c->stream));
         ShadeArgs a {};
@@ -1851,7 +1871,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.out = { out.o.p + i, out.d.p + i, out.thr.p + i };
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
         a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u };
-        a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3;
+        a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3, a.deposits = dCtl.p + 4;
         hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
         uint32_t back[4];
         float4 px;

@@ -30,7 +30,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_generated", C.c_uint64),
                 ("shade_hits", C.c_uint64), ("deposits", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
-                ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double)]
+                ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double),
+                ("deposits_shadow", C.c_uint64)]
 
 
 class RaysSoA(C.Structure):
@@ -53,7 +54,7 @@ class ShadeBatchIO(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_upload_static", "pt_upload_dynamic",
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
-           "pt_synchronize", "pt_resolve", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
+           "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
            "pt_intersect", "pt_gen_rays", "pt_shade_batch", "pt_version"]
 
@@ -90,6 +91,7 @@ def lib():
         l.pt_render.argtypes = [C.c_void_p, C.c_uint32]
         l.pt_synchronize.argtypes = [C.c_void_p]
         l.pt_resolve.argtypes = [C.c_void_p, C.c_void_p]
+        l.pt_resolve_device.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_read_accum.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_write_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         l.pt_accum_device_ptr.restype = C.c_void_p
@@ -174,7 +176,16 @@ class Context:
         self._chk(lib().pt_set_tiles(self._h, arr if rects else None, len(rects)), "pt_set_tiles")
 
     def set_stream(self, stream_handle):
+        """Enqueue everything on a caller-owned HIP stream.  A handle of 0 is the legacy default stream -- what
+        torch.cuda.current_stream().cuda_stream is unless a torch.cuda.Stream is current -- which the C-ABI cannot tell from
+        "no stream" (NULL = the context's own stream): refuse it instead of silently losing the ordering."""
+        if not stream_handle:
+            raise PtError("set_stream(0): the legacy default stream cannot be selected; make a torch.cuda.Stream current "
+                          "and pass its handle (own_stream() returns to the context's own stream)")
         self._chk(lib().pt_set_stream(self._h, C.c_void_p(stream_handle)), "pt_set_stream")
+
+    def own_stream(self):
+        self._chk(lib().pt_set_stream(self._h, None), "pt_set_stream")
 
     def set_accum_buffer(self, device_ptr):
         self._chk(lib().pt_set_accum_buffer(self._h, C.c_void_p(device_ptr)), "pt_set_accum_buffer")
@@ -204,6 +215,10 @@ class Context:
         out = np.zeros((self.height, self.width, 4), np.float32)
         self._chk(lib().pt_resolve(self._h, _p(out)), "pt_resolve")
         return out
+
+    def resolve_device(self, device_ptr=None):
+        """accumulate kernel into device memory (None: a buffer owned by the context); asynchronous."""
+        self._chk(lib().pt_resolve_device(self._h, C.c_void_p(device_ptr) if device_ptr else None), "pt_resolve_device")
 
     @property
     def samples_per_pixel(self):

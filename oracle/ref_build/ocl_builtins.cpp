@@ -184,3 +184,55 @@ void ocl_write_imagef_2d(RefImage* img, int2_t xy, float4_t c)
     t[2] = c.z;
     t[3] = c.w;
 }
+
+// ---- plain-C doors to the built-ins above, for tests/test_ocl_builtins.py ------------------------------------------
+// (the kernels reach them through their OpenCL-mangled names with vector arguments in SSE registers, which ctypes
+// cannot pass).  The test checks them against values derived from the OpenCL 1.2 specification WITHOUT restating the
+// formulas above: what is left unpinned by running the reference's kernels on this shim is the shim itself.
+extern "C" {
+void ref_test_read_imagef(const RefImage* img, const float* coord4, float* out4)
+{
+    float4_t c = { coord4[0], coord4[1], coord4[2], coord4[3] };
+    float4_t r = ocl_read_imagef_2darray(img, ocl_translate_sampler(0), c);
+    for (int k = 0; k < 4; k++)
+        out4[k] = r[k];
+}
+void ref_test_vec3(int op, const float* a3, const float* b3, float* out3)
+{
+    float3_t a = { a3[0], a3[1], a3[2] }, b = { b3[0], b3[1], b3[2] }, r = { 0, 0, 0 };
+    switch (op) {
+    case 0: r.x = ocl_dot3(a, b); break;
+    case 1: r = ocl_cross3(a, b); break;
+    case 2: r = ocl_normalize3(a); break;
+    case 3: r = ocl_exp3(a); break;
+    case 4: r = ocl_pow3(a, b); break;
+    case 5: r = ocl_fabs3(a); break;
+    }
+    out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+float ref_test_scalar(int op, float x, float y, float z)
+{
+    switch (op) {
+    case 0: return ocl_min(x, y);
+    case 1: return ocl_max(x, y);
+    case 2: return ocl_mix(x, y, z);
+    case 3: return ocl_clamp(x, y, z);
+    case 4: return ocl_fmin(x, y);
+    case 5: return ocl_fmax(x, y);
+    case 6: return ocl_cos(x);
+    case 7: return ocl_sin(x);
+    case 8: return ocl_tan(x);
+    case 9: return ocl_acos(x);
+    case 10: return ocl_atan(x);
+    case 11: return ocl_atan2(x, y);
+    case 12: return ocl_exp(x);
+    case 13: return ocl_pow(x, y);
+    case 14: return ocl_sqrt(x);
+    case 15: return ocl_fabs(x);
+    case 16: return ocl_log1p(x);
+    case 17: return ocl_log2(x);
+    }
+    return 0.f;
+}
+unsigned ref_test_atomic_inc(unsigned* p) { return ocl_atomic_inc(p); }
+}

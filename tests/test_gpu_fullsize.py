@@ -80,3 +80,69 @@ def test_config5_4k_thin_lens_properties(gpu):
     assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
     close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
     assert close.mean() > 0.97, close.mean()
+
+
+def _config_room_test(gpu, bundle, spp_total, seed, n_pixels=4096, first=8):
+    """A BASELINE room configuration at its full workload (1080p, its sample count): (1) the first `first` samples
+    path by path against the oracle on `n_pixels` sampled pixels at the production gates; (2) the full sample count:
+    ray-count conservation, additivity, determinism (a second context lands on the same bits) and the sampled pixels
+    against the oracle's full-spp values (every pixel now holds hundreds of paths, so one fp32 round-off flip per pixel
+    is the norm: the gates there are the image statistics of SURVEY 8(d) -- mean bias and tone-mapped RMSE)."""
+    sc = U.oracle_scene(bundle)
+    px = np.random.default_rng(seed).choice(W * H, n_pixels, replace=False).astype(np.uint32)
+    ctx = U.make_ctx(gpu, bundle, W, H, seed=seed)
+    ctx.render(first)
+    a = ctx.read_accum()[:, :3]
+    st = ctx.stats()
+    assert st["rays_generated"] == W * H * first
+    assert st["rays_generated"] <= st["rays_extension"] <= 4 * st["rays_generated"]
+    assert st["shade_hits"] <= st["rays_extension"] and st["rays_shadow"] <= st["shade_hits"]
+    assert 0 < st["deposits_shadow"] <= st["rays_shadow"] and st["deposits"] <= st["rays_shadow"] + st["rays_extension"]
+    ref, cnt = O.render(sc, bundle.camera, W, H, first, seed=seed, pixels=px, threads=8)
+    got, want = a[px], ref[px, :3]
+    assert abs(got.mean() - want.mean()) / want.mean() < 2e-3
+    close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
+    assert close.mean() > 0.97, close.mean()
+    # the rest of the configuration's samples on top
+    ctx.render(spp_total - first)
+    assert ctx.samples_per_pixel == spp_total
+    full = ctx.read_accum()[:, :3]
+    st = ctx.stats()
+    assert st["rays_generated"] == W * H * spp_total
+    assert np.isfinite(full).all() and full.min() >= 0
+    ctx.close()
+    again = U.make_ctx(gpu, bundle, W, H, seed=seed)
+    again.render(first)
+    again.render(spp_total - first)
+    assert np.array_equal(again.read_accum()[:, :3], full), "same seed, same batching: same bits"
+    again.close()
+    ref, _ = O.render(sc, bundle.camera, W, H, spp_total, seed=seed, pixels=px, threads=8)
+    got, want = full[px], ref[px, :3]
+    bias = abs(got.mean() - want.mean()) / want.mean()
+    assert bias < 2e-3, bias
+    e = U.rmse(U.tonemap(got, spp_total, bundle.camera), U.tonemap(want, spp_total, bundle.camera))
+    assert e < 2e-3, e
+    return st
+
+
+def test_config2_diffuse_mesh_binned_sah_1080p_256spp(gpu):
+    """BASELINE.json configs[1]: the ~70k-triangle mesh (81 920 here: the bunny PLY does not travel to the GPU box,
+    SURVEY 8d allows the seeded substitute), 3-axis binned-SAH BVH, diffuse 0.8, five-wall room + area light, 1080p, 256 spp."""
+    b = scenes.blob_room(W, H, level=6, builder=gpu_host().BVH_BINNED_SAH)
+    assert 70000 < len(b.flat.triangles) < 100000
+    st = _config_room_test(gpu, b, 256, seed=21)
+    assert st["packet_launches"] == 0 or st["packet_launches"] >= 1  # either traversal kernel may serve the primary rays
+
+
+def test_config3_glass_mesh_sbvh_1080p_1024spp(gpu):
+    """BASELINE.json configs[2]: the same room with Material::Refractive(smoothness 0.9, ior 1.5, colour (1,0.6,0.6),
+    absorption 5) on the mesh (material.h:112-120) and an SBVH bottom level, 1080p, 1024 spp."""
+    from ptamd import layout as L
+    b = scenes.blob_room(W, H, level=6, builder=gpu_host().BVH_SPATIAL_SPLIT, material=L.material_refractive(0.9, 1.5, (1.0, 0.6, 0.6), 5.0))
+    st = _config_room_test(gpu, b, 1024, seed=22)
+    assert st["rays_extension"] > 1.5 * st["rays_generated"], "paths continue through the glass"
+
+
+def gpu_host():
+    from ptamd import host
+    return host

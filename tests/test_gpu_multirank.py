@@ -1,0 +1,71 @@
+"""The N > 1 code path of bench.py ON THE DEVICE: two ranks (one process each, torch.distributed launcher) sharing the one
+GPU of the test box, gloo for the host-side exchange -- tile lists, per-rank accumulator planes indexed by owned-pixel
+ordinal, the reduce ordered after the render on the ranks' streams, the whole-job aggregation -- against a single-rank run
+of the same job.  (RCCL itself needs two GPUs; what it replaces here is only the transport of the one reduce.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+COMMON = ["--steps", "1", "--warmup", "1", "--rounds", "2", "--width", "192", "--height", "128", "--level", "3", "--no-cpu-baseline", "--no-roofline",
+          "--no-frame"]
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_two_rank_job_on_one_gpu_equals_the_single_rank_job(gpu, tmp_path):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    port = 29600 + os.getpid() % 300
+    j2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), "bench.py", "--gpus", "2", "--share-gpu", "--backend", "gloo", "--in-flight", "8", "--dump-accum", two] + COMMON, env)
+    j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--in-flight", "16", "--dump-accum", one] + COMMON, env)
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1 and j2["scaling"] == "weak"
+    assert j2["config"]["samples_in_flight"] == 16 and j2["config"]["pixels_per_rank"] == 192 * 128 // 2
+    # the same paths were traced: 2 ranks x half the pixels x 16 samples x 2 batches == 1 rank x all pixels x the same
+    assert j2["rays"] == j1["rays"] and j2["rays"]["primary"] == 192 * 128 * 32
+    assert 0 < j2["rays"]["deposits"] <= j2["rays"]["shadow"] + j2["rays"]["extension"]
+    a1, a2 = np.load(one), np.load(two)
+    assert a1.shape == (192 * 128, 4) and a1[:, :3].mean() > 0
+    assert np.array_equal(a1, a2), "tile-sharded render + reduce must equal the single-rank image bit for bit"
+    assert j2["value"] > 0 and j2["image_mean_radiance"] == j1["image_mean_radiance"]
+
+
+def test_oversized_jobs_and_overlapping_tiles_fail_with_a_message(gpu):
+    """BASELINE config 5 sized naively -- 4K, a rank's eighth of the pixels, 2 048 samples in flight = 2.1 G queue entries,
+    ~350 GB -- must be refused when the queues are set up, with a message that says what to change, not die in a later
+    hipMalloc; tile rectangles that share a pixel are refused too (deposits are plain read-modify-writes that rely on one
+    live path per pixel and plane)."""
+    import bench
+    from ptamd import scenes
+    import gpu_util as U
+    W4, H4 = 3840, 2160
+    b = scenes.cornell_box(W4, H4)
+    ctx = U.make_ctx(gpu, b, W4, H4, samples_in_flight=2048)
+    ctx.set_tiles(bench.tile_rects(W4, H4, 0, 8))
+    with pytest.raises(gpu.PtError, match="samples in flight"):
+        ctx.render(1)
+    with pytest.raises(gpu.PtError, match="overlaps"):
+        ctx.set_tiles([(0, 0, 64, 64), (32, 32, 96, 96)])
+    ctx.close()
+    # what bench.py would actually run there fits: the same share at the in-flight count plan_in_flight allows
+    owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in bench.tile_rects(W4, H4, 0, 8))
+    n = bench.plan_in_flight(256, 8, owned)
+    assert 256 <= n < 2048 and n * owned <= bench.MAX_ENTRIES
+    ctx = U.make_ctx(gpu, b, W4, H4, samples_in_flight=n)
+    ctx.set_tiles(bench.tile_rects(W4, H4, 0, 8))
+    ctx.render(n)
+    st = ctx.stats()
+    assert st["rays_generated"] == owned * n and ctx.samples_per_pixel == n
+    ctx.close()

@@ -458,3 +458,32 @@ def test_the_reference_light_plane_imports_as_main_cpp_uses_it():
     tf = H.TextureFiles()
     plain = H.Mesh.from_obj(f, builder=H.BVH_BINNED_SAH, textures=tf).geometry()[1]
     assert plain[0]["type"] == L.MAT_DIFFUSE and np.allclose(plain[0]["colour"][:3], 0.6) and tf.files() == []
+
+
+BUNNY = "/root/reference/assets/3dmodels/stanford/bunny/bun_zipper.ply"
+
+
+@pytest.mark.skipif(not os.path.isfile(BUNNY), reason="the reference's assets are only present in the build container")
+@pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_SPATIAL_SPLIT])
+def test_the_stanford_bunny_ply_loads_and_builds(builder):
+    """The mesh BASELINE configs 2-5 are quoted on (bun_zipper.ply: 35 947 vertices, 69 451 faces, no normals) through the
+    PLY reader, the area-weighted smooth normals and both builders the configs name, with the reference's BvhTester
+    checks (src/bvh/bvh_test.cpp:117-139; SBVH leaves hold clipped boxes, so 'triangles inside leaves' is exact for the
+    object-split tree only)."""
+    m = H.Mesh.from_ply(BUNNY, L.material_diffuse((0.8, 0.8, 0.8)), builder=builder)
+    verts, mats = m.geometry()
+    nodes, tris, orig = m.bvh()
+    v, n = verts["vertex"][:, :3], verts["normal"][:, :3]
+    assert len(v) == 35947 and len(mats) == 1 and tris["indices"].max() == 35946
+    assert sorted(set(orig.tolist())) == list(range(69451)), "every face of the file is referenced by some leaf"
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-4), "smooth normals are generated and unit length"
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    assert np.allclose(lo, [-0.0947, 0.0330, -0.0619], atol=1e-3) and np.allclose(hi, [0.0610, 0.1873, 0.0588], atol=1e-3)
+    s = m.stats()
+    assert s["num_input_triangles"] == 69451 and s["children_inside_parents"] and s["all_triangles_referenced"]
+    assert s["reachable_triangle_refs"] == s["num_triangle_refs"] >= 69451
+    if builder == H.BVH_BINNED_SAH:
+        assert s["triangles_inside_leaves"] and s["num_triangle_refs"] == 69451
+    else:
+        assert s["num_triangle_refs"] < 1.6 * 69451, "spatial splits duplicate a bounded share of the references"
+    assert s["max_leaf_size"] <= 8 and s["max_depth"] <= 60

@@ -1,7 +1,8 @@
 """N > 1 path on CPU (gloo, world_size 2): the tile partition bench.py uses, per-rank rendering of
-disjoint tiles and ONE reduce of the HDR accumulator onto rank 0.  The per-rank 'renderer' here is the
-oracle (CPU) restricted to the rank's pixels -- it stands in for the GPU context, whose tile logic is
-tested on the device in test_gpu_render.py; the collective call is the one bench.py issues."""
+disjoint tiles and ONE reduce of the HDR accumulator onto rank 0, through bench.py's own functions (tile_rects,
+plan_in_flight, reduce_accumulator, aggregate).  The per-rank 'renderer' here is the oracle (CPU) restricted to the
+rank's pixels -- there is no GPU in this container; the same job with the HIP contexts as renderers, two ranks on
+one GPU, is tests/test_gpu_multirank.py."""
 import os
 import sys
 
@@ -34,15 +35,15 @@ def _worker(rank, world, port, out_path):
     sc = O.BoundScene(b.flat, sky=b.sky)
     rects = bench.tile_rects(W, H, rank, world, tile=16)
     px = _pixels_of(rects, W)
+    assert bench.plan_in_flight(256, world, len(px)) == 256 * world  # weak scaling: N x the samples in flight on 1/N of the pixels
+    assert bench.plan_in_flight(256, 8, 3840 * 2160 // 8) * (3840 * 2160 // 8) <= bench.MAX_ENTRIES  # 4K: capped by memory
     acc, cnt = O.render(sc, b.camera, W, H, SPP, seed=1, pixels=px, threads=1)
     accum = torch.from_numpy(acc)
-    rays = torch.tensor([cnt["raysExtension"] + cnt["raysShadow"]], dtype=torch.float64)
-    dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-    dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    # the exchange and the whole-job aggregation are bench.py's own functions (host tensors: the gloo rehearsal path)
+    bench.reduce_accumulator(dist, accum, "gloo", world)
+    (rays,), tmax = bench.aggregate(dist, torch, [cnt["raysExtension"] + cnt["raysShadow"]], float(rank + 1), "gloo", world)
     if rank == 0:
-        np.savez(out_path, accum=accum.numpy(), rays=rays.numpy(), tmax=tmax.numpy(), owned=len(px))
+        np.savez(out_path, accum=accum.numpy(), rays=np.array([rays]), tmax=np.array([tmax]), owned=len(px))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -2,6 +2,8 @@
 REFERENCE'S OWN kernels (tests/golden/make_golden.py).  This is what pins the oracle."""
 import ctypes as C
 
+import os
+
 import numpy as np
 
 import golden_io
@@ -137,6 +139,22 @@ def test_queue_semantics_with_refill(golden):
     assert np.array_equal(st.accum[:, :3], golden["queue_accum_32x18_cap256"])
     assert g[0].tolist()[:3] == [0, 256, 0] and g[:, 1].sum() == 32 * 18 and g[-1, 3] == 0
     assert np.all(g[:, 0] + g[:, 1] <= 256)
+
+
+def test_refill_on_the_refraction_free_scene_v2_fixture(golden):
+    """golden_v2.npz (tests/golden/make_golden_v2.py): MAX_ACTIVE_RAYS = 512 < 64x36 pixels on the `plain` scene, two
+    samples through the reference's kernels; the oracle reproduces per-pass counters and sums bit for bit."""
+    v2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz"))
+    W, H, cap = (int(x) for x in v2["refill_plain_shape"])
+    sc, cam = _bound(golden, "plain")
+    st = O.QueueState(W, H, cap)
+    s = O.create_streams(W * H)
+    for spp in (1, 2):
+        trace, _ = O.trace_rays("oracle", sc, cam, st, s)
+        g = v2[f"refill_plain_trace_{spp}spp"]
+        assert np.array_equal(trace, g)
+        assert np.array_equal(st.accum[:, :3], v2[f"refill_plain_accum_{spp}spp"])
+        assert g[:, 1].sum() == W * H and np.all(g[:, 0] + g[:, 1] <= cap) and g[-1, 3] == 0 and (g[:, 1] > 0).sum() >= 5
 
 
 def test_accumulated_images_and_resolve(golden):
