@@ -675,16 +675,99 @@ struct ShadeIn {
     const float* invT;
     V3 multiplier;
     int flags;
+    V3 rayOrigin; // MIS: inData->ray.origin (distance to an emissive hit, shading.cl:78-79)
+    float pdf; // MIS: inData->pdf, the solid-angle density with which the previous bounce sampled this direction
+    bool mis; // neeMisShading instead of neeIsShading
+    bool weightedLights; // weightedRandomPointOnLight instead of randomPointOnLight
 };
 struct ShadeOut {
     int flags; // continuation ray
+    float pdf; // MIS: outData->pdf
     V3 origin, direction, multiplier;
     int shadowFlags;
     V3 shadowOrigin, shadowDirection, shadowMultiplier;
     float shadowLength;
 };
 
-V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
+// Heron on three points (shading_helper.cl:204-214)
+inline float triangleArea3(V3 v0, V3 v1, V3 v2)
+{
+    V3 A = v1 - v0, B = v2 - v1, C = v0 - v2;
+    float a = sqrtf(dot(A, A)), b = sqrtf(dot(B, B)), c = sqrtf(dot(C, C));
+    float s = (a + b + c) / 2.0f;
+    return sqrtf(s * (s - a) * (s - b) * (s - c));
+}
+
+struct LightSample {
+    V3 point, normal, colour;
+    float area;
+};
+// randomPointOnLight, shading_helper.cl:261-278: uniform choice of the triangle (1 draw), uniform point on it (2 draws)
+inline LightSample randomPointOnLight(const Scene& sc, Rng& rng)
+{
+    int li = rng.randomInteger(0, (int)sc.numEmissive - 1);
+    const EmissiveTri& lt = sc.emissive[li];
+    LightSample ls;
+    ls.normal = normalize(cross(mk(lt.v[1]) - mk(lt.v[0]), mk(lt.v[2]) - mk(lt.v[0])));
+    ls.colour = mk(lt.material.colour[0], lt.material.colour[1], lt.material.colour[2]);
+    float u1 = rng.u01(), u2 = rng.u01();
+    ls.point = (1 - sqrtf(u1)) * mk(lt.v[0]) + (sqrtf(u1) * (1 - u2)) * mk(lt.v[1]) + (sqrtf(u1) * u2) * mk(lt.v[2]);
+    ls.area = triangleArea(lt);
+    return ls;
+}
+// weightedRandomPointOnLight, shading_helper.cl:216-259: the triangle is chosen with probability proportional to the solid
+// angle its CENTROID direction gives it (area * cos / dist^2, capped at 2 pi, NOT clamped at zero: a back-facing triangle
+// enters with a negative weight, as in the reference), 1 draw; the colour carries weightTotal / numLights so that the caller's
+// `numLights * colour` becomes colour * weightTotal = colour / P(triangle) * weight(triangle); then the point, 2 draws.
+inline LightSample weightedRandomPointOnLight(const Scene& sc, V3 X, Rng& rng)
+{
+    const int numLights = (int)sc.numEmissive;
+    float weightTotal = 0;
+    float weights[255];
+    for (int i = 0; i < numLights && i < 255; i++) {
+        const EmissiveTri& lt = sc.emissive[i];
+        V3 lightPos = (mk(lt.v[2]) + mk(lt.v[1]) + mk(lt.v[0])) / 3.0f;
+        V3 L = lightPos - X;
+        float dist2 = dot(L, L);
+        float dist = sqrtf(dist2);
+        L = L / dist;
+        V3 lightNormal = normalize(cross(mk(lt.v[1]) - mk(lt.v[0]), mk(lt.v[2]) - mk(lt.v[0])));
+        float lightArea = triangleArea(lt);
+        float solidAngle = (dot(lightNormal, -L) * lightArea) / dist2;
+        solidAngle = clMin(2 * kPI, solidAngle);
+        weights[i] = solidAngle;
+        weightTotal += weights[i];
+    }
+    float randomValue = rng.u01() * weightTotal;
+    int li;
+    for (li = 0; li < numLights; ++li) {
+        randomValue -= weights[li];
+        if (randomValue <= 0)
+            break;
+    }
+    // li == numLights when round-off (or negative weights) leaves a remainder: the reference then reads one triangle past
+    // the end (BoundScene pads one zeroed light, as for quirk 3)
+    const EmissiveTri& lt = sc.emissive[li];
+    LightSample ls;
+    ls.normal = normalize(cross(mk(lt.v[1]) - mk(lt.v[0]), mk(lt.v[2]) - mk(lt.v[0])));
+    ls.colour = mk(lt.material.colour[0], lt.material.colour[1], lt.material.colour[2]) * weightTotal / (float)numLights;
+    float u1 = rng.u01(), u2 = rng.u01();
+    ls.point = (1 - sqrtf(u1)) * mk(lt.v[0]) + (sqrtf(u1) * (1 - u2)) * mk(lt.v[1]) + (sqrtf(u1) * u2) * mk(lt.v[2]);
+    ls.area = triangleArea(lt);
+    return ls;
+}
+
+// One function for both integrators: neeMisShading (shading.cl:35-349) repeats neeIsShading (:356-623) line for line except
+// where `in.mis` branches below.  Two things in neeMisShading are kept, one is not:
+//   kept   -- its PBR light sample takes the BRDF from diffuseColour(material) (shading.cl:140-145; pbrBrdf's value, :117,
+//             is overwritten), which reads a PBR record through the DIFFUSE view of the union: tex_id = the bits of
+//             `smoothness`, never -1, so the value is a material-texture fetch at a clamped layer;
+//   kept   -- its DIFFUSE light sample divides diffuseColour by pi without the alpha-0 check of the IS variant (:150);
+//   FIXED  -- its DIFFUSE continuation stores outData->pdf = dot(shadingNormal, reflection) / pi BEFORE `reflection` is
+//             assigned (:590-592): an uninitialised read, whatever the compiler makes of it.  Here the density is taken
+//             from the direction that is then sampled, which is what the comment next to it asks for ("MIS needs
+//             unsimplified PDF").  tests/test_oracle_vs_ref.py compares everything but that one field with the reference.
+V3 neeShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
 {
     const Triangle& tri = sc.triangles[in.tri];
     const Vertex* vtx[3] = { &sc.vertices[tri.indices[0]], &sc.vertices[tri.indices[1]], &sc.vertices[tri.indices[2]] };
@@ -704,27 +787,58 @@ V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
         out.shadowFlags = FLAG_FINISHED;
         if (in.flags & FLAG_LASTSPECULAR)
             return in.multiplier * mk(mat.colour[0], mat.colour[1], mat.colour[2]);
-        return BLACK;
+        if (!in.mis)
+            return BLACK; // next event estimation has already counted this light (shading.cl:387-397)
+        // MIS, shading.cl:69-90: the BSDF-sampled direction found the light; balance heuristic against the density
+        // with which NEE would have picked this point (1 / solid angle of the OBJECT-space triangle, sic)
+        float lightArea = triangleArea3(mk(vtx[0]->vertex), mk(vtx[1]->vertex), mk(vtx[2]->vertex));
+        V3 distV = in.X - in.rayOrigin;
+        float dist2 = dot(distV, distV);
+        float solidAngle = (dot(realNormal, -in.D) * lightArea) / dist2;
+        solidAngle = clMin(2 * kPI, solidAngle);
+        float pdf1 = 0;
+        if (solidAngle > kEPS)
+            pdf1 = 1 / solidAngle;
+        else
+            return BLACK;
+        float pdf2 = in.pdf;
+        if (pdf2 < kEPS)
+            return BLACK;
+        float weight = pdf2 / (pdf1 + pdf2);
+        return in.multiplier * mk(mat.colour[0], mat.colour[1], mat.colour[2]) * weight;
     }
 
     V3 BRDF = mk(0.0f);
     if (mat.type == MAT_REFRACTIVE || mat.type == MAT_BASIC_REFRACTIVE) {
         out.shadowFlags = FLAG_FINISHED;
     } else { // next event estimation, :399-448 + randomPointOnLight shading_helper.cl:261-278
-        int li = rng.randomInteger(0, (int)sc.numEmissive - 1);
-        const EmissiveTri& lt = sc.emissive[li];
-        V3 lightNormal = normalize(cross(mk(lt.v[1]) - mk(lt.v[0]), mk(lt.v[2]) - mk(lt.v[0])));
-        V3 lightColour = mk(lt.material.colour[0], lt.material.colour[1], lt.material.colour[2]);
-        float u1 = rng.u01(), u2 = rng.u01();
-        V3 lightPos = (1 - sqrtf(u1)) * mk(lt.v[0]) + (sqrtf(u1) * (1 - u2)) * mk(lt.v[1]) + (sqrtf(u1) * u2) * mk(lt.v[2]);
-        float lightArea = triangleArea(lt);
+        const LightSample ls = in.weightedLights ? weightedRandomPointOnLight(sc, in.X, rng) : randomPointOnLight(sc, rng);
+        const V3 lightNormal = ls.normal, lightColour = ls.colour, lightPos = ls.point;
+        const float lightArea = ls.area;
         V3 L = lightPos - in.X;
         float dist2 = dot(L, L);
         float dist = sqrtf(dist2);
         L = L / dist;
         if (dot(shadingNormal, L) > kEPS && dot(realNormal, L) > kEPS && dot(lightNormal, -L) > kEPS) {
-            if (mat.type == MAT_PBR) {
+            float pdf2 = 0.0f; // MIS: density with which the BSDF sampling below would have produced L
+            if (mat.type == MAT_PBR && in.mis) { // shading.cl:116-146
+                V3 f0 = pbrF0(mat);
+                V3 halfway = normalize(-in.D + L);
+                float LdotH = saturate(dot(L, halfway));
+                V3 F = F_Schlick(f0, 1.0f, LdotH);
+                float rand01 = rng.u01();
+                float NdotH = dot(shadingNormal, halfway);
+                if (!mat.metallic && rand01 > F.x)
+                    pdf2 = dot(shadingNormal, L) / kPI; // cosine weighted PDF
+                else
+                    pdf2 = D_GGX(NdotH, 1.0f - mat.smoothness);
+                V3 c = diffuseColour(sc, mat, vtx, in.u, in.v); // sic: the DIFFUSE view of a PBR record (see above)
+                BRDF = (c.x == -1.0f) ? mk(0.0f) : c / kPI;
+            } else if (mat.type == MAT_PBR) {
                 BRDF = pbrBrdfWithDiffuse(-in.D, L, shadingNormal, mat, mat.smoothness > kMaxSmoothness);
+            } else if (mat.type == MAT_DIFFUSE && in.mis) { // shading.cl:148-152
+                BRDF = diffuseColour(sc, mat, vtx, in.u, in.v) / kPI; // sic: no alpha-0 check here
+                pdf2 = dot(realNormal, L) / kPI;
             } else if (mat.type == MAT_DIFFUSE) {
                 V3 c = diffuseColour(sc, mat, vtx, in.u, in.v);
                 BRDF = (c.x == -1.0f) ? mk(0.0f) : c / kPI;
@@ -734,7 +848,13 @@ V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
                 solidAngle = (dot(lightNormal, -L) * lightArea) / dist2;
                 solidAngle = clClamp(solidAngle, 0.0f, 2 * kPI);
             }
-            V3 Ld = (float)sc.numEmissive * lightColour * BRDF * solidAngle * dot(shadingNormal, L);
+            V3 Ld;
+            if (in.mis) { // shading.cl:153-163
+                float pdf1 = 1 / solidAngle;
+                Ld = (float)sc.numEmissive * lightColour * BRDF * dot(realNormal, L) / (pdf1 + pdf2);
+            } else {
+                Ld = (float)sc.numEmissive * lightColour * BRDF * solidAngle * dot(shadingNormal, L);
+            }
             out.shadowFlags = 0;
             out.shadowMultiplier = Ld * in.multiplier;
             out.shadowOrigin = in.X + L * kEPS;
@@ -748,6 +868,7 @@ V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
     bool dospecular = false;
     float PDF = 1.0f, cosineTerm = 1.0f;
     V3 reflection = mk(0.0f);
+    out.pdf = 0; // for materials not interacting with MIS (shading.cl:175)
     if (mat.type == MAT_PBR) { // :456-496
         V3 f0 = pbrF0(mat);
         V3 V = -in.D;
@@ -766,8 +887,12 @@ V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
             reflection = cosineWeightedDiffuseReflection(shadingNormal, edge1, in.invT, rng);
             PDF = kINVPI;
             cosineTerm = 1.0f;
+            if (in.mis)
+                out.pdf = dot(shadingNormal, reflection) * kINVPI; // MIS needs the real unsimplified PDF (:205)
             BRDF = diffuseOnly(V, halfway, reflection, shadingNormal, mat);
         } else {
+            if (in.mis)
+                out.pdf = PDF; // MIS needs real PDF (:210)
             PDF = 1.0f;
             BRDF = brdfOnlyNoFresnelNoNDF(V, reflection, shadingNormal, mat);
             if (mat.metallic)
@@ -845,6 +970,8 @@ V3 neeIsShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
             BRDF = mk(1.0f);
         } else {
             reflection = cosineWeightedDiffuseReflection(realNormal, edge1, in.invT, rng);
+            if (in.mis)
+                out.pdf = dot(shadingNormal, reflection) * kINVPI; // FIXED: after sampling, not before (see above; :590-592)
             BRDF = c;
         }
     }
@@ -909,6 +1036,8 @@ void orc_generatePrimaryRays(size_t global, OrcRayData* outRays, OrcKernelData* 
         Rng rng = rngLoad(p, streams, gid, rayIndex, 0);
         uint32_t x = rayIndex % kd->scrWidth;
         uint32_t y = rayIndex / kd->scrWidth;
+        if (p && p->integrator == ORC_INTEGRATOR_COMPARE && x >= kd->scrWidth / 2) // COMPARE_SHADING, kernel.cl:48-51: both halves
+            x -= kd->scrWidth / 2; // of the image show the left half's view, one per integrator
         OrcRayData& r = outRays[kd->numInRays + gid];
         V3 o, d;
         if (kd->camera.thinLensEnabled)
@@ -978,14 +1107,21 @@ void orc_shade(size_t global, OrcFloat3* outputPixels, OrcRayData* outRays, OrcR
                 in.invT = sd.invTransform;
                 in.multiplier = mk(ray.multiplier);
                 in.flags = ray.flags;
+                in.rayOrigin = mk(ray.origin);
+                in.pdf = ray.pdf;
+                // COMPARE_SHADING (kernel.cl:248-265): neeMisShading for the pixels of the left half of the image
+                in.mis = p && (p->integrator == ORC_INTEGRATOR_MIS
+                              || (p->integrator == ORC_INTEGRATOR_COMPARE && (ray.outputPixel % kd->scrWidth) < kd->scrWidth / 2));
+                in.weightedLights = p && p->lightSampling == ORC_LIGHTS_SOLID_ANGLE;
                 Rng rng = rngLoad(p, streams, gid, (uint32_t)ray.outputPixel, 1u + (uint32_t)ray.numBounces);
                 ShadeOut so;
                 std::memset(&so, 0, sizeof(so));
-                V3 rad = neeIsShading(sc, in, rng, so);
+                V3 rad = neeShading(sc, in, rng, so);
                 OrcFloat3& px = outputPixels[ray.outputPixel];
                 px.x += rad.x, px.y += rad.y, px.z += rad.z;
                 if (c && (rad.x != 0 || rad.y != 0 || rad.z != 0)) c->deposits++;
                 outRay.flags = so.flags;
+                outRay.pdf = so.pdf;
                 outRay.origin = to3(so.origin), outRay.direction = to3(so.direction), outRay.multiplier = to3(so.multiplier);
                 outShadow.flags = so.shadowFlags;
                 outShadow.origin = to3(so.shadowOrigin), outShadow.direction = to3(so.shadowDirection);
@@ -1153,6 +1289,26 @@ void orc_intersect_batch(const OrcScene* s, uint32_t topRoot, uint32_t n, const 
 void orc_render(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample, uint32_t spp, uint32_t seed, uint32_t maxBounce,
     const uint32_t* pixels, uint32_t numPixels, OrcFloat3* accum, int threads, OrcCounters* c)
 {
+    orc_render_ex(kd, s, firstSample, spp, seed, maxBounce, ORC_INTEGRATOR_IS, ORC_LIGHTS_UNIFORM, pixels, numPixels, accum, threads, c);
+}
+
+void orc_weighted_light(const OrcScene* s, uint32_t numEmissive, const float* x3, void* stream48, float* outPoint3, float* outNormal3,
+    float* outColour3, float* outArea)
+{
+    Scene sc = bind(s, numEmissive, 0);
+    OrcParams prm { ORC_RNG_LFSR113, 0, 0, 0, 0, 0 };
+    Rng rng = rngLoad(&prm, stream48, 0, 0, 0);
+    LightSample ls = weightedRandomPointOnLight(sc, mk(x3[0], x3[1], x3[2]), rng);
+    rngStore(rng, stream48, 0);
+    outPoint3[0] = ls.point.x, outPoint3[1] = ls.point.y, outPoint3[2] = ls.point.z;
+    outNormal3[0] = ls.normal.x, outNormal3[1] = ls.normal.y, outNormal3[2] = ls.normal.z;
+    outColour3[0] = ls.colour.x, outColour3[1] = ls.colour.y, outColour3[2] = ls.colour.z;
+    *outArea = ls.area;
+}
+
+void orc_render_ex(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample, uint32_t spp, uint32_t seed, uint32_t maxBounce,
+    uint32_t integrator, uint32_t lightSampling, const uint32_t* pixels, uint32_t numPixels, OrcFloat3* accum, int threads, OrcCounters* c)
+{
     Scene sc = bind(s, kd->numEmissiveTriangles, kd->topLevelBvhRoot);
     const uint32_t total = pixels ? numPixels : kd->scrWidth * kd->scrHeight;
     const uint32_t bounces = maxBounce ? maxBounce : 4u;
@@ -1172,10 +1328,14 @@ void orc_render(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample
                 const uint32_t pixel = pixels ? pixels[k] : k;
                 OrcFloat3& px = accum[pixel];
                 for (uint32_t sIdx = firstSample; sIdx < firstSample + spp; sIdx++) {
-                    OrcParams prm { ORC_RNG_COUNTER, sIdx, seed, bounces };
+                    OrcParams prm { ORC_RNG_COUNTER, sIdx, seed, bounces, integrator, lightSampling };
                     Rng rng = rngLoad(&prm, nullptr, 0, pixel, 0);
                     V3 o, d;
                     int x = (int)(pixel % kd->scrWidth), y = (int)(pixel / kd->scrWidth);
+                    const bool mis = integrator == ORC_INTEGRATOR_MIS || (integrator == ORC_INTEGRATOR_COMPARE && (uint32_t)x < kd->scrWidth / 2);
+                    if (integrator == ORC_INTEGRATOR_COMPARE && (uint32_t)x >= kd->scrWidth / 2)
+                        x -= (int)(kd->scrWidth / 2);
+                    float pdf = 0; // outRayData.pdf of the previous bounce (kernel.cl: primary rays carry 0)
                     if (kd->camera.thinLensEnabled)
                         thinLensRay(kd->camera, x, y, (float)kd->scrWidth, (float)kd->scrHeight, rng, &o, &d);
                     else
@@ -1199,10 +1359,14 @@ void orc_render(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample
                         in.t = h.t, in.u = h.u, in.v = h.v, in.tri = h.tri, in.invT = h.invTransform;
                         in.multiplier = mult;
                         in.flags = flags;
+                        in.rayOrigin = o;
+                        in.pdf = pdf;
+                        in.mis = mis;
+                        in.weightedLights = lightSampling == ORC_LIGHTS_SOLID_ANGLE;
                         Rng srng = rngLoad(&prm, nullptr, 0, pixel, 1u + bounce);
                         ShadeOut so;
                         std::memset(&so, 0, sizeof(so));
-                        V3 rad = neeIsShading(sc, in, srng, so);
+                        V3 rad = neeShading(sc, in, srng, so);
                         px.x += rad.x, px.y += rad.y, px.z += rad.z;
                         if (rad.x != 0 || rad.y != 0 || rad.z != 0) cc.deposits++;
                         if (!(so.shadowFlags & FLAG_FINISHED)) {
@@ -1214,7 +1378,7 @@ void orc_render(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample
                         }
                         if (so.flags & FLAG_FINISHED)
                             break;
-                        o = so.origin, d = so.direction, mult = so.multiplier, flags = so.flags;
+                        o = so.origin, d = so.direction, mult = so.multiplier, flags = so.flags, pdf = so.pdf;
                     }
                 }
             }

@@ -73,12 +73,23 @@ struct OrcScene { // same member order as RefScene in ref_build/ref_driver.cpp
 };
 
 enum { ORC_RNG_LFSR113 = 0, ORC_RNG_COUNTER = 1 };
+// which integrator `shade` runs (kernel.cl:248-279): neeIsShading, the one the reference compiles in; neeMisShading
+// (shading.cl:35-349), reachable there under #define COMPARE_SHADING only; or exactly that build: neeMisShading for the
+// pixels of the left half of the image, neeIsShading for the right half, both halves showing the left half's view
+// (kernel.cl:48-51,248-265)
+enum { ORC_INTEGRATOR_IS = 0, ORC_INTEGRATOR_MIS = 1, ORC_INTEGRATOR_COMPARE = 2 };
+// how NEE picks its light: randomPointOnLight (uniform over the emissive triangles, shading_helper.cl:261-278) or
+// weightedRandomPointOnLight (proportional to the solid angle of each triangle seen from the shading point,
+// shading_helper.cl:216-259; not called by the reference's kernels)
+enum { ORC_LIGHTS_UNIFORM = 0, ORC_LIGHTS_SOLID_ANGLE = 1 };
 
 struct OrcParams {
     uint32_t rngMode; // ORC_RNG_*
     uint32_t sample; // counter mode: sample index of this frame
     uint32_t seed; // counter mode
     uint32_t maxBounces; // 0 -> 4 (MAX_ITERATIONS, kernel.cl:4)
+    uint32_t integrator; // ORC_INTEGRATOR_*
+    uint32_t lightSampling; // ORC_LIGHTS_*
 };
 
 struct OrcCounters {
@@ -113,4 +124,10 @@ void orc_intersect_batch(const OrcScene* s, uint32_t topRoot, uint32_t n, const 
 // (nullptr = all).  Equivalent to spp x orc_trace_rays in ORC_RNG_COUNTER mode.  accum += sums.
 void orc_render(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample, uint32_t spp, uint32_t seed, uint32_t maxBounces,
     const uint32_t* pixels, uint32_t numPixels, OrcFloat3* accum, int threads, OrcCounters* c);
+// same with an integrator / light-sampling choice (ORC_INTEGRATOR_*, ORC_LIGHTS_*)
+void orc_render_ex(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSample, uint32_t spp, uint32_t seed, uint32_t maxBounces,
+    uint32_t integrator, uint32_t lightSampling, const uint32_t* pixels, uint32_t numPixels, OrcFloat3* accum, int threads, OrcCounters* c);
+// weightedRandomPointOnLight (shading_helper.cl:216-259) alone, for the test against the reference's compiled function
+void orc_weighted_light(const OrcScene* s, uint32_t numEmissive, const float* x3, void* stream48, float* outPoint3, float* outNormal3,
+    float* outColour3, float* outArea);
 }

@@ -36,8 +36,13 @@ class SceneStruct(C.Structure):  # OrcScene == RefScene
                                           "materialTextures", "skydomeTextures")]
 
 
+INTEGRATOR_IS, INTEGRATOR_MIS, INTEGRATOR_COMPARE = 0, 1, 2  # neeIsShading | neeMisShading | COMPARE_SHADING's half-and-half
+LIGHTS_UNIFORM, LIGHTS_SOLID_ANGLE = 0, 1  # randomPointOnLight | weightedRandomPointOnLight
+
+
 class Params(C.Structure):
-    _fields_ = [("rngMode", C.c_uint32), ("sample", C.c_uint32), ("seed", C.c_uint32), ("maxBounces", C.c_uint32)]
+    _fields_ = [("rngMode", C.c_uint32), ("sample", C.c_uint32), ("seed", C.c_uint32), ("maxBounces", C.c_uint32),
+                ("integrator", C.c_uint32), ("lightSampling", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -201,7 +206,7 @@ def intersect_batch(scene, o, d, tmax=None, any_hit=False, threads=1, fast=False
 
 
 def render(scene, camera, width, height, spp, seed=1, first_sample=0, max_bounces=0, pixels=None, threads=1,
-           fast=False, accum=None):
+           fast=False, accum=None, integrator=INTEGRATOR_IS, light_sampling=LIGHTS_UNIFORM):
     """Production-mode (counter PRNG) path-by-path render on `threads` host threads."""
     lib = oracle(fast)
     kd = scene.kernel_data(camera, width, height)
@@ -209,9 +214,9 @@ def render(scene, camera, width, height, spp, seed=1, first_sample=0, max_bounce
         accum = np.zeros((width * height, 4), np.float32)
     cnt = Counters()
     px = None if pixels is None else np.ascontiguousarray(pixels, np.uint32)
-    lib.orc_render(_p(kd), C.byref(scene.struct), C.c_uint32(first_sample), C.c_uint32(spp), C.c_uint32(seed),
-                   C.c_uint32(max_bounces), _p(px), C.c_uint32(0 if px is None else len(px)), _p(accum), int(threads),
-                   C.byref(cnt))
+    lib.orc_render_ex(_p(kd), C.byref(scene.struct), C.c_uint32(first_sample), C.c_uint32(spp), C.c_uint32(seed),
+                      C.c_uint32(max_bounces), C.c_uint32(integrator), C.c_uint32(light_sampling), _p(px),
+                      C.c_uint32(0 if px is None else len(px)), _p(accum), int(threads), C.byref(cnt))
     return accum, cnt.as_dict()
 
 

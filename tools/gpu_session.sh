@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box session (run through gpurun): tools/gpu_session.sh <tag> [steps...]
+#   steps: micro  = the VALU issue micro-benchmark            -> gpurun_out/<tag>/valu_issue.md
+#          tests  = pytest -m gpu                              -> gpurun_out/<tag>/pytest.log
+#          bench  = bench.py (default flags)                   -> gpurun_out/<tag>/bench.json
+#          quick  = bench.py without the CPU / frame legs      -> gpurun_out/<tag>/bench_quick.json
+#          stats  = tools/trace_stats.py (needs variants/libptamd_stats.so)
+#          try:a,b = tools/try.sh a b (variant libraries)
+# A step that is killed by its timeout ends the session (no further GPU work after a hang).
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+out=gpurun_out/$tag; mkdir -p $out
+for step in "$@"; do
+  case $step in
+    micro) timeout -k 10 240 tools/micro/valu_issue 4096 > $out/valu_issue.md 2> $out/valu_issue.err; rc=$? ;;
+    tests) timeout -k 10 1500 python -m pytest tests -m gpu -q -x --durations=15 > $out/pytest.log 2>&1; rc=$?; tail -5 $out/pytest.log ;;
+    testsall) timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=15 > $out/pytest.log 2>&1; rc=$?; tail -15 $out/pytest.log ;;
+    bench) timeout -k 10 420 python bench.py > $out/bench.json 2> $out/bench.err; rc=$?; head -c 700 $out/bench.json; echo; tail -3 $out/bench.err ;;
+    quick) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 4 --warmup 1 --rounds 1 > $out/bench_quick.json 2> $out/bench_quick.err; rc=$?; head -c 400 $out/bench_quick.json; echo ;;
+    stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
+    try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
+    *) echo "unknown step $step"; rc=0 ;;
+  esac
+  echo "[$step] rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $step timed out: stopping"; exit $rc; fi
+done

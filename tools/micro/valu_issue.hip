@@ -37,14 +37,20 @@
 #define ACC8(op, mid) \
     op "%0" mid "%0\n\t" op "%1" mid "%1\n\t" op "%2" mid "%2\n\t" op "%3" mid "%3\n\t" op "%4" mid "%4\n\t" op "%5" mid "%5\n\t" op "%6" mid "%6\n\t" op "%7" mid "%7\n\t"
 #define ACC32(op, mid) ACC8(op, mid) ACC8(op, mid) ACC8(op, mid) ACC8(op, mid)
+#define ACC32F(op, tail) REP32(op, tail) /* v_fmac: the destination is the accumulator implicitly */
+// (compare, select) pairs on the eight registers: 16 instructions
+#define CC1(r) "v_cmp_lt_f32 vcc, %8, " r "\n\tv_cndmask_b32 " r ", %8, %9, vcc\n\t"
+#define CC8 CC1("%0") CC1("%1") CC1("%2") CC1("%3") CC1("%4") CC1("%5") CC1("%6") CC1("%7")
 
 enum Kind {
     K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
-    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_COUNT
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_COUNT
 };
 static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
     "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
-    "v_bfe_u32", "v_add_u32", "v_mov_b32", "v_perm_b32", "v_pk_fma_f32", "v_pk_mul_f32", "v_rcp_f32", "v_lshl_or_b32", "v_and_or_b32", "v_mad_u32_u24" };
+    "v_bfe_u32", "v_add_u32", "v_mov_b32", "v_perm_b32", "v_pk_fma_f32", "v_pk_mul_f32", "v_rcp_f32", "v_lshl_or_b32", "v_and_or_b32", "v_mad_u32_u24",
+    "v_cmp_lt_f32 vcc + v_cndmask_b32 (per instruction of the pair)", "v_cndmask_b32 (sgpr-pair mask, VOP3)", "v_or_b32", "v_max_f32", "v_min_u32", "v_cmp_lt_u32 (vcc)",
+    "v_lshl_add_u32", "v_mad_u64_u32", "v_sub_f32", "v_cvt_f32_i32", "v_fmac_f32 (VOP2)" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
@@ -55,7 +61,8 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
     f2 p0 = { r0, r1 }, p1 = { r2, r3 }, p2 = { r4, r5 }, p3 = { r6, r7 }, p4 = { r1, r0 }, p5 = { r3, r2 }, p6 = { r5, r4 }, p7 = { r7, r6 };
     f2 ps = { s, t };
     unsigned long long t0, t1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    unsigned long long rt0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memrealtime %1\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(rt0)::"memory");
     for (int i = 0; i < iters; i++) {
 #define OPS "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
         if (KIND == K_FMA) asm volatile(ACC32("v_fma_f32 ", ", %8, %9, ") : OPS : "v"(s), "v"(t));
@@ -82,25 +89,45 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
         if (KIND == K_LSHLOR) asm volatile(REP32("v_lshl_or_b32 ", ", %8, 8, %9") : OPS : "v"(s), "v"(t));
         if (KIND == K_ANDOR) asm volatile(REP32("v_and_or_b32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
         if (KIND == K_MADU24) asm volatile(REP32("v_mad_u32_u24 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        // 16 (compare, select) pairs: the select reads the mask the compare just wrote, as in the traversal's sorting network
+        if (KIND == K_CMPCND) asm volatile(CC8 CC8 : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_CND64) asm volatile(REP32("v_cndmask_b32 ", ", %8, %9, s[20:21]") : OPS : "v"(s), "v"(t), "s"(0) : "s20", "s21");
+        if (KIND == K_OR) asm volatile(REP32("v_or_b32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MAX) asm volatile(REP32("v_max_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MINU) asm volatile(REP32("v_min_u32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CMPU) asm volatile(REP32("v_cmp_lt_u32 vcc, %8, ", "") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_LSHLADD) asm volatile(REP32("v_lshl_add_u32 ", ", %8, 2, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_SUB) asm volatile(REP32("v_sub_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVTI) asm volatile(REP32("v_cvt_f32_i32 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_FMAC) asm volatile(ACC32F("v_fmac_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
 #undef OPS
         if (KIND == K_PKFMA)
             asm volatile(ACC32("v_pk_fma_f32 ", ", %8, %8, ")
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
                          : "v"(ps));
+        if (KIND == K_MAD64)
+            asm volatile(REP32("v_mad_u64_u32 ", ", vcc, %8, %8, 0")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "v"(s)
+                         : "vcc");
         if (KIND == K_PKMUL)
             asm volatile(REP32("v_pk_mul_f32 ", ", %8, %8")
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
                          : "v"(ps));
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    unsigned long long rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
     const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     float sink = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y;
-    if ((threadIdx.x & 63u) == 0u)
-        out[gwave] = (t1 - t0) | (sink == 12345.678f ? 1ull << 63 : 0ull);
+    if ((threadIdx.x & 63u) == 0u) {
+        out[2 * gwave] = (t1 - t0) | (sink == 12345.678f ? 1ull << 63 : 0ull);
+        out[2 * gwave + 1] = rt1 - rt0; // 100 MHz ticks over the same interval: shader clock = 100 MHz x (t1 - t0) / (r1 - r0)
+    }
 }
 
 template <int KIND>
-void runKind(unsigned long long* dOut, int iters, int numCUs, const int* wavesPerSimd, int nW, double* perWave, double* wallNsPerInst)
+void runKind(unsigned long long* dOut, int iters, int numCUs, const int* wavesPerSimd, int nW, double* perWave, double* wallNsPerInst, double* clockMHz, int instPerBlock = 32)
 {
     for (int wi = 0; wi < nW; wi++) {
         const int W = wavesPerSimd[wi];
@@ -119,13 +146,16 @@ void runKind(unsigned long long* dOut, int iters, int numCUs, const int* wavesPe
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         const size_t waves = (size_t)grid.x * wavesPerBlock;
-        std::vector<unsigned long long> h(waves);
-        CHECK(hipMemcpy(h.data(), dOut, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        double sum = 0;
-        for (auto v : h)
-            sum += (double)(v & ~(1ull << 63));
-        perWave[wi] = sum / (double)waves / ((double)iters * 32.0);
-        wallNsPerInst[wi] = (double)ms * 1e6 / ((double)iters * 32.0 * W); // wall ns per instruction per SIMD
+        std::vector<unsigned long long> h(2 * waves);
+        CHECK(hipMemcpy(h.data(), dOut, 2 * waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum = 0, real = 0;
+        for (size_t w = 0; w < waves; w++) {
+            sum += (double)(h[2 * w] & ~(1ull << 63));
+            real += (double)h[2 * w + 1];
+        }
+        perWave[wi] = sum / (double)waves / ((double)iters * instPerBlock);
+        clockMHz[wi] = 100.0 * sum / real;
+        wallNsPerInst[wi] = (double)ms * 1e6 / ((double)iters * instPerBlock * W); // wall ns per instruction per SIMD
         CHECK(hipEventDestroy(e0));
         CHECK(hipEventDestroy(e1));
     }
@@ -139,18 +169,20 @@ int main(int argc, char** argv)
     const int numCUs = prop.multiProcessorCount;
     const int W[5] = { 1, 2, 4, 7, 8 };
     unsigned long long* dOut = nullptr;
-    CHECK(hipMalloc((void**)&dOut, (size_t)numCUs * 32 * sizeof(unsigned long long)));
+    CHECK(hipMalloc((void**)&dOut, (size_t)numCUs * 32 * 2 * sizeof(unsigned long long)));
     printf("# VALU issue cost on %s (%d CUs), %d x 32 independent instructions per wave between two s_memtime stamps\n\n", prop.gcnArchName, numCUs, iters);
     printf("cycles per wave64 instruction: per wave (what one wave sees) / per SIMD (per-wave figure divided by the resident waves per SIMD)\n\n");
-    printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 |\n|---|---|---|---|---|---|---|\n");
-    double pw[5], ns[5];
+    printf("shader clock = 100 MHz x (s_memtime ticks) / (s_memrealtime ticks) over the measured interval; cycles = s_memtime ticks\n\n");
+    printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 | shader clock at W=8 (MHz) | class |\n|---|---|---|---|---|---|---|---|---|\n");
+    double pw[5], ns[5], mhz[5];
 #define RUN(K)                                                                                                                        \
-    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns);                                                                                   \
-    printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
-        pw[3] / 7, pw[4], pw[4] / 8, ns[4]);
+    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND ? 16 : 32);                                                      \
+    printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f | %.0f | %s |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
+        pw[3] / 7, pw[4], pw[4] / 8, ns[4], mhz[4], pw[4] / 8 < 1.6 ? "full rate" : (pw[4] / 8 < 3.0 ? "half rate" : "quarter rate or slower"));
     RUN(K_FMA) RUN(K_MUL) RUN(K_ADD) RUN(K_MIN) RUN(K_MAX3) RUN(K_MIN3) RUN(K_CVT_UB0) RUN(K_CVT_UB1) RUN(K_CVT_UB2) RUN(K_CVT_UB3) RUN(K_CVT_U32)
     RUN(K_CNDMASK) RUN(K_CMP) RUN(K_CMP_SGPR) RUN(K_AND) RUN(K_LSHR) RUN(K_BFE) RUN(K_ADDU) RUN(K_MOV) RUN(K_PERM) RUN(K_PKFMA) RUN(K_PKMUL) RUN(K_RCP)
-    RUN(K_LSHLOR) RUN(K_ANDOR) RUN(K_MADU24)
+    RUN(K_LSHLOR) RUN(K_ANDOR) RUN(K_MADU24) RUN(K_CMPCND) RUN(K_CND64) RUN(K_OR) RUN(K_MAX) RUN(K_MINU) RUN(K_CMPU) RUN(K_LSHLADD) RUN(K_MAD64) RUN(K_SUB)
+    RUN(K_CVTI) RUN(K_FMAC)
     CHECK(hipFree(dOut));
     return 0;
 }
