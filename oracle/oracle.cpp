@@ -678,6 +678,7 @@ struct ShadeIn {
     V3 rayOrigin; // MIS: inData->ray.origin (distance to an emissive hit, shading.cl:78-79)
     float pdf; // MIS: inData->pdf, the solid-angle density with which the previous bounce sampled this direction
     bool mis; // neeMisShading instead of neeIsShading
+    bool misAsCompiled; // ... with the density of a DIFFUSE continuation read as 0, as the reference's uninitialised read behaves in oracle/_ref
     bool weightedLights; // weightedRandomPointOnLight instead of randomPointOnLight
 };
 struct ShadeOut {
@@ -764,9 +765,13 @@ inline LightSample weightedRandomPointOnLight(const Scene& sc, V3 X, Rng& rng)
 //             `smoothness`, never -1, so the value is a material-texture fetch at a clamped layer;
 //   kept   -- its DIFFUSE light sample divides diffuseColour by pi without the alpha-0 check of the IS variant (:150);
 //   FIXED  -- its DIFFUSE continuation stores outData->pdf = dot(shadingNormal, reflection) / pi BEFORE `reflection` is
-//             assigned (:590-592): an uninitialised read, whatever the compiler makes of it.  Here the density is taken
-//             from the direction that is then sampled, which is what the comment next to it asks for ("MIS needs
-//             unsimplified PDF").  tests/test_oracle_vs_ref.py compares everything but that one field with the reference.
+//             assigned (:590-592): an uninitialised read, whatever the compiler makes of it.  In oracle/_ref (ROCm clang -O1
+//             for x86-64) it evaluates to 0: a light found by a diffuse bounce then contributes nothing (pdf2 < EPSILON, :87)
+//             although next event estimation was already weighted down by 1 / (pdf1 + pdf2) -- a biased (darker) estimator.
+//             `in.misAsCompiled` reproduces exactly that (ORC_INTEGRATOR_*_AS_COMPILED) and is bit-exact with the reference's
+//             COMPARE_SHADING build on whole queue loops (tests/test_oracle_vs_ref.py); the default takes the density from
+//             the direction that is then sampled, which is what the comment next to it asks for ("MIS needs unsimplified
+//             PDF") and what makes the two estimators agree.
 V3 neeShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
 {
     const Triangle& tri = sc.triangles[in.tri];
@@ -971,7 +976,7 @@ V3 neeShading(const Scene& sc, const ShadeIn& in, Rng& rng, ShadeOut& out)
         } else {
             reflection = cosineWeightedDiffuseReflection(realNormal, edge1, in.invT, rng);
             if (in.mis)
-                out.pdf = dot(shadingNormal, reflection) * kINVPI; // FIXED: after sampling, not before (see above; :590-592)
+                out.pdf = in.misAsCompiled ? 0.0f : dot(shadingNormal, reflection) * kINVPI; // FIXED: after sampling, not before (see above; :590-592)
             BRDF = c;
         }
     }
@@ -1036,7 +1041,7 @@ void orc_generatePrimaryRays(size_t global, OrcRayData* outRays, OrcKernelData* 
         Rng rng = rngLoad(p, streams, gid, rayIndex, 0);
         uint32_t x = rayIndex % kd->scrWidth;
         uint32_t y = rayIndex / kd->scrWidth;
-        if (p && p->integrator == ORC_INTEGRATOR_COMPARE && x >= kd->scrWidth / 2) // COMPARE_SHADING, kernel.cl:48-51: both halves
+        if (p && orcIsCompare(p->integrator) && x >= kd->scrWidth / 2) // COMPARE_SHADING, kernel.cl:48-51: both halves
             x -= kd->scrWidth / 2; // of the image show the left half's view, one per integrator
         OrcRayData& r = outRays[kd->numInRays + gid];
         V3 o, d;
@@ -1110,8 +1115,8 @@ void orc_shade(size_t global, OrcFloat3* outputPixels, OrcRayData* outRays, OrcR
                 in.rayOrigin = mk(ray.origin);
                 in.pdf = ray.pdf;
                 // COMPARE_SHADING (kernel.cl:248-265): neeMisShading for the pixels of the left half of the image
-                in.mis = p && (p->integrator == ORC_INTEGRATOR_MIS
-                              || (p->integrator == ORC_INTEGRATOR_COMPARE && (ray.outputPixel % kd->scrWidth) < kd->scrWidth / 2));
+                in.mis = p && (orcIsMis(p->integrator) || (orcIsCompare(p->integrator) && (ray.outputPixel % kd->scrWidth) < kd->scrWidth / 2));
+                in.misAsCompiled = p && (p->integrator == ORC_INTEGRATOR_MIS_AS_COMPILED || p->integrator == ORC_INTEGRATOR_COMPARE_AS_COMPILED);
                 in.weightedLights = p && p->lightSampling == ORC_LIGHTS_SOLID_ANGLE;
                 Rng rng = rngLoad(p, streams, gid, (uint32_t)ray.outputPixel, 1u + (uint32_t)ray.numBounces);
                 ShadeOut so;
@@ -1332,8 +1337,8 @@ void orc_render_ex(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSam
                     Rng rng = rngLoad(&prm, nullptr, 0, pixel, 0);
                     V3 o, d;
                     int x = (int)(pixel % kd->scrWidth), y = (int)(pixel / kd->scrWidth);
-                    const bool mis = integrator == ORC_INTEGRATOR_MIS || (integrator == ORC_INTEGRATOR_COMPARE && (uint32_t)x < kd->scrWidth / 2);
-                    if (integrator == ORC_INTEGRATOR_COMPARE && (uint32_t)x >= kd->scrWidth / 2)
+                    const bool mis = orcIsMis(integrator) || (orcIsCompare(integrator) && (uint32_t)x < kd->scrWidth / 2);
+                    if (orcIsCompare(integrator) && (uint32_t)x >= kd->scrWidth / 2)
                         x -= (int)(kd->scrWidth / 2);
                     float pdf = 0; // outRayData.pdf of the previous bounce (kernel.cl: primary rays carry 0)
                     if (kd->camera.thinLensEnabled)
@@ -1362,6 +1367,7 @@ void orc_render_ex(const OrcKernelData* kd, const OrcScene* s, uint32_t firstSam
                         in.rayOrigin = o;
                         in.pdf = pdf;
                         in.mis = mis;
+                        in.misAsCompiled = integrator == ORC_INTEGRATOR_MIS_AS_COMPILED || integrator == ORC_INTEGRATOR_COMPARE_AS_COMPILED;
                         in.weightedLights = lightSampling == ORC_LIGHTS_SOLID_ANGLE;
                         Rng srng = rngLoad(&prm, nullptr, 0, pixel, 1u + bounce);
                         ShadeOut so;

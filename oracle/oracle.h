@@ -77,7 +77,16 @@ enum { ORC_RNG_LFSR113 = 0, ORC_RNG_COUNTER = 1 };
 // (shading.cl:35-349), reachable there under #define COMPARE_SHADING only; or exactly that build: neeMisShading for the
 // pixels of the left half of the image, neeIsShading for the right half, both halves showing the left half's view
 // (kernel.cl:48-51,248-265)
-enum { ORC_INTEGRATOR_IS = 0, ORC_INTEGRATOR_MIS = 1, ORC_INTEGRATOR_COMPARE = 2 };
+enum {
+    ORC_INTEGRATOR_IS = 0,
+    ORC_INTEGRATOR_MIS = 1,
+    ORC_INTEGRATOR_COMPARE = 2,
+    // the same two with neeMisShading's uninitialised read (shading.cl:590-592) evaluating to 0, as it does in oracle/_ref
+    ORC_INTEGRATOR_MIS_AS_COMPILED = 3,
+    ORC_INTEGRATOR_COMPARE_AS_COMPILED = 4
+};
+inline bool orcIsMis(uint32_t i) { return i == ORC_INTEGRATOR_MIS || i == ORC_INTEGRATOR_MIS_AS_COMPILED; }
+inline bool orcIsCompare(uint32_t i) { return i == ORC_INTEGRATOR_COMPARE || i == ORC_INTEGRATOR_COMPARE_AS_COMPILED; }
 // how NEE picks its light: randomPointOnLight (uniform over the emissive triangles, shading_helper.cl:261-278) or
 // weightedRandomPointOnLight (proportional to the solid angle of each triangle seen from the shading point,
 // shading_helper.cl:216-259; not called by the reference's kernels)

@@ -20,6 +20,7 @@ from ptamd import layout as L  # noqa: E402  (layout definitions only: plain num
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 ORACLE_FAST_SO = os.path.join(_HERE, "liboracle_fast.so")
 REF_KERNELS_SO = os.path.join(_HERE, "_ref", "libref_kernels.so")
+REF_KERNELS_MIS_SO = os.path.join(_HERE, "_ref", "libref_kernels_mis.so")  # the same kernels built with -DCOMPARE_SHADING
 REF_ACCUM_SO = os.path.join(_HERE, "_ref", "libref_accumulate.so")
 REF_CLRNG_SO = os.path.join(_HERE, "_ref", "libref_clrng.so")
 
@@ -37,6 +38,7 @@ class SceneStruct(C.Structure):  # OrcScene == RefScene
 
 
 INTEGRATOR_IS, INTEGRATOR_MIS, INTEGRATOR_COMPARE = 0, 1, 2  # neeIsShading | neeMisShading | COMPARE_SHADING's half-and-half
+INTEGRATOR_MIS_AS_COMPILED, INTEGRATOR_COMPARE_AS_COMPILED = 3, 4  # ... with the reference's uninitialised pdf read as 0 (oracle/_ref)
 LIGHTS_UNIFORM, LIGHTS_SOLID_ANGLE = 0, 1  # randomPointOnLight | weightedRandomPointOnLight
 
 
@@ -81,8 +83,14 @@ def oracle(fast=False):
     return lib
 
 
-def ref_kernels():
-    return _load(REF_KERNELS_SO)
+def ref_kernels(compare_shading=False):
+    """The reference's kernels for the host; compare_shading: its COMPARE_SHADING build (kernel.cl:6) -- neeMisShading for
+    the left half of the image, neeIsShading for the right half, both halves showing the left half's view."""
+    return _load(REF_KERNELS_MIS_SO if compare_shading else REF_KERNELS_SO)
+
+
+def have_ref_mis():
+    return have_ref() and os.path.exists(REF_KERNELS_MIS_SO)
 
 
 def ref_accumulate():
@@ -172,21 +180,33 @@ class QueueState:
 
 
 def trace_rays(which, scene, camera, state, streams, params=None, max_passes=256, counters=None):
-    """One sample per pixel through the whole queue loop.  which: 'ref' or 'oracle'.
+    """One sample per pixel through the whole queue loop.  which: 'ref', 'ref_compare_shading' (the reference built with
+    -DCOMPARE_SHADING) or 'oracle' (integrator chosen by params).
     Returns the per-pass trace [(numInRays, newRays, rayOffset, numOutRays)]."""
     kd = scene.kernel_data(camera, state.width, state.height)
     trace = np.zeros((max_passes, 4), np.uint32)
-    if which == "ref":
-        n = ref_kernels().ref_trace_rays(_p(kd), C.c_uint32(state.max_rays), _p(state.rays[0]), _p(state.rays[1]),
+    if which in ("ref", "ref_compare_shading"):
+        n = ref_kernels(which == "ref_compare_shading").ref_trace_rays(_p(kd), C.c_uint32(state.max_rays), _p(state.rays[0]), _p(state.rays[1]),
                                          _p(state.shadow), _p(state.shading), _p(state.stack), _p(streams),
                                          _p(state.accum), C.byref(scene.struct), _p(trace), max_passes)
     else:
-        prm = params or Params(RNG_LFSR113, 0, 0, 0)
+        prm = params or Params(RNG_LFSR113, 0, 0, 0, INTEGRATOR_IS, LIGHTS_UNIFORM)
         n = oracle().orc_trace_rays(_p(kd), C.c_uint32(state.max_rays), _p(state.rays[0]), _p(state.rays[1]),
                                     _p(state.shadow), _p(state.shading), _p(streams), _p(state.accum),
                                     C.byref(scene.struct), C.byref(prm), _p(trace), max_passes,
                                     C.byref(counters) if counters is not None else None)
     return trace[:min(n, max_passes)].copy(), kd
+
+
+def weighted_light(which, scene, x, stream):
+    """weightedRandomPointOnLight (shading_helper.cl:216-259) at shading point x with one LFSR113 stream (advanced in place):
+    the reference's compiled function ('ref') or the oracle's restatement.  Returns (point, normal, colour, area)."""
+    x = np.ascontiguousarray(x, np.float32)
+    p, n, c = (np.zeros(3, np.float32) for _ in range(3))
+    area = C.c_float(0)
+    fn = ref_kernels().ref_test_weighted_light if which == "ref" else oracle().orc_weighted_light
+    fn(C.byref(scene.struct), C.c_uint32(len(scene.flat.lights)), _p(x), _p(stream), _p(p), _p(n), _p(c), C.byref(area))
+    return p, n, c, float(area.value)
 
 
 def intersect_batch(scene, o, d, tmax=None, any_hit=False, threads=1, fast=False, counters=None):

@@ -26,6 +26,13 @@ void shade(void* outputPixels, void* outRays, void* outShadowRays, void* inRays,
     void* kernelData, void* vertices, void* triangles, void* emissive, void* materials,
     void* materialTextures, void* skydomeTextures, void* streams);
 void updateKernelData(void* kernelData);
+
+// helpers of the same translation unit, called directly by the test door below
+typedef float ref_float3 __attribute__((ext_vector_type(3)));
+int clrngLfsr113CopyOverStreamsFromGlobal(size_t count, void* destStreams, const void* srcHostStreams);
+int clrngLfsr113CopyOverStreamsToGlobal(size_t count, void* destHostStreams, const void* srcStreams);
+void weightedRandomPointOnLight(const void* scene, ref_float3 intersection, void* randomStream, ref_float3* outPoint, ref_float3* outLightNormal,
+    ref_float3* outLightColour, float* outLightArea); // shading_helper.cl:216-259 (not called by any kernel)
 }
 
 namespace {
@@ -143,6 +150,34 @@ int ref_trace_rays(void* kdv, uint32_t maxRays, void* rays0, void* rays1, void* 
         out = t;
     }
     return pass;
+}
+
+// weightedRandomPointOnLight as the reference compiled it, on a Scene record filled like loadScene does (scene.cl:12-59).
+// hostStream48: a clrngLfsr113HostStream, advanced by the call (1 + 2 draws).
+void ref_test_weighted_light(const RefScene* s, uint32_t numEmissive, const float* x3, void* hostStream48, float* outPoint3,
+    float* outNormal3, float* outColour3, float* outArea)
+{
+    struct SceneRecord { // Scene, scene.cl:12-28 (96 bytes)
+        uint32_t numVertices, numTriangles, numEmissiveTriangles, numLights;
+        const void *vertices, *triangles, *meshMaterials, *emissiveTriangles, *subBvh, *topLevelBvh;
+        uint32_t topLevelBvhRoot;
+        float refractiveIndex;
+        int32_t cubemapTextureIndices[6];
+    } scene {};
+    static_assert(sizeof(SceneRecord) == 96, "Scene is 96 bytes");
+    scene.numEmissiveTriangles = numEmissive;
+    scene.vertices = s->vertices, scene.triangles = s->triangles, scene.meshMaterials = s->materials;
+    scene.emissiveTriangles = s->emissive, scene.subBvh = s->subBvh, scene.topLevelBvh = s->topBvh;
+    scene.refractiveIndex = 1.000277f;
+    alignas(16) unsigned char stream[64] = {}; // clrngLfsr113Stream: current state + pointer to the initial one
+    clrngLfsr113CopyOverStreamsFromGlobal(1, stream, hostStream48);
+    ref_float3 X = { x3[0], x3[1], x3[2] }, p, n, c;
+    float area = 0;
+    weightedRandomPointOnLight(&scene, X, stream, &p, &n, &c, &area);
+    clrngLfsr113CopyOverStreamsToGlobal(1, hostStream48, stream);
+    for (int k = 0; k < 3; k++)
+        outPoint3[k] = p[k], outNormal3[k] = n[k], outColour3[k] = c[k];
+    *outArea = area;
 }
 
 } // extern "C"

@@ -41,16 +41,30 @@
 // (compare, select) pairs on the eight registers: 16 instructions
 #define CC1(r) "v_cmp_lt_f32 vcc, %8, " r "\n\tv_cndmask_b32 " r ", %8, %9, vcc\n\t"
 #define CC8 CC1("%0") CC1("%1") CC1("%2") CC1("%3") CC1("%4") CC1("%5") CC1("%6") CC1("%7")
+#define CD1(r) "v_cmp_lt_f32_e64 s[20:21], %8, " r "\n\tv_cndmask_b32_e64 " r ", %8, %9, s[20:21]\n\t"
+#define CD8 CD1("%0") CD1("%1") CD1("%2") CD1("%3") CD1("%4") CD1("%5") CD1("%6") CD1("%7")
+// compare-exchange of (key ka, ref ra) with (key kb, ref rb): 5 instructions (the traversal's PT_CSWAP); %8 / %9 are scratch sources
+#define CX(ka, kb, ra, rb) "v_cmp_lt_f32 vcc, " kb ", " ka "\n\tv_cndmask_b32 " ka ", " ka ", " kb ", vcc\n\tv_cndmask_b32 " kb ", " kb ", %8, vcc\n\tv_cndmask_b32 " ra ", " ra ", " rb ", vcc\n\tv_cndmask_b32 " rb ", " rb ", %9, vcc\n\t"
+#define CY(ka, kb, ra, rb) "v_cmp_lt_f32_e64 s[20:21], " kb ", " ka "\n\tv_cndmask_b32_e64 " ka ", " ka ", " kb ", s[20:21]\n\tv_cndmask_b32_e64 " kb ", " kb ", %8, s[20:21]\n\tv_cndmask_b32_e64 " ra ", " ra ", " rb ", s[20:21]\n\tv_cndmask_b32_e64 " rb ", " rb ", %9, s[20:21]\n\t"
+// the same exchange with full-rate ops only (keys >= 0 as float bits): m = (kb - ka) >> 31 (all ones when kb < ka); x ^= (x ^ y) & m for keys and refs: 10 instructions
+#define CZ(ka, kb, ra, rb) "v_sub_u32 %8, " kb ", " ka "\n\tv_ashrrev_i32 %8, 31, %8\n\tv_xor_b32 %9, " ka ", " kb "\n\tv_and_b32 %9, %9, %8\n\tv_xor_b32 " ka ", " ka ", %9\n\tv_xor_b32 " kb ", " kb ", %9\n\tv_xor_b32 %9, " ra ", " rb "\n\tv_and_b32 %9, %9, %8\n\tv_xor_b32 " ra ", " ra ", %9\n\tv_xor_b32 " rb ", " rb ", %9\n\t"
+// packed keys (distance bits | slot): min / max, 2 instructions per exchange, the reference is looked up by slot afterwards
+#define CM(a, b) "v_min_u32 %8, " a ", " b "\n\tv_max_u32 " b ", " a ", " b "\n\tv_mov_b32 " a ", %8\n\t"
 
 enum Kind {
     K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
-    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_COUNT
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_COUNT
 };
 static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
     "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
     "v_bfe_u32", "v_add_u32", "v_mov_b32", "v_perm_b32", "v_pk_fma_f32", "v_pk_mul_f32", "v_rcp_f32", "v_lshl_or_b32", "v_and_or_b32", "v_mad_u32_u24",
     "v_cmp_lt_f32 vcc + v_cndmask_b32 (per instruction of the pair)", "v_cndmask_b32 (sgpr-pair mask, VOP3)", "v_or_b32", "v_max_f32", "v_min_u32", "v_cmp_lt_u32 (vcc)",
-    "v_lshl_add_u32", "v_mad_u64_u32", "v_sub_f32", "v_cvt_f32_i32", "v_fmac_f32 (VOP2)" };
+    "v_lshl_add_u32", "v_mad_u64_u32", "v_sub_f32", "v_cvt_f32_i32", "v_fmac_f32 (VOP2)",
+    "v_cndmask_b32_e32 (vcc written once before the loop)", "v_cndmask_b32_e64 with vcc as the explicit mask", "v_cmp_lt_f32_e64 s[20:21] + v_cndmask_b32_e64 s[20:21] (per instruction)",
+    "v_cmp_lt_f32 vcc + 4 x v_cndmask_b32_e32 vcc: one compare-exchange of (key, ref) (per instruction)",
+    "v_cmp_lt_f32_e64 s[20:21] + 4 x v_cndmask_b32_e64 s[20:21] (per instruction)",
+    "compare-exchange by full-rate ops: v_sub_f32, v_ashrrev_i32, 2 x (v_xor, v_and, v_xor, v_xor) (per instruction)", "v_ashrrev_i32", "v_xor_b32", "v_bfi_b32",
+    "compare-exchange of packed keys: v_min_u32 + v_max_u32 (per instruction)", "ds_write_b32 (own lane's slot)", "ds_read_b32 (own lane's slot)" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
@@ -61,6 +75,11 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
     f2 p0 = { r0, r1 }, p1 = { r2, r3 }, p2 = { r4, r5 }, p3 = { r6, r7 }, p4 = { r1, r0 }, p5 = { r3, r2 }, p6 = { r5, r4 }, p7 = { r7, r6 };
     f2 ps = { s, t };
     unsigned long long t0, t1;
+    __shared__ float ldsBuf[1024];
+    const unsigned ldsAddr = threadIdx.x * 4u;
+    ldsBuf[threadIdx.x] = s;
+    if (KIND == K_CND_VCC_SET || KIND == K_CND64_VCC)
+        asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(r0), "v"(r1) : "vcc");
     unsigned long long rt0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memrealtime %1\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(rt0)::"memory");
     for (int i = 0; i < iters; i++) {
@@ -100,6 +119,19 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
         if (KIND == K_SUB) asm volatile(REP32("v_sub_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
         if (KIND == K_CVTI) asm volatile(REP32("v_cvt_f32_i32 ", ", %8") : OPS : "v"(s), "v"(t));
         if (KIND == K_FMAC) asm volatile(ACC32F("v_fmac_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CND_VCC_SET) asm volatile(REP32("v_cndmask_b32 ", ", %8, %9, vcc") : OPS : "v"(s), "v"(t)); // vcc set before the loop, not clobbered
+        if (KIND == K_CND64_VCC) asm volatile(REP32("v_cndmask_b32_e64 ", ", %8, %9, vcc") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CMP64_CND64) asm volatile(CD8 CD8 : OPS : "v"(s), "v"(t) : "s20", "s21");
+        // 6 compare-exchanges of (key, ref) pairs: (r0,r1 | r2,r3), ... : compare keys, select both keys and both refs
+        if (KIND == K_CMP_4CND) asm volatile(CX("%0", "%1", "%2", "%3") CX("%4", "%5", "%6", "%7") CX("%0", "%4", "%2", "%6") CX("%1", "%5", "%3", "%7") CX("%1", "%4", "%3", "%6") CX("%0", "%1", "%2", "%3") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_CMP64_4CND64) asm volatile(CY("%0", "%1", "%2", "%3") CY("%4", "%5", "%6", "%7") CY("%0", "%4", "%2", "%6") CY("%1", "%5", "%3", "%7") CY("%1", "%4", "%3", "%6") CY("%0", "%1", "%2", "%3") : OPS : "v"(s), "v"(t) : "s20", "s21");
+        if (KIND == K_XORSWAP) asm volatile(CZ("%0", "%1", "%2", "%3") CZ("%4", "%5", "%6", "%7") CZ("%0", "%4", "%2", "%6") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(s), "+v"(t));
+        if (KIND == K_ASHR) asm volatile(REP32("v_ashrrev_i32 ", ", 31, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_XOR) asm volatile(REP32("v_xor_b32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_BFI) asm volatile(REP32("v_bfi_b32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MINMAX_SWAP) asm volatile(CM("%0", "%1") CM("%2", "%3") CM("%4", "%5") CM("%6", "%7") CM("%0", "%2") CM("%1", "%3") CM("%4", "%6") CM("%5", "%7") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(s));
+        if (KIND == K_DSW) asm volatile(REP32("ds_write_b32 %10, ", "") : OPS : "v"(s), "v"(t), "v"(ldsAddr) : "memory");
+        if (KIND == K_DSR) { asm volatile(REP32("ds_read_b32 ", ", %10") "s_waitcnt lgkmcnt(0)\n\t" : OPS : "v"(s), "v"(t), "v"(ldsAddr) : "memory"); }
 #undef OPS
         if (KIND == K_PKFMA)
             asm volatile(ACC32("v_pk_fma_f32 ", ", %8, %8, ")
@@ -176,13 +208,14 @@ int main(int argc, char** argv)
     printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 | shader clock at W=8 (MHz) | class |\n|---|---|---|---|---|---|---|---|---|\n");
     double pw[5], ns[5], mhz[5];
 #define RUN(K)                                                                                                                        \
-    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND ? 16 : 32);                                                      \
+    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND || K == K_CMP64_CND64 ? 16 : (K == K_CMP_4CND || K == K_CMP64_4CND64 || K == K_XORSWAP ? 30 : (K == K_MINMAX_SWAP ? 24 : 32)));                                                      \
     printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f | %.0f | %s |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
         pw[3] / 7, pw[4], pw[4] / 8, ns[4], mhz[4], pw[4] / 8 < 1.6 ? "full rate" : (pw[4] / 8 < 3.0 ? "half rate" : "quarter rate or slower"));
     RUN(K_FMA) RUN(K_MUL) RUN(K_ADD) RUN(K_MIN) RUN(K_MAX3) RUN(K_MIN3) RUN(K_CVT_UB0) RUN(K_CVT_UB1) RUN(K_CVT_UB2) RUN(K_CVT_UB3) RUN(K_CVT_U32)
     RUN(K_CNDMASK) RUN(K_CMP) RUN(K_CMP_SGPR) RUN(K_AND) RUN(K_LSHR) RUN(K_BFE) RUN(K_ADDU) RUN(K_MOV) RUN(K_PERM) RUN(K_PKFMA) RUN(K_PKMUL) RUN(K_RCP)
     RUN(K_LSHLOR) RUN(K_ANDOR) RUN(K_MADU24) RUN(K_CMPCND) RUN(K_CND64) RUN(K_OR) RUN(K_MAX) RUN(K_MINU) RUN(K_CMPU) RUN(K_LSHLADD) RUN(K_MAD64) RUN(K_SUB)
-    RUN(K_CVTI) RUN(K_FMAC)
+    RUN(K_CVTI) RUN(K_FMAC) RUN(K_CND_VCC_SET) RUN(K_CND64_VCC) RUN(K_CMP64_CND64) RUN(K_CMP_4CND) RUN(K_CMP64_4CND64) RUN(K_XORSWAP) RUN(K_ASHR) RUN(K_XOR) RUN(K_BFI)
+    RUN(K_MINMAX_SWAP) RUN(K_DSW) RUN(K_DSR)
     CHECK(hipFree(dOut));
     return 0;
 }

@@ -13,6 +13,9 @@ def read():
 
 def report(tag, s, nrays):
     it, act, ki, kl, ks, li, ll, ls, ho, hr = s[:10]
+    if it == 0:
+        print(f"{tag:12s} rays {nrays:8d}: not traced by k_trace (packet kernel)")
+        return
     print(f"{tag:12s} rays {nrays:8d} wave-iters/ray*64 {it*64/max(nrays,1):6.1f}  active/iter {act/max(it,1):5.1f}  iters inner/leaf/special {ki/it:.2f}/{kl/it:.2f}/{ks/it:.2f} "
           f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
     if s[16]:
