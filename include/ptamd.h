@@ -139,6 +139,17 @@ typedef struct {
 #define PT_FLAG_TWO_LEVEL_ONLY 4u /* copy only single-leaf instances (quads, lights) to world space, not whole meshes */
 #define PT_FLAG_NO_PACKETS 8u /* never use the packet traversal kernel (primary rays then go through the per-ray kernel) */
 #define PT_FLAG_PACKET_INTERSECT 16u /* pt_intersect (test hook) uses the packet kernel where the scene allows it */
+/* shade runs neeMisShading (assets/cl/shading.cl:35-349: NEE + BSDF sampling combined by the balance heuristic) instead of
+ * neeIsShading (:356-623), the integrator the reference compiles in.  The reference reaches its MIS code only under
+ * #define COMPARE_SHADING (kernel.cl:6); one uninitialised read in it is fixed here. */
+#define PT_FLAG_INTEGRATOR_MIS 32u
+/* exactly the reference's COMPARE_SHADING build (kernel.cl:48-51,248-265; raytracer.cpp:464-495): neeMisShading for the pixels of
+ * the left half of the image, neeIsShading for the right half, both halves showing the left half's view -- two estimators of one
+ * image side by side, whose mean luminances must agree */
+#define PT_FLAG_COMPARE_SHADING 64u
+/* next event estimation picks its light with probability proportional to the solid angle each emissive triangle subtends at the
+ * shading point (weightedRandomPointOnLight, shading_helper.cl:216-259) instead of uniformly (randomPointOnLight, :261-278) */
+#define PT_FLAG_SOLID_ANGLE_LIGHTS 128u
 
 typedef struct { uint32_t x0, y0, x1, y1; } pt_rect; /* [x0,x1) x [y0,y1) */
 

@@ -200,6 +200,7 @@ __device__ inline V3 cosineWeightedDiffuseReflection(V3 normal, V3 edge1, const 
 
 struct ShadeResult {
     V3 radiance; // deposited by shade itself
+    float pdf; // MIS: solid-angle density with which the continuation direction was sampled (outData->pdf)
     uint32_t flags; // continuation ray flags
     V3 origin, direction, throughput;
     uint32_t shadowFlags;
@@ -207,10 +208,66 @@ struct ShadeResult {
     float shadowLength;
 };
 
-// neeIsShading, shading.cl:356-623
-__device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u, float v, uint32_t prim, uint32_t instIdx,
-    V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out)
+// Options of the general shading kernel (k_shade<PARITY, true>); the default kernel is neeIsShading with uniform light choice.
+struct ShadeOpts {
+    bool mis; // neeMisShading (shading.cl:35-349) instead of neeIsShading (:356-623)
+    bool weightedLights; // weightedRandomPointOnLight (shading_helper.cl:216-259) instead of randomPointOnLight (:261-278)
+    V3 rayOrigin; // MIS: origin of the ray that was traced (distance to an emissive hit, shading.cl:78-79)
+    float inPdf; // MIS: inData->pdf
+};
+
+// material-texture fetch for diffuseColour (shading_helper.cl:280-307); x = -1 marks an alpha-0 texel.  Without a texture
+// array the fetch returns opaque white (what the oracle binds by default): only neeMisShading's PBR light sample can get
+// here without one, through its DIFFUSE view of a PBR record (see shadeHit).
+__device__ inline V3 diffuseColourTextured(const SceneDev& sc, const MatView& mat, const VertexShade& a0, const VertexShade& a1, const VertexShade& a2, float u, float v)
 {
+    if (!sc.materialTex.texels)
+        return mk(1.0f);
+    const float t0x = a0.n_u.w, t0y = a0.v_pad.x;
+    const float tcx = t0x + (a1.n_u.w - t0x) * u + (a2.n_u.w - t0x) * v;
+    const float tcy = t0y + (a1.v_pad.x - t0y) * u + (a2.v_pad.x - t0y) * v;
+    const float4 c = sampleLinearRepeat(sc.materialTex, tcx, tcy, (float)mat.texId);
+    return (c.w == 0.0f) ? mk(-1.0f) : xyz(c);
+}
+
+// weightedRandomPointOnLight, shading_helper.cl:216-259: the light is chosen with probability proportional to the solid
+// angle its centroid direction gives it (area * cos / dist^2, capped at 2 pi, not clamped at zero), one draw; the colour
+// carries weightTotal / numLights.  The reference keeps the weights in a 255-entry private array; here they are computed
+// twice (same arithmetic, same values) so that no per-lane array is needed.
+__device__ inline float lightWeight(const Light& lt, V3 X)
+{
+    const V3 centroid = (xyz(lt.v2) + xyz(lt.v1) + xyz(lt.v0)) / 3.0f;
+    V3 L = centroid - X;
+    const float dist2 = dot(L, L);
+    L = L / sqrtf(dist2);
+    const float solidAngle = (dot(xyz(lt.normal), -L) * lt.v0.w) / dist2;
+    return 2 * kPI < solidAngle ? 2 * kPI : solidAngle; // OpenCL min(2 pi, x)
+}
+__device__ inline int pickWeightedLight(const SceneDev& sc, V3 X, Rng& rng, float* weightTotalOut)
+{
+    const int n = (int)sc.numLights;
+    float weightTotal = 0;
+    for (int i = 0; i < n; i++)
+        weightTotal += lightWeight(sc.lights[i], X);
+    float randomValue = rng.u01() * weightTotal;
+    int li;
+    for (li = 0; li < n; ++li) {
+        randomValue -= lightWeight(sc.lights[li], X);
+        if (randomValue <= 0)
+            break;
+    }
+    *weightTotalOut = weightTotal;
+    return li; // == n when the walk falls off the end (negative weights): the caller treats that light as black, like the zeroed
+               // record the reference then reads
+}
+
+// neeIsShading, shading.cl:356-623; with GENERAL also neeMisShading, :35-349 (the two differ in four places, marked MIS below;
+// what is kept and what is fixed of the reference's MIS code: oracle/oracle.cpp, neeShading) and weighted light choice
+template <bool GENERAL>
+__device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u, float v, uint32_t prim, uint32_t instIdx,
+    V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out, const ShadeOpts& opt)
+{
+    const bool MIS = GENERAL && opt.mis;
     const TriShade ts = sc.triShade[prim];
     const TriIsect* tp = &sc.tris[prim];
     const float4 ta = tp->a, tb = tp->b, tc = tp->c;
@@ -226,12 +283,28 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
     const MatView mat = loadMaterial(sc, ts.material);
     out.radiance = mk(0.0f);
     out.flags = 0;
+    out.pdf = 0.f;
     out.shadowFlags = FLAG_FINISHED;
 
     if (mat.type == MAT_EMISSIVE) { // :387-397
         out.flags = FLAG_FINISHED;
-        if (inFlags & FLAG_LASTSPECULAR)
+        if (inFlags & FLAG_LASTSPECULAR) {
             out.radiance = throughput * mat.colour;
+        } else if (MIS) { // shading.cl:69-90: a BSDF-sampled direction found the light: balance heuristic against NEE's density
+            const V3 v0 = mk(ta.x, ta.y, ta.z), v1 = v0 + edge1, v2 = v0 + edge2; // object space, as the reference
+            const V3 A = v1 - v0, B = v2 - v1, C = v0 - v2;
+            const float la = sqrtf(dot(A, A)), lb = sqrtf(dot(B, B)), lc = sqrtf(dot(C, C));
+            const float hs = (la + lb + lc) / 2.0f;
+            const float lightArea = sqrtf(hs * (hs - la) * (hs - lb) * (hs - lc));
+            const V3 distV = X - opt.rayOrigin;
+            float solidAngle = (dot(realNormal, -D) * lightArea) / dot(distV, distV);
+            solidAngle = 2 * kPI < solidAngle ? 2 * kPI : solidAngle;
+            const float pdf2 = opt.inPdf;
+            if (solidAngle > kEPS && !(pdf2 < kEPS)) {
+                const float pdf1 = 1 / solidAngle;
+                out.radiance = throughput * mat.colour * (pdf2 / (pdf1 + pdf2));
+            }
+        }
         return;
     }
 
@@ -247,26 +320,58 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
 
     V3 BRDF = mk(0.0f);
     if (mat.type != MAT_REFRACTIVE && mat.type != MAT_BASIC_REFRACTIVE) { // NEE, :399-448
-        const int li = rng.randomInteger(0, (int)sc.numLights - 1);
-        const Light lt = sc.lights[li];
+        int li;
+        float colourScale = 1.0f;
+        if (GENERAL && opt.weightedLights) {
+            float weightTotal;
+            li = pickWeightedLight(sc, X, rng, &weightTotal);
+            colourScale = weightTotal / (float)sc.numLights;
+        } else {
+            li = rng.randomInteger(0, (int)sc.numLights - 1);
+        }
+        Light lt = sc.lights[min(li, (int)sc.numLights - 1)];
+        if (GENERAL && li >= (int)sc.numLights) // past the end (see pickWeightedLight): a zero-area, black light
+            lt.colour = lt.v0 = lt.v1 = lt.v2 = make_float4(0.f, 0.f, 0.f, 0.f), lt.normal = make_float4(NAN, NAN, NAN, 0.f);
         const float u1 = rng.u01(), u2 = rng.u01();
         const V3 lightPos = (1 - sqrtf(u1)) * xyz(lt.v0) + (sqrtf(u1) * (1 - u2)) * xyz(lt.v1) + (sqrtf(u1) * u2) * xyz(lt.v2);
         const V3 lightNormal = xyz(lt.normal);
+        const V3 lightColour = GENERAL ? xyz(lt.colour) * colourScale : xyz(lt.colour);
         V3 L = lightPos - X;
         const float dist2 = dot(L, L);
         const float dist = sqrtf(dist2);
         L = L / dist;
         if (dot(shadingNormal, L) > kEPS && dot(realNormal, L) > kEPS && dot(lightNormal, -L) > kEPS) {
-            if (mat.type == MAT_PBR)
+            float pdf2 = 0.0f; // MIS: density with which the BSDF sampling below would have produced L
+            if (mat.type == MAT_PBR && MIS) { // shading.cl:116-146
+                const V3 halfway = normalize(-D + L);
+                const V3 F = F_Schlick(pbrF0(mat), 1.0f, saturate(dot(L, halfway)));
+                const float rand01 = rng.u01();
+                if (!mat.metallic && rand01 > F.x)
+                    pdf2 = dot(shadingNormal, L) / kPI; // cosine weighted PDF
+                else
+                    pdf2 = D_GGX(dot(shadingNormal, halfway), 1.0f - mat.p0);
+                // sic: diffuseColour() of a PBR record -- tex_id is the bit pattern of `smoothness`, never -1, so this is a
+                // material-texture fetch at a clamped layer (pbrBrdf's value, shading.cl:117, is overwritten there)
+                const V3 c = diffuseColourTextured(sc, mat, a0, a1, a2, u, v);
+                BRDF = (c.x == -1.0f) ? mk(0.0f) : c / kPI;
+            } else if (mat.type == MAT_PBR) {
                 BRDF = pbrBrdfWithDiffuse(-D, L, shadingNormal, mat, mat.p0 > kMaxSmoothness);
-            else if (mat.type == MAT_DIFFUSE)
+            } else if (mat.type == MAT_DIFFUSE && MIS) { // shading.cl:148-152
+                BRDF = albedo / kPI; // sic: no alpha-0 check in this variant
+                pdf2 = dot(realNormal, L) / kPI;
+            } else if (mat.type == MAT_DIFFUSE) {
                 BRDF = (albedo.x == -1.0f) ? mk(0.0f) : albedo / kPI;
+            }
             float solidAngle = 2 * kPI;
             if (dist2 > kEPS) {
                 solidAngle = (dot(lightNormal, -L) * lt.v0.w) / dist2;
                 solidAngle = fminf(fmaxf(solidAngle, 0.0f), 2 * kPI);
             }
-            const V3 Ld = (float)sc.numLights * xyz(lt.colour) * BRDF * solidAngle * dot(shadingNormal, L);
+            V3 Ld;
+            if (MIS) // shading.cl:153-163
+                Ld = (float)sc.numLights * lightColour * BRDF * dot(realNormal, L) / (1 / solidAngle + pdf2);
+            else
+                Ld = (float)sc.numLights * lightColour * BRDF * solidAngle * dot(shadingNormal, L);
             out.shadowFlags = 0;
             out.shadowContribution = Ld * throughput;
             out.shadowOrigin = X + L * kEPS;
@@ -291,6 +396,8 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
         const V3 halfway = orient(mk(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta), shadingNormal, mk(1.0f, 0.0f, 0.0f), in);
         reflection = normalize(2 * dot(halfway, V) * halfway - V);
+        if (MIS) // the density ggxWeightedImportanceDirection reports (shading_helper.cl:162-175); "MIS needs real PDF", shading.cl:210
+            out.pdf = D_GGX(dot(halfway, shadingNormal), alpha);
         cosineTerm = dot(shadingNormal, reflection);
         if (cosineTerm < 0.05f || dot(realNormal, reflection) < kEPS) {
             out.flags = FLAG_FINISHED;
@@ -304,6 +411,8 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
             reflection = cosineWeightedDiffuseReflection(shadingNormal, edge1, in, rng);
             PDF = kINVPI;
             cosineTerm = 1.0f;
+            if (MIS)
+                out.pdf = dot(shadingNormal, reflection) * kINVPI; // MIS needs the real unsimplified PDF (shading.cl:205)
             // diffuseOnly, pbr_brdf.cl:217-237
             const float NdotV = fabsf(dot(shadingNormal, V)) + 1e-5f;
             const float Fd = Fr_DisneyDiffuse(NdotV, saturate(dot(shadingNormal, reflection)), saturate(dot(reflection, halfway)), sqrtf(roughness));
@@ -390,6 +499,8 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
             BRDF = mk(1.0f);
         } else {
             reflection = cosineWeightedDiffuseReflection(realNormal, edge1, in, rng);
+            if (MIS) // taken from the direction just sampled; the reference reads `reflection` before assigning it (:590-592)
+                out.pdf = dot(shadingNormal, reflection) * kINVPI;
             BRDF = albedo;
         }
     }
@@ -422,7 +533,11 @@ struct FrameParams {
     uint32_t interleave; // k_gen: samples of one pixel in consecutive queue entries (a power of two dividing planes)
     uint32_t interleaveShift; // log2 of it
     float invWidth;
+    uint32_t integrator; // 0: neeIsShading; 1: neeMisShading; 2: COMPARE_SHADING -- MIS for the pixels of the left half of the
+                         // image, IS for the right half, both halves showing the left half's view (kernel.cl:48-51,248-265)
+    uint32_t weightedLights; // NEE picks its light by weightedRandomPointOnLight instead of randomPointOnLight
 };
+enum : uint32_t { INTEGRATOR_IS = 0, INTEGRATOR_MIS = 1, INTEGRATOR_COMPARE = 2 };
 
 // generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th (pixel, sample) pair to
 // issue into queue slot slotBase + i.  With one sample in flight: pixel = pixelList[first + i] (or the index itself
@@ -459,7 +574,9 @@ __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const u
         py--;
     if ((py + 1u) * fp.width <= pixel)
         py++;
-    const uint32_t px = pixel - py * fp.width;
+    uint32_t px = pixel - py * fp.width;
+    if (fp.integrator == INTEGRATOR_COMPARE && px >= fp.width / 2u) // COMPARE_SHADING, kernel.cl:48-51
+        px -= fp.width / 2u;
     Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
     V3 o, d;
     cameraRay(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, &o, &d);
@@ -500,7 +617,9 @@ struct ShadeArgs {
 #endif
 constexpr int kShadeBlock = PT_SHADE_BLOCK;
 
-template <bool PARITY>
+// GENERAL = false: the integrator the reference compiles in (neeIsShading, uniform light choice) -- the production kernel;
+// GENERAL = true: integrator and light choice selected by a.fp at run time (MIS, COMPARE_SHADING, weighted lights).
+template <bool PARITY, bool GENERAL = false>
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,7 +646,16 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
                 shaded = true;
                 const V3 X = o + h.x * d;
                 Rng rng = PARITY ? rngLfsrLoad(a.streams, i) : rngCounter(pixel, a.fp.sample + plane, a.fp.seed, 1u + bounce);
-                shadeHit(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r);
+                ShadeOpts opt;
+                opt.mis = opt.weightedLights = false;
+                if (GENERAL) {
+                    opt.mis = a.fp.integrator == INTEGRATOR_MIS
+                        || (a.fp.integrator == INTEGRATOR_COMPARE && (pixel % a.fp.width) < a.fp.width / 2u);
+                    opt.weightedLights = a.fp.weightedLights != 0u;
+                    opt.rayOrigin = o;
+                    opt.inPdf = thr.w; // 0 for primary rays (they carry LASTSPECULAR: never consulted)
+                }
+                shadeHit<GENERAL>(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r, opt);
                 if (PARITY)
                     rngLfsrStore(a.streams, i, rng);
                 if (r.radiance.x != 0.f || r.radiance.y != 0.f || r.radiance.z != 0.f) {
@@ -562,7 +690,7 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
         if (shaded) {
             a.out.o[i] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
             a.out.d[i] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane)));
-            a.out.thr[i] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+            a.out.thr[i] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, GENERAL ? r.pdf : 0.f);
             a.shadow.o[i] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
             a.shadow.d[i] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
             a.shadow.c[i] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(r.shadowFlags, 0u, plane)));
@@ -607,7 +735,7 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
         const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);
         a.out.o[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
         a.out.d[idx] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane)));
-        a.out.thr[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+        a.out.thr[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, GENERAL ? r.pdf : 0.f);
     }
     if (emitShadow) {
         const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);

@@ -164,6 +164,8 @@ int guarded(pt_ctx* c, const char* what, F&& body)
 inline AccumView accumView(const pt_ctx* c) { return { c->accum, c->accumPlanes.p, c->pixelOrdinal.p, c->planes - 1u }; }
 inline uint32_t maxBounces(const pt_ctx* c) { return c->cfg.max_bounces ? c->cfg.max_bounces : 4u; }
 inline bool parityMode(const pt_ctx* c) { return c->cfg.rng_mode == PT_RNG_LFSR113_PARITY; }
+// anything but the integrator the reference compiles in (neeIsShading, uniform light choice) runs the general shading kernel
+inline bool generalShading(const pt_ctx* c) { return (c->cfg.flags & (PT_FLAG_INTEGRATOR_MIS | PT_FLAG_COMPARE_SHADING | PT_FLAG_SOLID_ANGLE_LIGHTS)) != 0u; }
 
 void refreshSceneView(pt_ctx* c)
 {
@@ -555,6 +557,8 @@ FrameParams frameParams(const pt_ctx* c, uint32_t sample)
     fp.interleave = 1;
     fp.interleaveShift = 0;
     fp.invWidth = 1.0f / (float)c->cfg.width;
+    fp.integrator = (c->cfg.flags & PT_FLAG_COMPARE_SHADING) ? INTEGRATOR_COMPARE : ((c->cfg.flags & PT_FLAG_INTEGRATOR_MIS) ? INTEGRATOR_MIS : INTEGRATOR_IS);
+    fp.weightedLights = (c->cfg.flags & PT_FLAG_SOLID_ANGLE_LIGHTS) ? 1u : 0u;
     return fp;
 }
 
@@ -663,7 +667,10 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
         a.out = c->stagedRays.view();
         a.shadow = c->stagedShadow.view();
         a.activeFlag = c->activeFlag.p;
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+        if (generalShading(c))
+            hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
         CompactArgs ca {};
         ca.staged = c->stagedRays.view();
         ca.out = c->rays[out].view();
@@ -678,7 +685,10 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     } else {
         a.out = c->rays[out].view();
         a.shadow = c->shadow.view();
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+        if (generalShading(c))
+            hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
     }
 }
 
@@ -1872,7 +1882,10 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
         a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u };
         a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3, a.deposits = dCtl.p + 4;
-        hipLaunchKernelGGL(k_shade<false>, dim3(1), dim3(64), 0, c->stream, a);
+        if (generalShading(c))
+            hipLaunchKernelGGL((k_shade<false, true>), dim3(1), dim3(64), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_shade<false, false>), dim3(1), dim3(64), 0, c->stream, a);
         uint32_t back[4];
         float4 px;
         chk(hipMemcpyAsync(back, dCtl.p, sizeof(back), hipMemcpyDeviceToHost, c->stream));

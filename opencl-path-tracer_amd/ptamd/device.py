@@ -14,6 +14,9 @@ FLAG_NO_BAKED_INSTANCES = 2  # every instance stays two-level
 FLAG_TWO_LEVEL_ONLY = 4  # only single-leaf instances are copied to world space
 FLAG_NO_PACKETS = 8  # primary rays through the per-ray kernel too
 FLAG_PACKET_INTERSECT = 16  # the pt_intersect hook uses the packet kernel where the scene allows it
+FLAG_INTEGRATOR_MIS = 32  # neeMisShading instead of neeIsShading
+FLAG_COMPARE_SHADING = 64  # the reference's COMPARE_SHADING build: MIS on the left half of the image, IS on the right, same view
+FLAG_SOLID_ANGLE_LIGHTS = 128  # NEE picks lights by weightedRandomPointOnLight
 
 
 class Config(C.Structure):
