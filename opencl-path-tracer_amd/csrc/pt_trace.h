@@ -54,6 +54,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_VOTE_INNER 2 // an inner step runs when 2 * (lanes wanting one) >= 3 * (lanes wanting a leaf): leaf steps are the
 #define PT_VOTE_LEAF 3 // long ones (sequential triangle fetches), so they are not left waiting for a majority
 #endif
+#ifndef PT_INTKEYS
+#define PT_INTKEYS 0 // 1: integer child keys, visibility and push counts by sign-bit arithmetic (no lane masks)
+#endif
+#ifndef PT_CLOSEST_PARTIAL_SORT
+#define PT_CLOSEST_PARTIAL_SORT 0 // 1: closest-hit rays also only bring the nearest visible child to the front
+#endif
+#ifndef PT_LEAF_SINGLE
+#define PT_LEAF_SINGLE 0 // 1: a leaf step tests ONE triangle per lane; lanes with more stay in the leaf for the next vote
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
@@ -410,6 +419,44 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                     const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
                     const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
+#if PT_INTKEYS
+                    // Child ordering on INTEGER keys, with no lane mask on the way (measured, profiles/round2 valu_issue: a
+                    // compare whose mask the next instruction selects on stalls the issue port for ~8 cycles; v_sub / shifts /
+                    // and / or / xor are full-rate instructions, compares, selects, min / max half-rate):
+                    //   key = bits of max(tmin, 0) -- ordered like the distances -- or >= 0x7F800000 when the box is not visible.
+                    uint32_t key[4];
+                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
+                        const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
+                        const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
+                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
+                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                        const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
+                        // max(tmin, 0) on the bit patterns as signed integers: negative distances (and -0) become +0
+                        const uint32_t tloBits = (uint32_t)max((int32_t)asU(tmin), 0);
+                        const float tlo = asF(tloBits);
+                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box: tmax >= tmin && tmax >= 0 &&
+                        // tmin < closest  <=>  tmax >= tlo && tlo < closest (closest > 0).  Sign bit of the OR <=> rejected;
+                        // at tlo == closest the box is entered although the reference would not: nothing in it can be
+                        // accepted (a hit needs t < closest), the result is the same.
+                        const uint32_t rejected = asU(tmax - tlo) | asU(tClosest - tlo);
+                        key[k] = tloBits | ((uint32_t)((int32_t)rejected >> 31) & 0x7F800000u);
+                    }
+#define PT_VISIBLE(k) ((key[k] - 0x7F800000u) >> 31) /* 1 when key < 0x7F800000 */
+#define PT_CSWAP(i, j)                                   \
+    {                                                    \
+        const bool sw = key[j] < key[i];                 \
+        const uint32_t tk = sw ? key[j] : key[i];        \
+        key[j] = sw ? key[i] : key[j];                   \
+        key[i] = tk;                                     \
+        const uint32_t tr = sw ? ref[j] : ref[i];        \
+        ref[j] = sw ? ref[i] : ref[j];                   \
+        ref[i] = tr;                                     \
+    }
+#else
                     float key[4];
                     uint32_t ref[4] = { D.x, D.y, D.z, D.w };
 #pragma unroll
@@ -425,6 +472,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest;
                         key[k] = vis ? tmin : INFINITY;
                     }
+#define PT_VISIBLE(k) (key[k] < INFINITY ? 1 : 0)
                     // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
 #define PT_CSWAP(i, j)                                   \
     {                                                    \
@@ -436,8 +484,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         ref[j] = sw ? ref[i] : ref[j];                   \
         ref[i] = tr;                                     \
     }
+#endif
 #if PT_ANYHIT_SORT == 0
-                    if (ANY_HIT) { // any occluder will do: only move a visible child to the front
+                    if (ANY_HIT || PT_CLOSEST_PARTIAL_SORT) { // any occluder will do: only move the nearest visible child to the front
                         PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2)
                     } else
 #endif
@@ -450,31 +499,32 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         // common case, branch-free: every candidate is stored, the stack pointer only moves past the
                         // ones that are kept (a rejected one is overwritten by the next store)
                         ldsStack[wave][sp][lane] = ref[3];
-                        sp += key[3] < INFINITY ? 1 : 0;
+                        sp += (int)PT_VISIBLE(3);
                         ldsStack[wave][sp][lane] = ref[2];
-                        sp += key[2] < INFINITY ? 1 : 0;
+                        sp += (int)PT_VISIBLE(2);
                         ldsStack[wave][sp][lane] = ref[1];
-                        sp += key[1] < INFINITY ? 1 : 0;
+                        sp += (int)PT_VISIBLE(1);
                     } else {
-                        if (key[3] < INFINITY) {
+                        if (PT_VISIBLE(3)) {
                             push(sp, ref[3]);
                             sp++;
                         }
-                        if (key[2] < INFINITY) {
+                        if (PT_VISIBLE(2)) {
                             push(sp, ref[2]);
                             sp++;
                         }
-                        if (key[1] < INFINITY) {
+                        if (PT_VISIBLE(1)) {
                             push(sp, ref[1]);
                             sp++;
                         }
                     }
                     // no visible child => nothing was pushed => the prefetched stack top is still the top
                     const uint32_t next = popTop(stackTop);
-                    if (key[0] < INFINITY)
+                    if (PT_VISIBLE(0))
                         cur = ref[0];
                     else
                         cur = next, sp = max(sp - 1, 0);
+#undef PT_VISIBLE
                 }
                 PT_TOC(11, tInner);
             } else {
@@ -483,7 +533,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_TIC(tLeaf);
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
-                    const uint32_t first = refIndex(cur), n = kindBits;
+                    const uint32_t first = refIndex(cur), n = PT_LEAF_SINGLE ? 1u : kindBits;
                     bool done = false;
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
@@ -517,6 +567,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             a.occluded[rayIdx] = 1u;
                         active = false;
                         cur = kRefFinish;
+                    } else if (PT_LEAF_SINGLE && kindBits > 1u) {
+                        cur += 1u - (1u << kRefIndexBits); // next triangle of the leaf, one fewer to go
                     } else {
                         cur = popTop(stackTop);
                         sp = max(sp - 1, 0);

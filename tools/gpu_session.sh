@@ -17,6 +17,7 @@ for step in "$@"; do
     testsall) timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=15 > $out/pytest.log 2>&1; rc=$?; tail -15 $out/pytest.log ;;
     bench) timeout -k 10 420 python bench.py > $out/bench.json 2> $out/bench.err; rc=$?; head -c 700 $out/bench.json; echo; tail -3 $out/bench.err ;;
     quick) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 4 --warmup 1 --rounds 1 > $out/bench_quick.json 2> $out/bench_quick.err; rc=$?; head -c 400 $out/bench_quick.json; echo ;;
+    pytest:*) timeout -k 10 900 python -m pytest ${step#pytest:} -m gpu -q -x > $out/pytest_sel.log 2>&1; rc=$?; tail -8 $out/pytest_sel.log ;;
     stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
     try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
     *) echo "unknown step $step"; rc=0 ;;
