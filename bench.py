@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=5, help="batches per step (5: the driver's 20 steps time ~12 s of rendering)")
     ap.add_argument("--in-flight", type=int, default=256, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
+    ap.add_argument("--max-entries", type=int, default=MAX_ENTRIES, help="path segments resident per rank (memory: ~190 B each)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")
@@ -257,7 +258,7 @@ def main():
     flat = bundle.flat
     rects = tile_rects(W, Hh, rank, world) if world > 1 else []
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
-    in_flight = plan_in_flight(args.in_flight, world, owned)
+    in_flight = plan_in_flight(args.in_flight, world, owned, args.max_entries)
     if world > 1:  # every rank must use the same batch: the smallest share decides
         t = torch.tensor([in_flight], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)

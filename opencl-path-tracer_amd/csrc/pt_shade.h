@@ -619,12 +619,19 @@ constexpr int kShadeBlock = PT_SHADE_BLOCK;
 
 // GENERAL = false: the integrator the reference compiles in (neeIsShading, uniform light choice) -- the production kernel;
 // GENERAL = true: integrator and light choice selected by a.fp at run time (MIS, COMPARE_SHADING, weighted lights).
+// The launch does not know how many entries are live (the count is a device word: no read-back anywhere in the schedule) and
+// covers the queue's capacity, while the queue of a later bounce holds 5-30 % of that: a workgroup whose tile lies beyond the
+// live entries leaves at once, before any ballot, LDS traffic or barrier.  (A grid sized to the machine with every workgroup
+// walking tiles in a loop was built too: the loop keeps the scene pointers live across iterations -- 128 instead of 96 VGPRs and
+// spills.)
 template <bool PARITY, bool GENERAL = false>
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
+    const uint32_t count = *a.inCount;
+    if (blockIdx.x * kShadeBlock >= count) // uniform for the workgroup
+        return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t count = *a.inCount;
     bool emitRay = false, emitShadow = false, shaded = false, deposited = false;
     ShadeResult r;
     uint32_t pixel = 0, bounce = 0, plane = 0;

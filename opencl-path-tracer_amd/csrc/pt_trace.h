@@ -60,6 +60,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_CLOSEST_PARTIAL_SORT
 #define PT_CLOSEST_PARTIAL_SORT 0 // 1: closest-hit rays also only bring the nearest visible child to the front
 #endif
+#ifndef PT_INLINE_FINISH
+#define PT_INLINE_FINISH 0 // 1: a ray that has nothing left to traverse retires inside the hot loop (hit record stored at once / its
+#endif                     // index queued in LDS for a batched deposit) instead of parking its lane until the loop breaks
+#ifndef PT_DEPOSIT_BATCH
+#define PT_DEPOSIT_BATCH 40 // any-hit: queued unoccluded rays that trigger a deposit pass
+#endif
 #ifndef PT_LEAF_SINGLE
 #define PT_LEAF_SINGLE 0 // 1: a leaf step tests ONE triangle per lane; lanes with more stay in the leaf for the next vote
 #endif
@@ -125,6 +131,13 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
+#if PT_INLINE_FINISH
+    // any-hit: queue entries of the unoccluded rays that have finished and wait for their deposit (made in batches of
+    // >= PT_DEPOSIT_BATCH: the three dependent memory accesses of a deposit then stall the wave once per batch, and the lanes of
+    // the finished rays are free for new rays at once)
+    __shared__ uint32_t ldsDone[ANY_HIT ? kTraceBlock / 64 : 1][ANY_HIT ? 128 : 1];
+    uint32_t doneCount = 0; // wave-uniform
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -153,6 +166,25 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
 #ifdef PT_TRACE_STATS
     unsigned long long statAcc[24] = {};
     PT_TIC(tKernel);
+#endif
+#if PT_INLINE_FINISH
+    auto flushDeposits = [&]() { // any-hit only
+        for (uint32_t base = 0; base < doneCount; base += 64u) {
+            const uint32_t e = base + lane;
+            if (e < doneCount) {
+                const uint32_t idx = ldsDone[ANY_HIT ? wave : 0][ANY_HIT ? e : 0];
+                const float4 contrib = a.rayC[idx];
+                const uint32_t pixel = asU(a.rayD[idx].w);
+                float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                float4 px = *ap;
+                px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                *ap = px;
+            }
+        }
+        if (lane == 0)
+            ldsDeposits[wave] += doneCount;
+        doneCount = 0;
+    };
 #endif
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
@@ -319,11 +351,13 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
                         *ap = px;
                     } else {
+#if !PT_INLINE_FINISH
                         if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of an instance: back to (original triangle, instance)
                             const float4 tc = sc.tris[hprim].c;
                             hprim = (int)asU(tc.y);
                             hinst = (int)asU(tc.z);
                         }
+#endif
                         a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
                         a.inst[rayIdx] = hinst;
                     }
@@ -380,7 +414,38 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             PT_STAT(1, nInner + nLeaf);
             // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
             // enough lanes are idle for a hand-out (and the queue still has rays)
+#if PT_INLINE_FINISH
+            unsigned long long mSpecial = __ballot(active && kindBits == kRefSpecial);
+            if (mSpecial != 0ull) { // wave-uniform
+                const bool fin = active && cur == kRefFinish;
+                const unsigned long long mFin = __ballot(fin);
+                if (mFin != 0ull) {
+                    if (ANY_HIT) {
+                        // unoccluded (an occluded ray retires in its leaf step): queue the deposit, free the lane
+                        if (doneCount + (uint32_t)__popcll(mFin) > 128u)
+                            flushDeposits();
+                        if (fin) {
+                            ldsDone[ANY_HIT ? wave : 0][ANY_HIT ? doneCount + (uint32_t)__popcll(mFin & ((1ull << lane) - 1ull)) : 0] = rayIdx;
+                            if (a.occluded)
+                                a.occluded[rayIdx] = 0u;
+                            active = false;
+                        }
+                        doneCount += (uint32_t)__popcll(mFin);
+                        if (doneCount >= PT_DEPOSIT_BATCH)
+                            flushDeposits();
+                    } else if (fin) {
+                        // closestT != maxT decides hit/miss (scene.cl:257); hprim / hinst already name the original triangle
+                        a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+                        a.inst[rayIdx] = hinst;
+                        active = false;
+                    }
+                    mSpecial &= ~mFin;
+                }
+            }
+            const int nSpecial = __popcll(mSpecial);
+#else
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
+#endif
             const int nWork = nInner + nLeaf;
             if (nWork == 0 || nSpecial >= (ANY_HIT ? kParkedBreakAny : kParkedBreak) || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
@@ -538,7 +603,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
+#if PT_INLINE_FINISH
+                        const float4 tcv = tp->c; // e2.z, and for a world-space copy of an instance: original triangle, instance
+                        const float tcx = tcv.x;
+#else
                         const float tcx = tp->c.x;
+#endif
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
                         const V3 P = cross(cd, e2);
                         const float det = dot(e1, P);
@@ -558,8 +628,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             tClosest = t;
                             hu = u;
                             hv = v;
+#if PT_INLINE_FINISH
+                            // a hit at world level is a hit on a world-space copy: name the original triangle and instance now
+                            hprim = curInst < 0 ? (int)asU(tcv.y) : (int)(first + k);
+                            hinst = curInst < 0 ? (int)asU(tcv.z) : curInst;
+#else
                             hprim = (int)(first + k);
                             hinst = curInst;
+#endif
                         }
                     }
                     if (ANY_HIT && done) { // occluded: nothing to deposit
@@ -578,6 +654,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             }
         }
     }
+#if PT_INLINE_FINISH
+    if (ANY_HIT && doneCount)
+        flushDeposits();
+#endif
     if (ANY_HIT && lane == 0 && ldsDeposits[wave])
         atomicAdd(&a.ctl->depositsShadow, ldsDeposits[wave]);
     PT_TOC(10, tKernel);

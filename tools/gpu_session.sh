@@ -18,6 +18,9 @@ for step in "$@"; do
     bench) timeout -k 10 420 python bench.py > $out/bench.json 2> $out/bench.err; rc=$?; head -c 700 $out/bench.json; echo; tail -3 $out/bench.err ;;
     quick) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 4 --warmup 1 --rounds 1 > $out/bench_quick.json 2> $out/bench_quick.err; rc=$?; head -c 400 $out/bench_quick.json; echo ;;
     pytest:*) timeout -k 10 900 python -m pytest ${step#pytest:} -m gpu -q -x > $out/pytest_sel.log 2>&1; rc=$?; tail -8 $out/pytest_sel.log ;;
+    vtest:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#vtest:}.so timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py tests/test_gpu_fullsize.py -m gpu -q -x > $out/vtest_${step#vtest:}.log 2>&1; rc=$?; tail -5 $out/vtest_${step#vtest:}.log ;;
+    inflight512) timeout -k 10 400 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 --in-flight 512 --max-entries 1100000000 > $out/bench_if512.json 2> $out/bench_if512.err; rc=$?; head -c 300 $out/bench_if512.json; echo; tail -2 $out/bench_if512.err ;;
+    quick2) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 > $out/bench_quick2.json 2> $out/bench_quick2.err; rc=$?; head -c 300 $out/bench_quick2.json; echo ;;
     stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
     try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
     *) echo "unknown step $step"; rc=0 ;;
