@@ -187,11 +187,16 @@ int pt_upload_static(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, cons
     const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 int pt_upload_dynamic(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
     const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
-/* kind 0: material textures (CLTextureArray 1024x1024 BGRA8 in the reference, src/raytracer.cpp:284),
- * kind 1: skydome (RGBA32F, src/raytracer.cpp:153-160).  data: layers*h*w*4 floats, RGBA, already
- * linear / brightness-scaled (what read_imagef would return).  Sampling reproduces
+/* kind 0: material textures (CLTextureArray 1024x1024, CL_BGRA / CL_UNORM_INT8 in the reference, src/raytracer.cpp:284,
+ * src/opencl/texture.cpp:112-131,148), kind 1: skydome (CL_RGBA / CL_FLOAT, src/raytracer.cpp:153-160, texture.cpp:96-110).
+ * format: the two image formats the reference creates (texture.cpp:133-164) --
+ *   PT_TEX_RGBA32F     data = layers*h*w*4 floats, r g b a, already linear / brightness-scaled (what read_imagef returns)
+ *   PT_TEX_BGRA8_UNORM data = layers*h*w*4 bytes, b g r a (the FreeImage 32-bit bitmap the reference uploads); a fetch
+ *                      returns byte / 255 like read_imagef on CL_UNORM_INT8; a quarter of the bytes per fetch.
+ * Rows bottom-up as FreeImage stores them (the reference uploads FreeImage_GetBits as is).  Sampling reproduces
  * CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_REPEAT | CLK_FILTER_LINEAR. */
-int pt_upload_texture_array(pt_ctx* ctx, int kind, uint32_t width, uint32_t height, uint32_t layers, const float* rgba);
+typedef enum { PT_TEX_RGBA32F = 0, PT_TEX_BGRA8_UNORM = 1 } pt_texture_format;
+int pt_upload_texture_array(pt_ctx* ctx, int kind, uint32_t width, uint32_t height, uint32_t layers, int format, const void* data);
 
 /* ---- per-frame state -- replaces the KernelData upload, src/raytracer.cpp:294-317 */
 int pt_set_camera(pt_ctx* ctx, const pt_camera* cam); /* does NOT clear; caller decides (src/raytracer.cpp:99-105) */

@@ -93,6 +93,8 @@ int pth_image_load_hdr(const char* path, uint32_t width, uint32_t height, float 
 int pth_image_png_info(const char* path, uint32_t* width, uint32_t* height);
 int pth_image_load_png_rgba8(const char* path, uint8_t* rgba_out);
 int pth_image_load_material_png(const char* path, uint32_t width, uint32_t height, int isLinear, float* rgba_out);
+/* the same layer as bytes b g r a, rows bottom-up: the bitmap the reference uploads (PT_TEX_BGRA8_UNORM) */
+int pth_image_load_material_png_bgra8(const char* path, uint32_t width, uint32_t height, int isLinear, uint8_t* bgra_out);
 
 #ifdef __cplusplus
 }

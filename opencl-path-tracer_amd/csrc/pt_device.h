@@ -93,9 +93,19 @@ struct Light { // EmissiveTriangle (light.cl:5-9) pre-digested: 80 B
 };
 
 struct Texture {
-    const float4* texels; // [layer][y][x]
-    int32_t width, height, layers, _pad;
+    const void* texels; // [layer][y][x]: float4 (format 0) or 4 bytes B, G, R, A as UNORM_INT8 (format 1)
+    int32_t width, height, layers;
+    int32_t format; // pt_texture_format
 };
+// one texel as read_imagef returns it: RGBA32F as stored; CL_BGRA / CL_UNORM_INT8 (the reference's material array,
+// src/opencl/texture.cpp:148) as byte / 255 with the channels back in r, g, b, a order
+__device__ inline float4 fetchTexel(const Texture& tex, size_t index)
+{
+    if (tex.format == 0)
+        return ((const float4*)tex.texels)[index];
+    const uint32_t p = ((const uint32_t*)tex.texels)[index];
+    return make_float4((float)((p >> 16) & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)(p & 0xFFu) / 255.0f, (float)(p >> 24) / 255.0f);
+}
 
 struct SceneDev {
     const PairNode* nodes; // the reference's binary tree, both boxes per node: host-side intermediate, not uploaded (null)

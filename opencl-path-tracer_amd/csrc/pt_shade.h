@@ -35,9 +35,9 @@ __device__ inline float4 sampleLinearRepeat(const Texture& tex, float s, float t
     const float b = (v - 0.5f) - floorf(v - 0.5f);
     int layer = (int)rintf(layerCoord);
     layer = max(0, min(layer, tex.layers - 1));
-    const float4* base = tex.texels + (size_t)layer * w * h;
-    const float4 t00 = base[(size_t)j0 * w + i0], t10 = base[(size_t)j0 * w + i1];
-    const float4 t01 = base[(size_t)j1 * w + i0], t11 = base[(size_t)j1 * w + i1];
+    const size_t base = (size_t)layer * w * h;
+    const float4 t00 = fetchTexel(tex, base + (size_t)j0 * w + i0), t10 = fetchTexel(tex, base + (size_t)j0 * w + i1);
+    const float4 t01 = fetchTexel(tex, base + (size_t)j1 * w + i0), t11 = fetchTexel(tex, base + (size_t)j1 * w + i1);
     const float w00 = (1 - a) * (1 - b), w10 = a * (1 - b), w01 = (1 - a) * b, w11 = a * b;
     return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
         w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z, w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);

@@ -78,7 +78,7 @@ struct pt_ctx {
     DevBuf<Material> materials;
     DevBuf<Instance> instances;
     DevBuf<Light> lights;
-    DevBuf<float4> texMaterial, texSky;
+    DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
     std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
     std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
@@ -879,11 +879,12 @@ void pt_destroy(pt_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
-    DevBuf<float4>* f4[] = { &c->texMaterial, &c->texSky, &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
+    DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
         &c->rays[1].d, &c->rays[1].thr, &c->stagedRays.o, &c->stagedRays.d, &c->stagedRays.thr, &c->shadow.o, &c->shadow.d, &c->shadow.c,
         &c->stagedShadow.o, &c->stagedShadow.d, &c->stagedShadow.c };
     for (auto* b : f4)
         b->release();
+    c->texMaterial.release(), c->texSky.release();
     c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
     c->wide.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
@@ -1373,23 +1374,24 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     });
 }
 
-int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height, uint32_t layers, const float* rgba)
+int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height, uint32_t layers, int format, const void* data)
 {
     return guarded(c, "pt_upload_texture_array", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
-    if ((kind != 0 && kind != 1) || !rgba || width == 0 || height == 0 || layers == 0)
+    if ((kind != 0 && kind != 1) || !data || width == 0 || height == 0 || layers == 0 || (format != PT_TEX_RGBA32F && format != PT_TEX_BGRA8_UNORM))
         return fail(c, PT_ERR_INVALID, "pt_upload_texture_array: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    DevBuf<float4>& buf = kind == 0 ? c->texMaterial : c->texSky;
-    const size_t n = (size_t)width * height * layers;
-    HIPCHK(c, buf.alloc(n));
-    HIPCHK(c, hipMemcpy(buf.p, rgba, n * sizeof(float4), hipMemcpyHostToDevice));
+    DevBuf<uint8_t>& buf = kind == 0 ? c->texMaterial : c->texSky;
+    const size_t bytes = (size_t)width * height * layers * (format == PT_TEX_RGBA32F ? sizeof(float4) : 4u);
+    HIPCHK(c, buf.alloc(bytes));
+    HIPCHK(c, hipMemcpy(buf.p, data, bytes, hipMemcpyHostToDevice));
     Texture& t = kind == 0 ? c->scene.materialTex : c->scene.sky;
     t.width = (int)width;
     t.height = (int)height;
     t.layers = (int)layers;
+    t.format = format;
     refreshSceneView(c);
     return PT_OK;
     });

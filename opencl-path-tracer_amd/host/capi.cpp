@@ -179,6 +179,14 @@ int pth_image_load_material_png(const char* path, uint32_t width, uint32_t heigh
     });
 }
 
+int pth_image_load_material_png_bgra8(const char* path, uint32_t width, uint32_t height, int isLinear, uint8_t* bgra_out)
+{
+    return guarded([&] {
+        const ImageRGBA8 img = loadMaterialLayerBGRA8(path, width, height, isLinear != 0);
+        std::memcpy(bgra_out, img.rgba.data(), img.rgba.size());
+    });
+}
+
 void pth_mesh_destroy(pth_mesh* m) { delete (MeshHandle*)m; }
 
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out)

@@ -349,6 +349,22 @@ ImageRGBA8 loadPNG(const std::string& path)
     return img;
 }
 
+// the same layer as the 32-bit bitmap the reference uploads into its CL_BGRA / CL_UNORM_INT8 array (texture.cpp:112-131):
+// bytes b, g, r, a per texel, rows bottom-up
+ImageRGBA8 loadMaterialLayerBGRA8(const std::string& path, uint32_t width, uint32_t height, bool isLinear)
+{
+    const ImageRGBAF f = loadMaterialLayer(path, width, height, isLinear);
+    ImageRGBA8 out;
+    out.width = f.width, out.height = f.height;
+    out.rgba.resize(f.rgba.size());
+    for (size_t t = 0; t < f.rgba.size() / 4; t++) {
+        const uint8_t r = (uint8_t)std::lround(f.rgba[4 * t] * 255.0f), g = (uint8_t)std::lround(f.rgba[4 * t + 1] * 255.0f),
+                      b = (uint8_t)std::lround(f.rgba[4 * t + 2] * 255.0f), a = (uint8_t)std::lround(f.rgba[4 * t + 3] * 255.0f);
+        out.rgba[4 * t] = b, out.rgba[4 * t + 1] = g, out.rgba[4 * t + 2] = r, out.rgba[4 * t + 3] = a;
+    }
+    return out;
+}
+
 ImageRGBAF loadMaterialLayer(const std::string& path, uint32_t width, uint32_t height, bool isLinear)
 {
     const ImageRGBA8 png = loadPNG(path);

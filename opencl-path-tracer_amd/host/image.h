@@ -38,6 +38,9 @@ ImageRGBA8 loadPNG(const std::string& path);
 // alpha kept (alpha-0 texels are cut-outs, shading.cl:587-601).  Returns what read_imagef yields for those bytes
 // (value / 255), rows bottom-up.
 ImageRGBAF loadMaterialLayer(const std::string& path, uint32_t width, uint32_t height, bool isLinear);
+// ... and as the bytes themselves: b, g, r, a per texel, rows bottom-up (the FreeImage 32-bit bitmap the reference uploads into
+// its CL_BGRA / CL_UNORM_INT8 image array; `rgba` holds them in that order)
+ImageRGBA8 loadMaterialLayerBGRA8(const std::string& path, uint32_t width, uint32_t height, bool isLinear);
 
 // UniqueTextureArray (src/opencl/texture.h:18-31, texture.cpp:9-24): the files a scene's materials refer to, each
 // once, in first-use order; the index is the material's tex_id = the layer of the texture array.

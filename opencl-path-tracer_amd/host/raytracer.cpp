@@ -38,10 +38,12 @@ void RayTracer::upload(const TextureArray& materialTextures, const TextureArray&
               m_flat.materials.data(), (uint32_t)m_flat.materials.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
         "pt_upload_static");
     if (materialTextures.layers)
-        check(pt_upload_texture_array(m_ctx, 0, materialTextures.width, materialTextures.height, materialTextures.layers, materialTextures.rgba.data()),
+        check(pt_upload_texture_array(m_ctx, 0, materialTextures.width, materialTextures.height, materialTextures.layers,
+                  materialTextures.storeAsFloat() ? PT_TEX_RGBA32F : PT_TEX_BGRA8_UNORM, materialTextures.data()),
             "pt_upload_texture_array(material)");
     if (skydomeTextures.layers)
-        check(pt_upload_texture_array(m_ctx, 1, skydomeTextures.width, skydomeTextures.height, skydomeTextures.layers, skydomeTextures.rgba.data()),
+        check(pt_upload_texture_array(m_ctx, 1, skydomeTextures.width, skydomeTextures.height, skydomeTextures.layers,
+                  skydomeTextures.storeAsFloat() ? PT_TEX_RGBA32F : PT_TEX_BGRA8_UNORM, skydomeTextures.data()),
             "pt_upload_texture_array(skydome)");
     // ... then the dynamic part (lights + top-level BVH), as the reference's constructor ends with frameTick()
     frameTick();

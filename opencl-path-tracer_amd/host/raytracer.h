@@ -18,13 +18,18 @@ namespace raytracer {
 // `layers` RGBA float images of one size, already linear and brightness-scaled
 struct TextureArray {
     uint32_t width = 0, height = 0, layers = 0;
-    std::vector<float> rgba;
+    std::vector<float> rgba; // storeAsFloat = true (skydome): r g b a floats
+    std::vector<uint8_t> bgra8; // storeAsFloat = false (material textures): b g r a bytes, as the reference uploads them
+    bool storeAsFloat() const { return bgra8.empty(); }
+    const void* data() const { return storeAsFloat() ? (const void*)rgba.data() : (const void*)bgra8.data(); }
     int add(const float* texels, uint32_t w, uint32_t h)
     {
         if (layers == 0)
             width = w, height = h;
         if (w != width || h != height)
             throw std::invalid_argument("TextureArray: all layers must have the same size");
+        if (!bgra8.empty())
+            throw std::invalid_argument("TextureArray: float and 8-bit layers cannot be mixed");
         rgba.insert(rgba.end(), texels, texels + (size_t)w * h * 4);
         return (int)layers++;
     }
@@ -51,8 +56,15 @@ struct TextureArray {
     // UniqueTextureArray::add(filePath, isLinear) for the 8-bit material array (PNG files: every texture the reference ships)
     int addMaterial(const std::string& pngFile, bool isLinear = false)
     {
-        const ImageRGBAF img = loadMaterialLayer(pngFile, width, height, isLinear); // 0 x 0: the first file fixes the layer size
-        return add(img.rgba.data(), img.width, img.height);
+        if (!rgba.empty())
+            throw std::invalid_argument("TextureArray: float and 8-bit layers cannot be mixed");
+        const ImageRGBA8 img = loadMaterialLayerBGRA8(pngFile, width, height, isLinear); // 0 x 0: the first file fixes the layer size
+        if (layers == 0)
+            width = img.width, height = img.height;
+        if (img.width != width || img.height != height)
+            throw std::invalid_argument("TextureArray: all layers must have the same size");
+        bgra8.insert(bgra8.end(), img.rgba.begin(), img.rgba.end());
+        return (int)layers++;
     }
 };
 

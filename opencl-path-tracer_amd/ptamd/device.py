@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEVICE_LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "..", "csrc", "libptamd.so")  # PTAMD_LIB: tuning builds
 
 RNG_COUNTER, RNG_LFSR113_PARITY = 0, 1
+TEX_RGBA32F, TEX_BGRA8_UNORM = 0, 1
 FLAG_ROWMAJOR_PIXELS = 1
 FLAG_NO_BAKED_INSTANCES = 2  # every instance stays two-level
 FLAG_TWO_LEVEL_ONLY = 4  # only single-leaf instances are copied to world space
@@ -86,7 +87,7 @@ def lib():
         l.pt_upload_static.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                        C.c_uint32, C.c_void_p, C.c_uint32]
         l.pt_upload_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
-        l.pt_upload_texture_array.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        l.pt_upload_texture_array.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         l.pt_set_camera.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_set_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         l.pt_set_accum_buffer.argtypes = [C.c_void_p, C.c_void_p]
@@ -165,9 +166,13 @@ class Context:
                                           len(flat.top_nodes), flat.top_root), "pt_upload_dynamic")
 
     def upload_texture(self, kind, arr):
-        arr = np.ascontiguousarray(arr, np.float32)
+        """[layers][h][w][4]: float32 r g b a (PT_TEX_RGBA32F) or uint8 b g r a (PT_TEX_BGRA8_UNORM, the reference's material
+        array format); rows bottom-up."""
+        arr = np.asarray(arr)
+        fmt = TEX_BGRA8_UNORM if arr.dtype == np.uint8 else TEX_RGBA32F
+        arr = np.ascontiguousarray(arr, np.uint8 if fmt == TEX_BGRA8_UNORM else np.float32)
         assert arr.ndim == 4 and arr.shape[3] == 4
-        self._chk(lib().pt_upload_texture_array(self._h, kind, arr.shape[2], arr.shape[1], arr.shape[0], _p(arr)),
+        self._chk(lib().pt_upload_texture_array(self._h, kind, arr.shape[2], arr.shape[1], arr.shape[0], fmt, _p(arr)),
                   "pt_upload_texture_array")
 
     def set_camera(self, camera):

@@ -75,6 +75,7 @@ def lib():
         _lib.pth_image_png_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib.pth_image_load_png_rgba8.argtypes = [C.c_char_p, C.c_void_p]
         _lib.pth_image_load_material_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        _lib.pth_image_load_material_png_bgra8.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -307,14 +308,20 @@ def load_png(path):
     return out
 
 
-def load_material_png(path, width=None, height=None, is_linear=False):
-    """PNG -> [1][height][width][4] float32 layer of the material texture array (reference
-    CLTextureArray::loadImage for the 8-bit array, src/opencl/texture.cpp:72-92,112-131): Lanczos-3 rescale,
-    FreeImage_AdjustGamma(1/2.2) unless is_linear, byte / 255, rows bottom-up."""
+def load_material_png(path, width=None, height=None, is_linear=False, as_bgra8=False):
+    """PNG -> [1][height][width][4] layer of the material texture array (reference CLTextureArray::loadImage for the
+    8-bit array, src/opencl/texture.cpp:72-92,112-131): Lanczos-3 rescale, FreeImage_AdjustGamma(1/2.2) unless is_linear,
+    rows bottom-up; float32 r g b a = byte / 255 (what read_imagef returns), or with as_bgra8 the uint8 b g r a bitmap
+    the reference uploads itself (device format PT_TEX_BGRA8_UNORM)."""
     w, h = C.c_uint32(0), C.c_uint32(0)
     if lib().pth_image_png_info(str(path).encode(), C.byref(w), C.byref(h)):
         _err("pth_image_png_info")
     width, height = width or w.value, height or h.value
+    if as_bgra8:
+        out8 = np.zeros((1, height, width, 4), np.uint8)
+        if lib().pth_image_load_material_png_bgra8(str(path).encode(), width, height, int(is_linear), _ptr(out8)):
+            _err("pth_image_load_material_png_bgra8")
+        return out8
     out = np.zeros((1, height, width, 4), np.float32)
     if lib().pth_image_load_material_png(str(path).encode(), width, height, int(is_linear), _ptr(out)):
         _err("pth_image_load_material_png")
@@ -342,10 +349,11 @@ class TextureFiles:
             out.append((lib().pth_texture_files_path(self._h, i, C.byref(lin), C.byref(br)).decode(), bool(lin.value), br.value))
         return out
 
-    def load(self, width=1024, height=1024):
-        """[layers][height][width][4] float32 for pt_upload_texture_array kind 0 (CLTextureArray ctor, 1024x1024 in the
-        reference, src/raytracer.cpp:284); one zero layer when there is no file (std::max(1, arrayLength), texture.cpp:141)."""
+    def load(self, width=1024, height=1024, as_bgra8=False):
+        """[layers][height][width][4] for pt_upload_texture_array kind 0 (CLTextureArray ctor, 1024x1024 in the reference,
+        src/raytracer.cpp:284): float32 r g b a, or with as_bgra8 the reference's own storage, uint8 b g r a; one zero layer
+        when there is no file (std::max(1, arrayLength), texture.cpp:141)."""
         fs = self.files()
         if not fs:
-            return np.zeros((1, height, width, 4), np.float32)
-        return np.concatenate([load_material_png(p, width, height, lin) for p, lin, _ in fs])
+            return np.zeros((1, height, width, 4), np.uint8 if as_bgra8 else np.float32)
+        return np.concatenate([load_material_png(p, width, height, lin, as_bgra8) for p, lin, _ in fs])

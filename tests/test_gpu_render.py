@@ -140,6 +140,18 @@ def test_obj_with_png_diffuse_map_renders_like_the_oracle(gpu, tmp_path):
     assert np.isclose(a, ref, rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1).mean() > 0.97
     assert U.rmse(U.tonemap(a, spp, b.camera), U.tonemap(ref, spp, b.camera)) < 5e-3
     ctx.close()
+    # the same layers in the reference's own storage, CL_BGRA / CL_UNORM_INT8 (src/opencl/texture.cpp:112-131,148): bytes on
+    # the device, byte / 255 at fetch time -- the same image up to the last bit of that division
+    b8 = scenes.SceneBundle(b.scene, b.camera, 96, 54, material_textures=tf.load(64, 64, as_bgra8=True), name="card8")
+    assert b8.material_textures.dtype == np.uint8
+    ctx = gpu.Context(96, 54, seed=4, samples_in_flight=1)
+    ctx.upload_scene(b8.flat, material_textures=b8.material_textures)
+    ctx.set_camera(b8.camera)
+    ctx.render(spp)
+    a8, st8 = ctx.read_accum()[:, :3], ctx.stats()
+    ctx.close()
+    assert st8["rays_extension"] == st["rays_extension"] and st8["rays_shadow"] == st["rays_shadow"]
+    assert np.allclose(a8, a, rtol=1e-4, atol=1e-5 * a.max())
 
 
 def test_determinism_batching_refill_and_tiles(gpu):

@@ -487,3 +487,21 @@ def test_the_stanford_bunny_ply_loads_and_builds(builder):
     else:
         assert s["num_triangle_refs"] < 1.6 * 69451, "spatial splits duplicate a bounded share of the references"
     assert s["max_leaf_size"] <= 8 and s["max_depth"] <= 60
+
+
+def test_material_layer_as_the_bgra8_bitmap_the_reference_uploads(tmp_path):
+    """The 8-bit storage of the material array (CL_BGRA / CL_UNORM_INT8, src/opencl/texture.cpp:112-131,148): the same layer as
+    bytes b g r a; byte / 255 with the channels swapped back is exactly the float layer (what read_imagef returns for it)."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (24, 40, 4), dtype=np.uint8)
+    img[5:9, :, 3] = 0
+    Image.fromarray(img).save(tmp_path / "t.png")
+    for w, h, lin in ((0, 0, False), (16, 32, True)):
+        f = H.load_material_png(tmp_path / "t.png", w or None, h or None, is_linear=lin)
+        b = H.load_material_png(tmp_path / "t.png", w or None, h or None, is_linear=lin, as_bgra8=True)
+        assert b.dtype == np.uint8 and b.shape == f.shape
+        assert np.array_equal(b[..., [2, 1, 0, 3]].astype(np.float32) / np.float32(255.0), f)
+    tf = H.TextureFiles()
+    tf.add(tmp_path / "t.png")
+    assert tf.load(8, 8, as_bgra8=True).shape == (1, 8, 8, 4) and H.TextureFiles().load(8, 8, as_bgra8=True).dtype == np.uint8
