@@ -187,6 +187,18 @@ int pt_upload_static(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, cons
     const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 int pt_upload_dynamic(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
     const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
+/* transferDynamicData + frameTick as the reference runs them (src/raytracer.cpp:183-189,497-595): the dynamic part of the scene
+ * is double-buffered on the device.  pt_upload_dynamic_async converts the next state on the host ("Lot of CPU work", :185) and
+ * copies it into the INACTIVE buffers on a copy stream of its own -- the GPU keeps rendering the active state meanwhile, nothing
+ * waits on the host; pt_frame_tick makes the render stream wait for that copy (the barrier of :593) and flips m_activeBuffer.
+ * pt_upload_dynamic is the two in a row. */
+int pt_upload_dynamic_async(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
+    const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
+int pt_frame_tick(pt_ctx* ctx);
+/* New vertices and refitted boxes for an unchanged topology (refitBVH, src/bvh/refit_bvh.cpp:6-34; MeshSequence::buildBvh,
+ * src/model/mesh_sequence.cpp:81-97): the caller's whole vertex and sub-BVH arrays after the refit.  Takes effect with the next
+ * pt_upload_dynamic(_async) + pt_frame_tick. */
+int pt_update_geometry(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 /* kind 0: material textures (CLTextureArray 1024x1024, CL_BGRA / CL_UNORM_INT8 in the reference, src/raytracer.cpp:284,
  * src/opencl/texture.cpp:112-131,148), kind 1: skydome (CL_RGBA / CL_FLOAT, src/raytracer.cpp:153-160, texture.cpp:96-110).
  * format: the two image formats the reference creates (texture.cpp:133-164) --

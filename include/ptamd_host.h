@@ -69,6 +69,9 @@ pth_mesh* pth_mesh_from_obj_textured(const char* path, const pt_material* overri
 void pth_mesh_destroy(pth_mesh* m);
 int pth_mesh_info(const pth_mesh* m, pth_mesh_stats* out);
 int pth_mesh_copy_bvh(const pth_mesh* m, pt_sub_bvh_node* nodes, pt_triangle* triangles, uint32_t* originalTriangle);
+/* A deformed frame of the same mesh (MeshSequence + refitBVH, reference src/model/mesh_sequence.cpp:81-97, src/bvh/refit_bvh.cpp):
+ * 3 * num_vertices new positions, normals likewise or NULL (regenerated smooth); topology and leaf order stay, boxes are refitted. */
+int pth_mesh_refit(pth_mesh* m, const float* positions, const float* normals);
 int pth_mesh_copy_geometry(const pth_mesh* m, pt_vertex* vertices, pt_material* materials, uint32_t* numMaterials); /* vertices: num_vertices entries */
 
 pth_scene* pth_scene_create(void);

@@ -72,19 +72,45 @@ struct pt_ctx {
     // scene (HBM)
     DevBuf<PairNode> nodes;
     DevBuf<WideNode> wide;
-    DevBuf<TriIsect> tris;
     DevBuf<TriShade> triShade;
     DevBuf<VertexShade> verts;
     DevBuf<Material> materials;
-    DevBuf<Instance> instances;
-    DevBuf<Light> lights;
+    // The dynamic part of the scene -- what pt_upload_dynamic(_async) produces: 4-wide nodes of both levels, intersection
+    // triangles (object space + world-space copies of instances), instances, lights -- exists TWICE, like the reference's
+    // double-buffered cl::Buffers (m_topBvhBuffers[2], m_emissiveTrianglesBuffers[2], ... src/raytracer.h:93-106): renders
+    // enqueued so far keep reading set `active` while the next state is converted on the host and copied into the other set on
+    // the copy stream; pt_frame_tick makes the render stream wait for that copy and flips (RayTracer::frameTick,
+    // src/raytracer.cpp:183-189; the barrier of :593).
+    struct DynamicSet {
+        DevBuf<WideNode> wide;
+        DevBuf<TriIsect> tris;
+        DevBuf<Instance> instances;
+        DevBuf<Light> lights;
+        // pinned staging the asynchronous copies read from (grow-only, like the device buffers)
+        void* stage = nullptr;
+        size_t stageBytes = 0;
+        uint32_t numLights = 0, rootRef = 0;
+        bool packetOk = false;
+        std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
+        hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
+        hipEvent_t lastUse = nullptr; // recorded on the render stream when the set stopped being the active one
+        bool used = false;
+    } dyn[2];
+    int active = 0; // set the render kernels read
+    int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
+    hipStream_t copyStream = nullptr;
+    bool vertsDirty = false; // pt_update_geometry changed the shading vertices: copied on the render stream at the next tick
+    std::vector<VertexShade> hostVerts;
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
     std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
     std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
     std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
     std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
-    std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
+    std::vector<TriShade> hostTriShade; // vertex indices + material of every triangle (kept for pt_update_geometry)
+    std::vector<pt_material> hostMaterials;
+    std::vector<pt_sub_bvh_node> hostSubNodes; // the caller's sub-BVH as uploaded (topology; boxes are replaced by pt_update_geometry)
+    uint32_t numVerts = 0;
     uint32_t numRefNodes = 0, numTris = 0;
     bool haveStatic = false, haveDynamic = false, haveCamera = false;
 
@@ -97,7 +123,6 @@ struct pt_ctx {
     uint32_t capacity = 0;
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
-    bool packetOk = false; // the scene is one world-space tree whose stack fits k_trace_packet
     uint32_t packetBlocks = 0;
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
     uint64_t packetLaunches = 0;
@@ -172,13 +197,16 @@ void refreshSceneView(pt_ctx* c)
 {
     SceneDev& s = c->scene;
     s.nodes = c->nodes.p;
-    s.wide = c->wide.p;
-    s.tris = c->tris.p;
+    const pt_ctx::DynamicSet& d = c->dyn[c->active];
+    s.wide = d.wide.p;
+    s.tris = d.tris.p;
     s.triShade = c->triShade.p;
     s.verts = c->verts.p;
     s.materials = c->materials.p;
-    s.instances = c->instances.p;
-    s.lights = c->lights.p;
+    s.instances = d.instances.p;
+    s.lights = d.lights.p;
+    s.numLights = d.numLights;
+    s.rootRef = d.rootRef;
     s.materialTex.texels = c->texMaterial.p;
     s.sky.texels = c->texSky.p;
     s.numTriangles = c->numTris;
@@ -625,7 +653,7 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false)
     a.inst = c->hitInst.p;
     a.ctl = ctl;
     a.pass = pass;
-    if (coherent && c->packetOk && (c->packetUse & 1u))
+    if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
         launchPacket(c, false, a);
     else
         launchTrace(c, false, a);
@@ -641,7 +669,7 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false)
     a.accum = accumView(c);
     a.ctl = ctl;
     a.pass = pass;
-    if (coherent && c->packetOk && (c->packetUse & 2u))
+    if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 2u))
         launchPacket(c, true, a);
     else
         launchTrace(c, true, a);
@@ -712,7 +740,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
         const bool coherent = b == 0 && fp.interleave >= 16u;
-        if (c->profile && coherent && c->packetOk && (c->packetUse & 1u))
+        if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
         launchIntersect(c, in, b, coherent);
         prof.end();
@@ -850,8 +878,14 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate");
     c->ownStream = true;
+    if ((e = hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate (copy stream)");
     if ((e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess)
         return bail(e, "hipEventCreate");
+    for (auto& d : c->dyn)
+        if ((e = hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming)) != hipSuccess
+            || (e = hipEventCreateWithFlags(&d.lastUse, hipEventDisableTiming)) != hipSuccess)
+            return bail(e, "hipEventCreate");
     if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream)) != hipSuccess)
         return bail(e, "alloc totals");
     if ((e = c->accumOwn.alloc((size_t)cfg->width * cfg->height)) != hipSuccess
@@ -885,8 +919,15 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->texMaterial.release(), c->texSky.release();
-    c->nodes.release(), c->tris.release(), c->triShade.release(), c->verts.release(), c->materials.release();
-    c->wide.release(), c->instances.release(), c->lights.release(), c->pixelList.release(), c->hitInst.release();
+    c->nodes.release(), c->triShade.release(), c->verts.release(), c->materials.release();
+    for (auto& d : c->dyn) {
+        d.wide.release(), d.tris.release(), d.instances.release(), d.lights.release();
+        if (d.stage) (void)hipHostFree(d.stage);
+        if (d.uploaded) (void)hipEventDestroy(d.uploaded);
+        if (d.lastUse) (void)hipEventDestroy(d.lastUse);
+    }
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
+    c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
@@ -915,10 +956,12 @@ int pt_set_stream(pt_ctx* c, void* hip_stream)
     return PT_OK;
 }
 
-int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
-    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
+// geometryOnly: pt_update_geometry -- same topology, new positions / normals / boxes: only host-side state and (at the next
+// tick) the shading vertices change; what is on the device stays valid for the renders in flight
+static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN, bool geometryOnly)
 {
-    return guarded(c, "pt_upload_static", [&]() -> int {
+    {
     if (!c)
         return PT_ERR_INVALID;
     if (!verts || !tris || !mats || !nodes || nV == 0 || nT == 0 || nM == 0 || nN == 0)
@@ -1053,32 +1096,80 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
 
     int rc;
     c->hostTris = hTris;
+    c->hostBottomNodes = std::move(hNodes);
+    if (geometryOnly) {
+        c->hostVerts = std::move(hVerts);
+        c->vertsDirty = true; // copied in stream order at the next pt_frame_tick, together with the flip to the refitted trees
+        for (uint32_t i = 0; i < nN; i++) // only the boxes may differ
+            c->hostSubNodes[i] = nodes[i];
+        return PT_OK;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
     if ((rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
         || (rc = uploadVec(c, c->materials, hMats)))
         return rc;
-    c->hostBottomNodes = std::move(hNodes);
+    c->hostTriShade = std::move(hShade);
+    c->hostMaterials.assign(mats, mats + nM);
+    c->hostSubNodes.assign(nodes, nodes + nN);
+    c->hostVerts = std::move(hVerts);
+    c->vertsDirty = false;
+    c->numVerts = nV;
     c->numRefNodes = nN;
     c->numTris = nT;
     c->haveStatic = true;
     c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
+    c->pending = -1;
     refreshSceneView(c);
     return PT_OK;
+    }
+}
+
+int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
+{
+    return guarded(c, "pt_upload_static", [&]() -> int { return uploadStaticImpl(c, verts, nV, tris, nT, mats, nM, nodes, nN, false); });
+}
+
+// New vertex data and refitted boxes for an UNCHANGED topology (what refitBVH, src/bvh/refit_bvh.cpp:6-34, leaves of a deforming
+// mesh; the reference rewrites the dynamic tail of its vertex and sub-BVH buffers every tick, src/raytracer.cpp:510-568).  The
+// arrays are the caller's whole vertex and sub-BVH arrays again; triangles, materials and node links must be the ones uploaded.
+// Takes effect with the next pt_upload_dynamic(_async) + pt_frame_tick; renders in flight are not disturbed.
+int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_sub_bvh_node* nodes, uint32_t nN)
+{
+    return guarded(c, "pt_update_geometry", [&]() -> int {
+        if (!c)
+            return PT_ERR_INVALID;
+        if (!c->haveStatic)
+            return fail(c, PT_ERR_STATE, "pt_update_geometry: call pt_upload_static first");
+        if (!verts || !nodes || nV != c->numVerts || nN != c->numRefNodes)
+            return fail(c, PT_ERR_INVALID, "pt_update_geometry: the vertex and node counts must be the uploaded ones (%u, %u)", c->numVerts, c->numRefNodes);
+        for (uint32_t i = 0; i < nN; i++)
+            if (nodes[i].leftChildOrFirstTriangle != c->hostSubNodes[i].leftChildOrFirstTriangle || nodes[i].triangleCount != c->hostSubNodes[i].triangleCount)
+                return fail(c, PT_ERR_INVALID, "pt_update_geometry: node %u changed its links: a refit keeps the topology (use pt_upload_static for a rebuilt tree)", i);
+        std::vector<pt_triangle> tris(c->numTris);
+        for (uint32_t t = 0; t < c->numTris; t++)
+            tris[t] = { { c->hostTriShade[t].i0, c->hostTriShade[t].i1, c->hostTriShade[t].i2 }, c->hostTriShade[t].material };
+        return uploadStaticImpl(c, verts, nV, tris.data(), c->numTris, c->hostMaterials.data(), (uint32_t)c->hostMaterials.size(), nodes, nN, true);
     });
 }
 
-int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
-{
-    return guarded(c, "pt_upload_dynamic", [&]() -> int {
-    if (!c)
-        return PT_ERR_INVALID;
-    if (!c->haveStatic)
-        return fail(c, PT_ERR_STATE, "pt_upload_dynamic: call pt_upload_static first");
-    if (!topNodes || nTop == 0 || topRoot >= nTop)
-        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: bad top-level BVH");
-    if (nL > 0 && !lights)
-        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
-    HIPCHK(c, hipSetDevice(c->device));
+} // extern "C"
 
+namespace {
+
+// What the host-side conversion of one dynamic state produces (no device call in it): the arrays of a DynamicSet.
+struct DynamicHost {
+    std::vector<TriIsect> tris;
+    std::vector<WideNode> wide;
+    std::vector<Instance> instances;
+    std::vector<Light> lights;
+    std::vector<uint32_t> instanceTopNode;
+    uint32_t numLights = 0, rootRef = 0;
+    bool packetOk = false;
+};
+
+int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
+{
     // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
     std::vector<Instance> hInst;
     std::vector<uint32_t> topRef(nTop, kRefNone); // reference of top node i as a child
@@ -1088,7 +1179,7 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         uint32_t topNode, inst;
     };
     std::vector<BakeCandidate> bakeCandidates;
-    c->instanceTopNode.clear();
+    out.instanceTopNode.clear();
     uint32_t numTopInner = 0, maxBottomDepth = 0;
     const uint32_t bottomCount = (uint32_t)c->hostBottomNodes.size();
     for (uint32_t i = 0; i < nTop; i++) {
@@ -1109,7 +1200,7 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
             const uint32_t instIndex = (uint32_t)hInst.size();
             topRef[i] = makeRef(instIndex, kRefSpecial);
             hInst.push_back(in);
-            c->instanceTopNode.push_back(i);
+            out.instanceTopNode.push_back(i);
             // A mesh that is a single leaf (a ground quad, an area light) is not worth an instance entry + leave
             // per ray: its triangles are copied to world space and referenced from the top level as a plain
             // leaf.  (t,u,v) are the same in both spaces (the reference never renormalises the transformed
@@ -1309,8 +1400,6 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
         hLights[i].normal = make_float4(nrm.x, nrm.y, nrm.z, 0.f);
         hLights[i].colour = make_float4(e.material.u.emissive.emissiveColour[0], e.material.u.emissive.emissiveColour[1], e.material.u.emissive.emissiveColour[2], 0.f);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc;
     std::vector<TriIsect> allTris = c->hostTris;
     allTris.insert(allTris.end(), baked.begin(), baked.end());
     // one all-zero triangle (det == 0: never hit) for the unused child slots of the 4-wide nodes to refer to
@@ -1323,11 +1412,11 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
     if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
         return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
     // k_trace_packet walks one world-space tree: no instance left to enter, the root an inner node, 64 stack entries
-    c->packetOk = stackNeed <= kPacketStack && refCount(topRef[topRoot]) == 0u;
+    out.packetOk = stackNeed <= kPacketStack && refCount(topRef[topRoot]) == 0u;
     for (const WideNode& w : hWide)
         for (int k = 0; k < 4; k++)
             if (refCount(w.child[k]) == kRefSpecial)
-                c->packetOk = false;
+                out.packetOk = false;
     // ---- pack the 4-wide nodes: only the ones the collapse kept (about half of the pair-node indices), each node's
     // children next to each other, level by level from every root -- half the footprint in the 4 MB-per-XCD L2 and
     // sibling nodes share 128-byte lines
@@ -1364,14 +1453,131 @@ int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL
 #else
     packed = hWide;
 #endif
-    if ((rc = uploadVec(c, c->tris, allTris)) || (rc = uploadVec(c, c->wide, packed)) || (rc = uploadVec(c, c->instances, hInst)) || (rc = uploadVec(c, c->lights, hLights)))
+    out.tris = std::move(allTris);
+    out.wide = std::move(packed);
+    out.instances = std::move(hInst);
+    out.lights = std::move(hLights);
+    out.numLights = nL;
+    out.rootRef = packedRoot;
+    return PT_OK;
+}
+
+template <typename T>
+int growTo(pt_ctx* c, DevBuf<T>& buf, size_t count, bool* reallocated)
+{
+    if (buf.n >= std::max<size_t>(count, 1))
+        return PT_OK;
+    *reallocated = true;
+    HIPCHK(c, buf.alloc(std::max<size_t>(count + count / 8, 1))); // some headroom: the baked copies vary from state to state
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// Convert the next dynamic state on the host and start copying it into the INACTIVE set on the copy stream; returns without
+// waiting for the device.  Renders already enqueued (and any enqueued before the next pt_frame_tick) keep using the active set.
+int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
+{
+    return guarded(c, "pt_upload_dynamic_async", [&]() -> int {
+    if (!c)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic)
+        return fail(c, PT_ERR_STATE, "pt_upload_dynamic: call pt_upload_static first");
+    if (!topNodes || nTop == 0 || topRoot >= nTop)
+        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: bad top-level BVH");
+    if (nL > 0 && !lights)
+        return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
+    HIPCHK(c, hipSetDevice(c->device));
+    DynamicHost h;
+    int rc = convertDynamic(c, lights, nL, topNodes, nTop, topRoot, h); // "Lot of CPU work" (raytracer.cpp:185): the GPU keeps rendering
+    if (rc)
         return rc;
-    c->scene.numLights = nL;
-    c->scene.rootRef = packedRoot;
+    const int target = c->haveDynamic ? 1 - c->active : c->active; // nothing active yet: fill the active set itself
+    pt_ctx::DynamicSet& d = c->dyn[target];
+    // the copy may not start before the renders that still read this set are done (it was the active set until the last tick),
+    // nor before an earlier, never-adopted upload into it has finished (same stream: ordered)
+    if (d.used)
+        HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
+    bool reallocated = false;
+    const size_t need[4] = { h.wide.size() * sizeof(WideNode), h.tris.size() * sizeof(TriIsect), h.instances.size() * sizeof(Instance),
+        h.lights.size() * sizeof(Light) };
+    const size_t total = need[0] + need[1] + need[2] + need[3];
+    if (d.wide.n < h.wide.size() || d.tris.n < h.tris.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1) || d.lights.n < std::max<size_t>(h.lights.size(), 1)
+        || d.stageBytes < total) {
+        // growing frees device memory, which the runtime only does once nothing uses it: wait for both streams (rare: the first
+        // uploads, or a state with more world-space copies than any before)
+        HIPCHK(c, hipStreamSynchronize(c->copyStream));
+        if (d.used)
+            HIPCHK(c, hipEventSynchronize(d.lastUse));
+        if ((rc = growTo(c, d.wide, h.wide.size(), &reallocated)) || (rc = growTo(c, d.tris, h.tris.size(), &reallocated))
+            || (rc = growTo(c, d.instances, h.instances.size(), &reallocated)) || (rc = growTo(c, d.lights, h.lights.size(), &reallocated)))
+            return rc;
+        if (d.stageBytes < total) {
+            if (d.stage)
+                (void)hipHostFree(d.stage);
+            d.stage = nullptr;
+            d.stageBytes = total + total / 8;
+            HIPCHK(c, hipHostMalloc(&d.stage, d.stageBytes, hipHostMallocDefault));
+        }
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->copyStream)); // the staging memory of this set is about to be rewritten
+    }
+    unsigned char* st = (unsigned char*)d.stage;
+    const void* src[4] = { h.wide.data(), h.tris.data(), h.instances.data(), h.lights.data() };
+    void* dst[4] = { d.wide.p, d.tris.p, d.instances.p, d.lights.p };
+    for (int k = 0; k < 4; k++) {
+        if (need[k] == 0)
+            continue;
+        std::memcpy(st, src[k], need[k]);
+        HIPCHK(c, hipMemcpyAsync(dst[k], st, need[k], hipMemcpyHostToDevice, c->copyStream));
+        st += need[k];
+    }
+    HIPCHK(c, hipEventRecord(d.uploaded, c->copyStream));
+    d.numLights = h.numLights;
+    d.rootRef = h.rootRef;
+    d.packetOk = h.packetOk;
+    d.instanceTopNode = std::move(h.instanceTopNode);
+    c->pending = target;
+    return PT_OK;
+    });
+}
+
+// RayTracer::frameTick's flip (src/raytracer.cpp:183-189) with the barrier of transferDynamicData (:593): renders enqueued from
+// now on wait for the pending upload and read the new set; nothing waits on the host.
+int pt_frame_tick(pt_ctx* c)
+{
+    if (!c)
+        return PT_ERR_INVALID;
+    if (c->pending < 0)
+        return PT_OK; // nothing was uploaded since the last tick
+    HIPCHK(c, hipSetDevice(c->device));
+    pt_ctx::DynamicSet& next = c->dyn[c->pending];
+    HIPCHK(c, hipStreamWaitEvent(c->stream, next.uploaded, 0));
+    if (c->pending != c->active) {
+        pt_ctx::DynamicSet& old = c->dyn[c->active];
+        HIPCHK(c, hipEventRecord(old.lastUse, c->stream)); // everything enqueued so far may still read the old set
+        old.used = true;
+    }
+    next.used = true;
+    HIPCHK(c, hipEventRecord(next.lastUse, c->stream));
+    if (c->vertsDirty) { // refitted geometry (pt_update_geometry): shading normals / texture coordinates, in stream order
+        HIPCHK(c, hipMemcpyAsync(c->verts.p, c->hostVerts.data(), c->hostVerts.size() * sizeof(VertexShade), hipMemcpyHostToDevice, c->stream));
+        c->vertsDirty = false;
+    }
+    c->active = c->pending;
+    c->pending = -1;
     c->haveDynamic = true;
     refreshSceneView(c);
     return PT_OK;
-    });
+}
+
+// the synchronous-looking form: the next pt_render sees the new state (still no host-side wait for the device)
+int pt_upload_dynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
+{
+    const int rc = pt_upload_dynamic_async(c, lights, nL, topNodes, nTop, topRoot);
+    return rc ? rc : pt_frame_tick(c);
 }
 
 int pt_upload_texture_array(pt_ctx* c, int kind, uint32_t width, uint32_t height, uint32_t layers, int format, const void* data)
@@ -1745,7 +1951,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u }, a.occluded = dOcc.p;
         a.ctl = dCtl.p, a.pass = 0;
         chk(hipEventRecord(e0, c->stream));
-        if (c->packetOk && (c->packetUse & 4u))
+        if (c->dyn[c->active].packetOk && (c->packetUse & 4u))
             launchPacket(c, any_hit != 0, a);
         else
             launchTrace(c, any_hit != 0, a);
@@ -1772,7 +1978,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
                 int32_t prim;
                 std::memcpy(&prim, &h[i].w, 4);
                 hits->prim[i] = prim;
-                hits->inst[i] = (in[i] >= 0 && (size_t)in[i] < c->instanceTopNode.size()) ? (int32_t)c->instanceTopNode[in[i]] : -1;
+                hits->inst[i] = (in[i] >= 0 && (size_t)in[i] < c->dyn[c->active].instanceTopNode.size()) ? (int32_t)c->dyn[c->active].instanceTopNode[in[i]] : -1;
             }
         }
     }
@@ -1835,10 +2041,11 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
     const uint32_t n = io->n;
     // instance index from the reported top-level leaf
     std::vector<int32_t> topToInst;
-    for (size_t k = 0; k < c->instanceTopNode.size(); k++) {
-        if (c->instanceTopNode[k] >= topToInst.size())
-            topToInst.resize(c->instanceTopNode[k] + 1, -1);
-        topToInst[c->instanceTopNode[k]] = (int32_t)k;
+    const std::vector<uint32_t>& instanceTopNode = c->dyn[c->active].instanceTopNode;
+    for (size_t k = 0; k < instanceTopNode.size(); k++) {
+        if (instanceTopNode[k] >= topToInst.size())
+            topToInst.resize(instanceTopNode[k] + 1, -1);
+        topToInst[instanceTopNode[k]] = (int32_t)k;
     }
     std::vector<float4> hO(n), hD(n), hT(n), hH(n);
     std::vector<int32_t> hI(n);

@@ -179,6 +179,15 @@ int pth_image_load_material_png(const char* path, uint32_t width, uint32_t heigh
     });
 }
 
+int pth_mesh_refit(pth_mesh* m, const float* positions, const float* normals)
+{
+    return guarded([&] {
+        if (!m || !positions)
+            throw std::invalid_argument("pth_mesh_refit: null argument");
+        ((MeshHandle*)m)->mesh->refit(positions, normals);
+    });
+}
+
 int pth_image_load_material_png_bgra8(const char* path, uint32_t width, uint32_t height, int isLinear, uint8_t* bgra_out)
 {
     return guarded([&] {

@@ -43,20 +43,8 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
             throw std::invalid_argument("Mesh: material index out of range");
         m_inputTriangles[t].materialIndex = mi;
     }
-    if (!normals) { // area-weighted smooth normals (cross product length = 2*area)
-        std::vector<vec3> acc(numVertices);
-        for (const auto& tri : m_inputTriangles) {
-            auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
-            vec3 n = cross(P(1) - P(0), P(2) - P(0));
-            for (int k = 0; k < 3; k++)
-                acc[tri.indices[k]] += n;
-        }
-        for (size_t i = 0; i < numVertices; i++) {
-            float len = length(acc[i]);
-            vec3 n = len > 0.0f ? acc[i] / len : vec3(0, 1, 0);
-            m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
-        }
-    }
+    if (!normals)
+        generateSmoothNormals();
     if (bvhCacheFile.empty() || !loadBvh(bvhCacheFile)) {
         m_bvh = buildBVH(m_vertices.data(), m_vertices.size(), m_inputTriangles.data(), m_inputTriangles.size(), builder);
         if (!bvhCacheFile.empty())
@@ -354,6 +342,45 @@ std::shared_ptr<Mesh> Mesh::fromOBJ(const std::string& path, const Material* ove
     }
     return std::make_shared<Mesh>(positions.data(), allNormals ? normals.data() : nullptr, uvs.data(), corners.size(), indices.data(),
         materialIndex.data(), indices.size() / 3, materials, builder, bvhCacheFile);
+}
+
+void Mesh::generateSmoothNormals()
+{
+    // area-weighted smooth normals (cross product length = 2*area)
+    const size_t numVertices = m_vertices.size();
+    std::vector<vec3> acc(numVertices);
+    for (const auto& tri : m_inputTriangles) {
+        auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
+        vec3 n = cross(P(1) - P(0), P(2) - P(0));
+        for (int k = 0; k < 3; k++)
+            acc[tri.indices[k]] += n;
+    }
+    for (size_t i = 0; i < numVertices; i++) {
+        float len = length(acc[i]);
+        vec3 n = len > 0.0f ? acc[i] / len : vec3(0, 1, 0);
+        m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
+    }
+}
+
+// A deformed frame of the same mesh (MeshSequence with m_refitting, reference src/model/mesh_sequence.cpp:81-97): new positions
+// (and normals) for the same vertices and triangles; the BVH keeps its topology and leaf order, its boxes are recomputed bottom-up
+// (refitBVH, src/bvh/refit_bvh.cpp:6-34).  Valid for any builder -- boxes of spatial-split references then cover the whole
+// triangle, looser than the clipped ones but conservative.
+void Mesh::refit(const float* positions, const float* normals)
+{
+    m_bounds = AABB();
+    for (size_t i = 0; i < m_vertices.size(); i++) {
+        for (int k = 0; k < 3; k++)
+            m_vertices[i].vertex[k] = positions[3 * i + k];
+        if (normals)
+            for (int k = 0; k < 3; k++)
+                m_vertices[i].normal[k] = normals[3 * i + k];
+        m_bounds.fit(vec3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]));
+    }
+    if (!normals)
+        generateSmoothNormals();
+    refitBVH(m_bvh.nodes, m_bvh.rootNode, m_bvh.triangles, m_vertices);
+    m_bvhFromCache = false;
 }
 
 std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& material, BvhBuilder builder)

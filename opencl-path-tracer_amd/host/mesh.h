@@ -74,11 +74,15 @@ public:
     bool loadBvh(const std::string& fileName);
     bool bvhFromCache() const { return m_bvhFromCache; }
 
+    // new positions (3 * numVertices floats) and normals (null: regenerated smooth) for the same topology: the BVH is refitted
+    void refit(const float* positions, const float* normals);
+
     const BvhBuildResult& getBvh() const { return m_bvh; }
     size_t numInputTriangles() const { return m_inputTriangles.size(); }
     BvhBuilder builder() const { return m_builder; }
 
 private:
+    void generateSmoothNormals();
     std::vector<VertexSceneData> m_vertices;
     std::vector<TriangleSceneData> m_inputTriangles;
     std::vector<Material> m_materials;

@@ -51,12 +51,25 @@ void RayTracer::upload(const TextureArray& materialTextures, const TextureArray&
 
 RayTracer::~RayTracer() { pt_destroy(m_ctx); }
 
+// transferDynamicData + the flip (reference src/raytracer.cpp:183-189,497-595): lights and top-level BVH from the scene graph as
+// it stands, converted and copied into the inactive device buffers on the copy stream while frames enqueued so far keep
+// rendering, then adopted by everything enqueued from here on.  No wait on the host.
 void RayTracer::frameTick()
 {
     flattenDynamic(*m_scene, m_flat);
-    check(pt_upload_dynamic(m_ctx, m_flat.emissiveTriangles.data(), (uint32_t)m_flat.emissiveTriangles.size(), m_flat.topBvhNodes.data(),
+    check(pt_upload_dynamic_async(m_ctx, m_flat.emissiveTriangles.data(), (uint32_t)m_flat.emissiveTriangles.size(), m_flat.topBvhNodes.data(),
               (uint32_t)m_flat.topBvhNodes.size(), m_flat.topBvhRoot),
-        "pt_upload_dynamic");
+        "pt_upload_dynamic_async");
+    check(pt_frame_tick(m_ctx), "pt_frame_tick");
+}
+
+// Deformed meshes (Mesh::refit: same topology, refitted boxes -- the reference rewrites the dynamic tail of its vertex and
+// sub-BVH buffers in transferDynamicData, :510-568): re-flatten the geometry and hand it over; the following frameTick adopts it.
+void RayTracer::updateGeometry()
+{
+    flattenStatic(*m_scene, m_flat);
+    check(pt_update_geometry(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
+        "pt_update_geometry");
 }
 
 void RayTracer::rayTrace(const Camera& camera)

@@ -77,7 +77,8 @@ public:
     RayTracer& operator=(const RayTracer&) = delete;
 
     void rayTrace(const Camera& camera); // one sample per pixel; resets the accumulation when the camera changed
-    void frameTick(); // re-flatten lights + top-level BVH after scene-graph transforms changed
+    void frameTick(); // re-flatten lights + top-level BVH after scene-graph transforms changed (asynchronous upload + flip)
+    void updateGeometry(); // after Mesh::refit: new vertices and refitted boxes; takes effect with the next frameTick
     int getSamplesPerPixel() const;
     int getMaxSamplesPerPixel() const { return 20000000; } // MAX_SAMPLES_PER_PIXEL, src/raytracer.cpp:38
 

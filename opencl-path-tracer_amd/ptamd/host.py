@@ -75,6 +75,7 @@ def lib():
         _lib.pth_image_png_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib.pth_image_load_png_rgba8.argtypes = [C.c_char_p, C.c_void_p]
         _lib.pth_image_load_material_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        _lib.pth_mesh_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.pth_image_load_material_png_bgra8.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     return _lib
 
@@ -134,6 +135,17 @@ class Mesh:
         if not h:
             _err("pth_mesh_from_obj")
         return Mesh(None, None, None, builder=builder, _handle=h)
+
+    def refit(self, positions, normals=None):
+        """A deformed frame of the same mesh: new positions (and normals; None = regenerated smooth) for the same vertices
+        and triangles.  The BVH keeps topology and leaf order, its boxes are refitted (reference refitBVH,
+        src/bvh/refit_bvh.cpp:6-34, as MeshSequence::buildBvh uses it, src/model/mesh_sequence.cpp:81-97)."""
+        pos = _f32(positions, (-1, 3))
+        if len(pos) != self.stats()["num_vertices"]:
+            raise RuntimeError("Mesh.refit: the vertex count must stay the same")
+        nrm = _f32(normals, (-1, 3))
+        if lib().pth_mesh_refit(self._h, _ptr(pos), _ptr(nrm)):
+            _err("pth_mesh_refit")
 
     def geometry(self):
         """(vertices, materials) in the reference's device layouts."""

@@ -505,3 +505,37 @@ def test_material_layer_as_the_bgra8_bitmap_the_reference_uploads(tmp_path):
     tf = H.TextureFiles()
     tf.add(tmp_path / "t.png")
     assert tf.load(8, 8, as_bgra8=True).shape == (1, 8, 8, 4) and H.TextureFiles().load(8, 8, as_bgra8=True).dtype == np.uint8
+
+
+@pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
+def test_refit_keeps_topology_and_restores_the_invariants(builder):
+    """refitBVH (reference src/bvh/refit_bvh.cpp:6-34) through Mesh.refit: a deformed frame of the same mesh keeps node links,
+    leaf ranges and triangle order; every box is recomputed bottom-up, so the BvhTester invariants hold again -- for spatial-split
+    trees too (their references then get whole-triangle boxes) -- and a refit back to the first frame restores the first boxes of
+    an object-split tree exactly."""
+    v, f = scenes.icosphere(3)
+    p0 = (v * 0.5).astype(np.float32)
+    m = H.Mesh(p0, f.astype(np.uint32), [L.material_diffuse((0.8, 0.8, 0.8))], builder=builder)
+    nodes0, tris0, orig0 = m.bvh()
+    verts0, _ = m.geometry()
+    # deform: twist about y and squash
+    ang = 1.5 * p0[:, 1]
+    p1 = np.stack([np.cos(ang) * p0[:, 0] - np.sin(ang) * p0[:, 2], 0.6 * p0[:, 1] + 0.1 * np.sin(4 * p0[:, 0]), np.sin(ang) * p0[:, 0] + np.cos(ang) * p0[:, 2]], 1)
+    m.refit(p1)
+    s = m.stats()
+    assert s["children_inside_parents"] and s["triangles_inside_leaves"] and s["all_triangles_referenced"]
+    nodes1, tris1, orig1 = m.bvh()
+    verts1, _ = m.geometry()
+    assert np.array_equal(nodes1["left"], nodes0["left"]) and np.array_equal(nodes1["count"], nodes0["count"])
+    assert np.array_equal(tris1, tris0) and np.array_equal(orig1, orig0)
+    assert np.allclose(verts1["vertex"][:, :3], p1) and not np.array_equal(nodes1["min"], nodes0["min"])
+    assert np.allclose(np.linalg.norm(verts1["normal"][:, :3], axis=1), 1.0, atol=1e-4) and not np.allclose(verts1["normal"], verts0["normal"])
+    # the root box is the box of the deformed vertices
+    assert np.allclose(nodes1["min"][0, :3], p1.min(axis=0)) and np.allclose(nodes1["max"][0, :3], p1.max(axis=0))
+    m.refit(p0, normals=verts0["normal"][:, :3])
+    nodes2, _, _ = m.bvh()
+    if builder != H.BVH_SPATIAL_SPLIT:
+        assert np.array_equal(nodes2["min"], nodes0["min"]) and np.array_equal(nodes2["max"], nodes0["max"])
+    assert np.array_equal(m.geometry()[0]["normal"], verts0["normal"])
+    with pytest.raises(RuntimeError):
+        m.refit(p0[:-1])
