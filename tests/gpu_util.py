@@ -38,9 +38,11 @@ def tri_vertex_ids(flat, prim):
     return np.sort(flat.triangles["indices"][prim], axis=1)
 
 
-def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0):
+def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0, t_outlier_frac=0.0):
     """hit/miss identical; t/u/v within tolerance; (prim, inst) identical except where two primitives are
     hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t.
+    `t_outlier_frac` > 0 (deformed meshes: twisted triangles become slivers, and t of a hit that grazes a sliver is ill-conditioned)
+    tolerates that fraction of rays beyond t_rtol, each within 1 %.
     `edge_flip_frac` > 0 (world-space copies of instances: triangle edges are rounded in another space than the
     reference's) tolerates that fraction of hit/miss disagreements, each of which must graze a triangle edge."""
     gh, wh = got["prim"] >= 0, want["prim"] >= 0
@@ -56,7 +58,9 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac
         flips = np.zeros_like(flips)
     assert flips.mean() <= 1e-4, f"hit/miss differs for {flips.sum()} rays"
     both = gh & wh
-    assert np.allclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=1e-6)
+    dt = np.abs(got["t"][both] - want["t"][both]) / np.maximum(np.abs(want["t"][both]), 1e-6)
+    bad = ~np.isclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=1e-6)
+    assert bad.mean() <= t_outlier_frac and (not bad.any() or dt[bad].max() < 1e-2), f"t differs for {bad.sum()} of {both.sum()} rays, worst {dt.max():.3e}"
     same_geom = np.all(tri_vertex_ids(flat, got["prim"][both]) == tri_vertex_ids(flat, want["prim"][both]), axis=1)
     same = same_geom & (got["inst"][both] == want["inst"][both])
     assert (~same).mean() <= max_tie_frac, f"{(~same).sum()} of {both.sum()} rays hit a different primitive"
