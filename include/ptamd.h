@@ -142,6 +142,8 @@ typedef struct {
 /* shade runs neeMisShading (assets/cl/shading.cl:35-349: NEE + BSDF sampling combined by the balance heuristic) instead of
  * neeIsShading (:356-623), the integrator the reference compiles in.  The reference reaches its MIS code only under
  * #define COMPARE_SHADING (kernel.cl:6); one uninitialised read in it is fixed here. */
+#define PT_FLAG_QUEUE_PRIMARY_RAYS 256u /* always write the primary rays to the queue (k_gen), also where the packet kernel could
+                                          regenerate them from the entry index (diagnostics; the image is the same) */
 #define PT_FLAG_INTEGRATOR_MIS 32u
 /* exactly the reference's COMPARE_SHADING build (kernel.cl:48-51,248-265; raytracer.cpp:464-495): neeMisShading for the pixels of
  * the left half of the image, neeIsShading for the right half, both halves showing the left half's view -- two estimators of one

@@ -98,8 +98,19 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         bool active = idx < count;
         float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 0, 1);
         if (active) {
-            ro = a.rayO[idx];
-            rd = a.rayD[idx];
+            if (!ANY_HIT && a.fused) { // wave-uniform
+                uint32_t px, pl;
+                primaryEntry(a.fp, a.pixelList, idx, &px, &pl);
+                V3 o, d;
+                primaryRay(a.fp, px, pl, &o, &d);
+                ro = make_float4(o.x, o.y, o.z, asF(px));
+                rd = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, pl)));
+                ((float4*)a.rayO)[idx] = ro; // queued for k_shade (the throughput of a primary ray is 1 and is not stored)
+                ((float4*)a.rayD)[idx] = rd;
+            } else {
+                ro = a.rayO[idx];
+                rd = a.rayD[idx];
+            }
         }
         float tClosest = ANY_HIT ? ro.w : INFINITY;
         if (!ANY_HIT && active && (asU(rd.w) & FLAG_FINISHED)) {

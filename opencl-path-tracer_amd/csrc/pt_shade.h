@@ -54,31 +54,89 @@ __device__ inline V3 readSkydome(const SceneDev& sc, V3 dir) // skydome.cl:12-26
 }
 
 // ---- camera (camera.cl:28-77) -----------------------------------------------------------------
+// Written as explicit scalar operations under `fp contract(off)`: three kernels generate primary rays (k_gen, and -- where the
+// primary rays are not queued -- the packet kernel), and what one of them traces must be bit for bit what another would
+// have: with the compiler free to contract a * b + c differently in each inlining context it was not (4 of 423 k rays of a
+// test render took another path).  FMAs are spelled out where wanted, and the two divisions and the square root are the
+// hardware's 1-ulp v_rcp_f32 / v_rsq_f32 by name (left to the compiler, `1 / x` came out as a bare v_rcp_f32 in k_gen and as a
+// range-scaled sequence in the packet kernel).
+__device__ inline float fmaE(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline void pinholeRay(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
 {
-    const V3 uStep = xyz(cam.u) / width;
-    const V3 vStep = xyz(cam.v) / height;
-    V3 sp = xyz(cam.screen) + uStep * (float)x + vStep * (float)y;
-    sp = sp + rng.u01() * uStep;
-    sp = sp + rng.u01() * vStep;
+#pragma clang fp contract(off)
+    const float rw = __builtin_amdgcn_rcpf(width), rh = __builtin_amdgcn_rcpf(height);
+    const float ux = cam.u.x * rw, uy = cam.u.y * rw, uz = cam.u.z * rw; // uStep = u / width
+    const float vx = cam.v.x * rh, vy = cam.v.y * rh, vz = cam.v.z * rh;
+    const float fx = (float)x, fy = (float)y;
+    float sx = fmaE(vx, fy, fmaE(ux, fx, cam.screen.x)), sy = fmaE(vy, fy, fmaE(uy, fx, cam.screen.y)), sz = fmaE(vz, fy, fmaE(uz, fx, cam.screen.z));
+    const float r1 = rng.u01();
+    sx = fmaE(r1, ux, sx), sy = fmaE(r1, uy, sy), sz = fmaE(r1, uz, sz);
+    const float r2 = rng.u01();
+    sx = fmaE(r2, vx, sx), sy = fmaE(r2, vy, sy), sz = fmaE(r2, vz, sz);
+    const float dx = sx - cam.eye.x, dy = sy - cam.eye.y, dz = sz - cam.eye.z;
+    const float inv = __builtin_amdgcn_rsqf(fmaE(dz, dz, fmaE(dy, dy, dx * dx)));
     *o = xyz(cam.eye);
-    *d = normalize(sp - xyz(cam.eye));
+    *d = mk(dx * inv, dy * inv, dz * inv);
 }
+// Parity mode: the reference's operations one by one, each correctly rounded and none contracted (what oracle/_ref and the
+// oracle execute: IEEE division and square root, (a + b) + c as written): the render follows the reference's kernels path by path
+// only until the first decision flips, and an ulp in a primary ray is enough to flip one within a few thousand paths.
+__device__ inline void pinholeRayPrecise(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
+{
+    const float ux = __fdiv_rn(cam.u.x, width), uy = __fdiv_rn(cam.u.y, width), uz = __fdiv_rn(cam.u.z, width);
+    const float vx = __fdiv_rn(cam.v.x, height), vy = __fdiv_rn(cam.v.y, height), vz = __fdiv_rn(cam.v.z, height);
+    const float fx = (float)x, fy = (float)y;
+    float sx = __fadd_rn(__fadd_rn(cam.screen.x, __fmul_rn(ux, fx)), __fmul_rn(vx, fy));
+    float sy = __fadd_rn(__fadd_rn(cam.screen.y, __fmul_rn(uy, fx)), __fmul_rn(vy, fy));
+    float sz = __fadd_rn(__fadd_rn(cam.screen.z, __fmul_rn(uz, fx)), __fmul_rn(vz, fy));
+    const float r1 = rng.u01();
+    sx = __fadd_rn(sx, __fmul_rn(r1, ux)), sy = __fadd_rn(sy, __fmul_rn(r1, uy)), sz = __fadd_rn(sz, __fmul_rn(r1, uz));
+    const float r2 = rng.u01();
+    sx = __fadd_rn(sx, __fmul_rn(r2, vx)), sy = __fadd_rn(sy, __fmul_rn(r2, vy)), sz = __fadd_rn(sz, __fmul_rn(r2, vz));
+    const float dx = __fsub_rn(sx, cam.eye.x), dy = __fsub_rn(sy, cam.eye.y), dz = __fsub_rn(sz, cam.eye.z);
+    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    *o = xyz(cam.eye);
+    *d = mk(__fdiv_rn(dx, len), __fdiv_rn(dy, len), __fdiv_rn(dz, len));
+}
+__device__ inline void cameraRayPrecise(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
+{
+    if (!cam.thinLens) {
+        pinholeRayPrecise(cam, x, y, width, height, rng, o, d);
+        return;
+    }
+    const float r1 = __fsub_rn(__fmul_rn(rng.u01(), 2.0f), 1.0f); // square aperture (camera.cl:62-66)
+    const float r2 = __fsub_rn(__fmul_rn(rng.u01(), 2.0f), 1.0f);
+    const float a = cam.apertureRadius;
+    const float ox = __fadd_rn(__fmul_rn(__fmul_rn(r1, cam.uN.x), a), __fmul_rn(__fmul_rn(r2, cam.vN.x), a));
+    const float oy = __fadd_rn(__fmul_rn(__fmul_rn(r1, cam.uN.y), a), __fmul_rn(__fmul_rn(r2, cam.vN.y), a));
+    const float oz = __fadd_rn(__fmul_rn(__fmul_rn(r1, cam.uN.z), a), __fmul_rn(__fmul_rn(r2, cam.vN.z), a));
+    V3 po, pd;
+    pinholeRayPrecise(cam, x, y, width, height, rng, &po, &pd);
+    const float f = cam.focalDistance;
+    const V3 focal = mk(__fadd_rn(po.x, __fmul_rn(f, pd.x)), __fadd_rn(po.y, __fmul_rn(f, pd.y)), __fadd_rn(po.z, __fmul_rn(f, pd.z)));
+    const V3 lens = mk(__fadd_rn(po.x, ox), __fadd_rn(po.y, oy), __fadd_rn(po.z, oz));
+    *o = lens;
+    *d = mk(__fsub_rn(focal.x, lens.x), __fsub_rn(focal.y, lens.y), __fsub_rn(focal.z, lens.z)); // not normalised (camera.cl:71-75)
+}
+
 __device__ inline void cameraRay(const CameraDev& cam, int x, int y, float width, float height, Rng& rng, V3* o, V3* d)
 {
+#pragma clang fp contract(off)
     if (!cam.thinLens) {
         pinholeRay(cam, x, y, width, height, rng, o, d);
         return;
     }
-    const float r1 = rng.u01() * 2.0f - 1.0f; // square aperture (camera.cl:62-66)
-    const float r2 = rng.u01() * 2.0f - 1.0f;
-    const V3 offset = r1 * xyz(cam.uN) * cam.apertureRadius + r2 * xyz(cam.vN) * cam.apertureRadius;
+    const float r1 = (rng.u01() * 2.0f - 1.0f) * cam.apertureRadius; // square aperture (camera.cl:62-66)
+    const float r2 = (rng.u01() * 2.0f - 1.0f) * cam.apertureRadius;
+    const float ox = fmaE(r2, cam.vN.x, r1 * cam.uN.x), oy = fmaE(r2, cam.vN.y, r1 * cam.uN.y), oz = fmaE(r2, cam.vN.z, r1 * cam.uN.z);
     V3 po, pd;
     pinholeRay(cam, x, y, width, height, rng, &po, &pd);
-    const V3 focal = po + cam.focalDistance * pd;
-    const V3 lens = po + offset;
+    // focal = po + focalDistance * pd, lens = po + offset, direction = focal - lens: not normalised, as the reference
+    // (camera.cl:71-75)
+    const V3 lens = mk(po.x + ox, po.y + oy, po.z + oz);
+    const V3 focal = mk(fmaE(cam.focalDistance, pd.x, po.x), fmaE(cam.focalDistance, pd.y, po.y), fmaE(cam.focalDistance, pd.z, po.z));
     *o = lens;
-    *d = focal - lens; // not normalised, as the reference (camera.cl:71-75)
+    *d = mk(focal.x - lens.x, focal.y - lens.y, focal.z - lens.z);
 }
 
 // ---- BSDF pieces (pbr_brdf.cl, refract.cl) -------------------------------------------------------
@@ -536,8 +594,51 @@ struct FrameParams {
     uint32_t integrator; // 0: neeIsShading; 1: neeMisShading; 2: COMPARE_SHADING -- MIS for the pixels of the left half of the
                          // image, IS for the right half, both halves showing the left half's view (kernel.cl:48-51,248-265)
     uint32_t weightedLights; // NEE picks its light by weightedRandomPointOnLight instead of randomPointOnLight
+    float invSpan; // 1 / (numOwned << interleaveShift): entry index -> sample group without an integer division (primaryEntry)
 };
 enum : uint32_t { INTEGRATOR_IS = 0, INTEGRATOR_MIS = 1, INTEGRATOR_COMPARE = 2 };
+
+// Entry i of the FIRST queue of a batch with several samples in flight: which (pixel, accumulator plane = sample of the batch) it
+// is.  Consecutive entries are `interleave` samples of one pixel, then the next owned pixel; after every owned pixel the next
+// group of samples (k_gen).  Used by the packet kernel, which generates the camera rays of its packet itself (and queues them for
+// k_shade) instead of reading what a k_gen launch would have written first.
+__device__ inline void primaryEntry(const FrameParams& fp, const uint32_t* __restrict__ pixelList, uint32_t i, uint32_t* pixel, uint32_t* plane)
+{
+    const uint32_t span = fp.numOwned << fp.interleaveShift;
+    uint32_t group = (uint32_t)((float)i * fp.invSpan); // float estimate, then exact correction
+    if (group * span > i)
+        group--;
+    if ((group + 1u) * span <= i)
+        group++;
+    const uint32_t r = i - group * span;
+    *plane = (group << fp.interleaveShift) + (r & ((1u << fp.interleaveShift) - 1u));
+    const uint32_t k = r >> fp.interleaveShift;
+    *pixel = pixelList ? pixelList[k] : k;
+}
+// the camera ray of (pixel, sample fp.sample + plane): origin, direction (un-normalised for a thin lens, camera.cl:71-75)
+__device__ inline void primaryRay(const FrameParams& fp, uint32_t pixel, uint32_t plane, V3* o, V3* d)
+{
+    // pixel -> (x, y) without an integer division: float estimate, then exact correction (pixel < 2^31)
+    uint32_t py = (uint32_t)((float)pixel * fp.invWidth);
+    if (py * fp.width > pixel)
+        py--;
+    if ((py + 1u) * fp.width <= pixel)
+        py++;
+    uint32_t px = pixel - py * fp.width;
+    if (fp.integrator == INTEGRATOR_COMPARE && px >= fp.width / 2u) // COMPARE_SHADING, kernel.cl:48-51
+        px -= fp.width / 2u;
+    Rng rng = rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
+    cameraRay(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, o, d);
+}
+
+// start of a batch whose primary rays are regenerated where they are needed instead of queued (k_gen's bookkeeping)
+__global__ void k_begin_batch(uint32_t* queueCount, uint32_t* generated, uint32_t n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *queueCount = n;
+        *generated += n;
+    }
+}
 
 // generatePrimaryRays, kernel.cl:24-84.  Thread i creates the ray of the i-th (pixel, sample) pair to
 // issue into queue slot slotBase + i.  With one sample in flight: pixel = pixelList[first + i] (or the index itself
@@ -579,7 +680,10 @@ __global__ void __launch_bounds__(256) k_gen(FrameParams fp, RayQueue q, const u
         px -= fp.width / 2u;
     Rng rng = fp.parity ? rngLfsrLoad(streams, i) : rngCounter(pixel, fp.sample + plane, fp.seed, 0u);
     V3 o, d;
-    cameraRay(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, &o, &d);
+    if (fp.parity)
+        cameraRayPrecise(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, &o, &d);
+    else
+        cameraRay(fp.cam, (int)px, (int)py, (float)fp.width, (float)fp.height, rng, &o, &d);
     if (fp.parity)
         rngLfsrStore(streams, i, rng);
     const uint32_t slot = slotBase + i;

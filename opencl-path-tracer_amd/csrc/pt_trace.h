@@ -29,7 +29,7 @@
 //    scenes never enter an instance: ptamd.hip copies instances to world space at upload while a byte budget
 //    lasts, which removed two parked steps per instance visit.)
 #pragma once
-#include "pt_math.h"
+#include "pt_shade.h"
 
 namespace ptd {
 
@@ -99,6 +99,10 @@ struct TraceArgs {
     //   shadowCursor[pass]; any-hit launches add their unoccluded rays (= accumulator updates) to ctl->depositsShadow
     Control* ctl;
     uint32_t pass;
+    // packet kernel, first pass of a batch: the camera rays are generated from the entry index instead of read from the queue
+    uint32_t fused;
+    const uint32_t* pixelList;
+    FrameParams fp;
     uint32_t* spill; // kSpillStack * totalThreads dwords
     uint32_t totalThreads;
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)

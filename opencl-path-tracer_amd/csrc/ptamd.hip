@@ -588,6 +588,7 @@ FrameParams frameParams(const pt_ctx* c, uint32_t sample)
     fp.invWidth = 1.0f / (float)c->cfg.width;
     fp.integrator = (c->cfg.flags & PT_FLAG_COMPARE_SHADING) ? INTEGRATOR_COMPARE : ((c->cfg.flags & PT_FLAG_INTEGRATOR_MIS) ? INTEGRATOR_MIS : INTEGRATOR_IS);
     fp.weightedLights = (c->cfg.flags & PT_FLAG_SOLID_ANGLE_LIGHTS) ? 1u : 0u;
+    fp.invSpan = 0.f;
     return fp;
 }
 
@@ -627,6 +628,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
+#ifndef PT_FUSED_PRIMARY
+#define PT_FUSED_PRIMARY 1 // primary rays regenerated by the packet kernel and the first k_shade instead of queued by k_gen
+#endif
 #ifndef PT_PACKET_USE
 #define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
 #endif
@@ -643,10 +647,15 @@ void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
 }
 
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
-void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false)
+void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
+    if (fused) {
+        a.fused = 1u;
+        a.fp = *fused;
+        a.pixelList = c->identityPixels ? nullptr : c->pixelList.p;
+    }
     a.rayO = c->rays[q].o.p;
     a.rayD = c->rays[q].d.p;
     a.hit = c->hitH.p;
@@ -731,10 +740,20 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     fp.interleave = 1;
     while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
         fp.interleave *= 2u, fp.interleaveShift++;
+    fp.invSpan = 1.0f / (float)((uint64_t)c->numOwned << fp.interleaveShift);
     const uint32_t bounces = maxBounces(c);
     const uint32_t entries = c->numOwned * batch;
+    // Where the packet kernel serves the primary rays it generates them itself, from the entry index, and queues them for
+    // k_shade: no k_gen launch (3.3 ms of a 121 ms batch, HBM-write-bound) and no read of 32 B per ray in a kernel that has
+    // bandwidth to spare for the two stores instead.  (k_shade regenerating the rays as well, so that they are never stored,
+    // was measured too: its 70 extra instructions per entry cost 2.3 ms per batch, more than the reads they replace.)
+    const bool packetsFirst = fp.interleave >= 16u && c->dyn[c->active].packetOk && (c->packetUse & 1u);
+    const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
     prof.begin(0);
-    launchGen(c, fp, 0, 0, entries, 0, 0);
+    if (fused)
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, &c->control.p->extCount[0], &c->control.p->generated, entries);
+    else
+        launchGen(c, fp, 0, 0, entries, 0, 0);
     prof.end();
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
@@ -742,7 +761,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         const bool coherent = b == 0 && fp.interleave >= 16u;
         if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
-        launchIntersect(c, in, b, coherent);
+        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr);
         prof.end();
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries);

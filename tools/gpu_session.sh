@@ -21,6 +21,8 @@ for step in "$@"; do
     vtest:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#vtest:}.so timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py tests/test_gpu_fullsize.py -m gpu -q -x > $out/vtest_${step#vtest:}.log 2>&1; rc=$?; tail -5 $out/vtest_${step#vtest:}.log ;;
     inflight512) timeout -k 10 400 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 --in-flight 512 --max-entries 1100000000 > $out/bench_if512.json 2> $out/bench_if512.err; rc=$?; head -c 300 $out/bench_if512.json; echo; tail -2 $out/bench_if512.err ;;
     quick2) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 > $out/bench_quick2.json 2> $out/bench_quick2.err; rc=$?; head -c 300 $out/bench_quick2.json; echo ;;
+    sorttest) timeout -k 10 400 python tools/sort_test.py > $out/sort_test.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/sort_test.txt | tail -12 ;;
+    py:*) timeout -k 10 400 python ${step#py:} > $out/py_$(basename ${step#py:} .py).txt 2>&1; rc=$?; grep -v amdgpu.ids $out/py_$(basename ${step#py:} .py).txt | tail -20 ;;
     stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
     try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
     *) echo "unknown step $step"; rc=0 ;;
