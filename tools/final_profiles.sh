@@ -5,11 +5,11 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
 rm -rf $out && mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 > $out/stats_bench.json 2> $out/stats.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-frame --steps 2 --warmup 1 > $out/stats_bench.json 2> $out/stats.log
 echo "stats done"
 for set in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_BRANCH" "GRBM_GUI_ACTIVE TA_BUSY_avr SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"; do
   name=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$name -- python3 bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > $out/pmc_$name.json 2> $out/pmc_$name.log
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$name -- python3 bench.py --no-cpu-baseline --no-roofline --no-frame --rounds 1 --steps 1 --warmup 1 > $out/pmc_$name.json 2> $out/pmc_$name.log
   python3 tools/pmc_sum.py $out/pmc_$name > $out/pmc_$name.txt
   echo "pmc $name done"
 done

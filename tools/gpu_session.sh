@@ -23,6 +23,7 @@ for step in "$@"; do
     quick2) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 > $out/bench_quick2.json 2> $out/bench_quick2.err; rc=$?; head -c 300 $out/bench_quick2.json; echo ;;
     sorttest) timeout -k 10 400 python tools/sort_test.py > $out/sort_test.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/sort_test.txt | tail -12 ;;
     py:*) timeout -k 10 400 python ${step#py:} > $out/py_$(basename ${step#py:} .py).txt 2>&1; rc=$?; grep -v amdgpu.ids $out/py_$(basename ${step#py:} .py).txt | tail -20 ;;
+    final) timeout -k 10 1100 tools/final_profiles.sh > $out/final.log 2>&1; rc=$?; tail -5 $out/final.log | cut -c1-600 ;;
     stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
     try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
     *) echo "unknown step $step"; rc=0 ;;

@@ -1,16 +1,21 @@
 """Turn the PMC passes of tools/final_profiles.sh into profiles/roundN/traffic.json (read by bench.py):
 
-    python tools/traffic_json.py gpurun_out/final profiles/round1/traffic.json
+    python tools/traffic_json.py gpurun_out/final profiles/round2/traffic.json [tag]
 
 Per kernel: HBM bytes per unit of work from FETCH_SIZE / WRITE_SIZE (own --pmc passes, unit KB), corrected as
 MI355X_MICROARCH.md prescribes for gfx950 -- FETCH_SIZE counts 16-B-per-lane coalesced reads at one half, which
-k_fold_planes (a pure stream of such reads, known size) confirms in the same runs -- and how busy the vector and
-scalar issue ports were (SQ_INSTS_VALU / SQ_INSTS_SALU x 4 cycles per wave64 instruction over SIMD-cycles)."""
+k_fold_planes (a pure stream of such reads, known size) confirms in the same runs -- and how busy the vector issue port was:
+SQ_INSTS_VALU x the mean issue cost of the kernel's inner-loop instruction mix (profiles/round2/isa_mix.json: 2 / 4 / 8 cycles per
+wave64 instruction by class, measured by tools/micro/valu_issue.hip) over SIMD-cycles (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)."""
 import json
 import re
 import sys
 
+import os
 src, dst = sys.argv[1], sys.argv[2]
+tag = sys.argv[3] if len(sys.argv) > 3 else "r2"
+rnd = os.path.basename(os.path.dirname(os.path.abspath(dst)))
+mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mix.json")))["kernels"]
 
 
 def table(name):
@@ -40,9 +45,13 @@ out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["
        "calibration": "FETCH_SIZE / WRITE_SIZE in KB, summed over the dispatches of one bench step; FETCH_SIZE counts 16 B/lane coalesced "
                       "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- 127 planes x 2073600 px x 16 B per launch -- reads back at x0.50 in "
                       "the same passes), everything else 1:1; WRITE_SIZE exact (k_gen: rays x 32 B).",
-       "kernels": {}, "issue_limit": {},
-       "source": [f"profiles/round1/{p}" for p in ("r1i_pmc_FETCH_SIZE.txt", "r1i_pmc_WRITE_SIZE.txt", "r1i_pmc_SQ_INSTS_VALU.txt",
-                                                   "r1i_pmc_GRBM_GUI_ACTIVE.txt", "r1i_bench.json")]}
+       "kernels": {}, "issue": {},
+       "issue_model": ("cycles a wave64 vector instruction occupies its SIMD's issue port, measured (tools/micro/valu_issue.hip, "
+                       f"profiles/{rnd}/r2c_valu_issue.md): full rate 2 (fma/mul/add, logic, shifts, moves), half rate 4 (min/max, compares, selects, "
+                       "conversions, VOP3 integer, packed f32), quarter rate 8 (rcp/rsq/sqrt/exp/log); valu_issue_frac = SQ_INSTS_VALU x the mean "
+                       f"cost of the kernel's inner-loop mix (profiles/{rnd}/isa_mix.json) / (1024 SIMDs x kernel cycles)"),
+       "source": [f"profiles/{rnd}/{tag}_{p}" for p in ("pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "pmc_SQ_INSTS_VALU.txt",
+                                                          "pmc_GRBM_GUI_ACTIVE.txt", "bench.json")]}
 for name, k in kern.items():
     if name not in fetch and name not in write:
         continue
@@ -59,11 +68,11 @@ for name, k in kern.items():
         cycles = act[name]["GRBM_GUI_ACTIVE"][0] / 8.0  # summed over the 8 XCDs
         simd_cycles = 1024.0 * cycles
         i = insts[name]
-        e = {"valu_issue_busy": round(i["SQ_INSTS_VALU"][0] * 4.0 / simd_cycles, 3), "salu_issue_busy": round(i["SQ_INSTS_SALU"][0] * 4.0 / simd_cycles, 3)}
+        cost = mix.get(name, {}).get("inner_loops", {}).get("avg_cycles", 4.0)
+        e = {"valu_issue_frac": round(i["SQ_INSTS_VALU"][0] * cost / simd_cycles, 3), "valu_cycles_per_instruction": cost,
+             "valu_instructions_per_unit": round(i["SQ_INSTS_VALU"][0] / STEPS / units, 2)}
         if "SQ_THREAD_CYCLES_VALU" in act[name] and "SQ_ACTIVE_INST_VALU" in act[name]:
-            e["valu_lane_utilisation"] = round(act[name]["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * act[name]["SQ_ACTIVE_INST_VALU"][0]), 3)
-        out["issue_limit"][name] = e
-out["issue_limit"]["note"] = ("a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles: busy = instructions x 4 / (1024 SIMDs x kernel cycles); "
-                              "the traversal kernels sit at the vector issue limit, not at HBM")
+            e["valu_active_lanes"] = round(act[name]["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * act[name]["SQ_ACTIVE_INST_VALU"][0]), 3)
+        out["issue"][name] = e
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
