@@ -403,16 +403,19 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
         kernels[name] = k
 
     primary = ps["rays_generated"] if packets else 0
+    fused = packets and ps["ms_gen"] < 0.05 * batches  # the packet kernel generated (and queued) the primary rays itself: no k_gen launch
     dep_shadow, dep_shade = ps["deposits_shadow"], ps["deposits"] - ps["deposits_shadow"]
     add("k_trace<true>", "any-hit traversal of the shadow rays + deposit of the unoccluded ones", ps["ms_shadow"], 4 * batches, ps["rays_shadow"],
         BYTES_PER_SHADOW_RAY, BYTES_PER_DEPOSIT * dep_shadow)
     add("k_trace<false>", "closest-hit traversal, one ray per lane (bounce rays%s)" % ("" if packets else " and primary rays"),
         ps["ms_intersect"] - ps["ms_packet"], (3 if packets else 4) * batches, ps["rays_extension"] - primary, BYTES_PER_EXT_RAY)
-    add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave", ps["ms_packet"], batches, primary,
-        BYTES_PER_EXT_RAY)
+    add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave"
+        + (" (generates the camera rays itself and queues them for k_shade: 32 B written per ray instead of 28 B read)" if fused else ""),
+        ps["ms_packet"], batches, primary, BYTES_PER_GEN_RAY + 20 if fused else BYTES_PER_EXT_RAY)
     add("k_shade<false>", "shade + NEE + continuation + compaction (+ deposits of emissive hits and sky misses)", ps["ms_shade"], 4 * batches,
         ps["shade_hits"], BYTES_PER_SHADED_HIT, BYTES_PER_DEPOSIT * dep_shade)
-    add("k_gen", "primary rays", ps["ms_gen"], batches, ps["rays_generated"], BYTES_PER_GEN_RAY)
+    if not fused:
+        add("k_gen", "primary rays", ps["ms_gen"], batches, ps["rays_generated"], BYTES_PER_GEN_RAY)
     dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dominant]
     achieved = dk["achieved"]

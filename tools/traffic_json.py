@@ -21,6 +21,7 @@ mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mi
 def table(name):
     out = {}
     for line in open(f"{src}/pmc_{name}.txt"):
+        line = line.replace("k_shade<false, false>", "k_shade<false>")  # the production instantiation (not the general integrator kernel)
         m = re.match(r"(?:void )?ptd::(\S+)\s+(\S+)\s+(\d+)\s+per-dispatch\s+(\d+)\s+\((\d+) dispatches\)", line)
         if m:
             out.setdefault(m.group(1), {})[m.group(2)] = (float(m.group(3)), int(m.group(5)))
@@ -31,20 +32,20 @@ bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
 kern = bench["roofline"]["kernels"]
 fetch, write = table("FETCH_SIZE"), table("WRITE_SIZE")
 insts, act = table("SQ_INSTS_VALU"), table("GRBM_GUI_ACTIVE")
-STEPS = 2  # the PMC passes run --warmup 1 --steps 1
+STEPS = 2  # the PMC passes run --rounds 1 --warmup 1 --steps 1: two batches
 # bytes per unit that FETCH_SIZE misses: the 16-B-per-lane reads of consecutive queue entries, counted at 1/2
 HALF_COUNTED = {
     "k_trace<true>": (16.0, "ray origin+length and direction+pixel, 2 x 16 B per ray at hand-out"),
     "k_trace<false>": (16.0, "ray origin and direction, 2 x 16 B per ray at hand-out"),
-    "k_trace_packet<false>": (16.0, "ray origin and direction, 2 x 16 B per ray"),
+    "k_trace_packet<false>": (0.0, "generates its rays itself: no queue reads; node and triangle data through the scalar cache and L2"),
     "k_shade<false>": (24.0, "ray origin, direction and hit record, 3 x 16 B per entry (a bounce ray's throughput adds 8 B)"),
     "k_gen": (0.0, "writes only"),
 }
 out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["height"], "level": bench["config"]["level"],
                   "samples_in_flight": bench["config"]["samples_in_flight"], "n_gpus": bench["n_gpus"]},
        "calibration": "FETCH_SIZE / WRITE_SIZE in KB, summed over the dispatches of one bench step; FETCH_SIZE counts 16 B/lane coalesced "
-                      "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- 127 planes x 2073600 px x 16 B per launch -- reads back at x0.50 in "
-                      "the same passes), everything else 1:1; WRITE_SIZE exact (k_gen: rays x 32 B).",
+                      "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- (samples in flight - 1) planes x owned pixels x 16 B per launch -- reads back "
+                      "at x0.50 in the same passes), everything else 1:1; WRITE_SIZE exact (primary rays x 32 B).",
        "kernels": {}, "issue": {},
        "issue_model": ("cycles a wave64 vector instruction occupies its SIMD's issue port, measured (tools/micro/valu_issue.hip, "
                        f"profiles/{rnd}/r2c_valu_issue.md): full rate 2 (fma/mul/add, logic, shifts, moves), half rate 4 (min/max, compares, selects, "
@@ -55,11 +56,11 @@ out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["
 for name, k in kern.items():
     if name not in fetch and name not in write:
         continue
-    units = k["units_per_launch"] * k["launches"]  # per step
+    units = k["units_per_launch"] * k["launches"] / bench["config"].get("batches_per_step", 1)  # per batch: a PMC pass runs --rounds 1
     rd = fetch.get(name, {}).get("FETCH_SIZE", (0, 0))[0] * 1024 / STEPS / units
     wr = write.get(name, {}).get("WRITE_SIZE", (0, 0))[0] * 1024 / STEPS / units
     add, why = HALF_COUNTED.get(name, (0.0, ""))
-    out["kernels"][name] = {"units_per_step": units, "raw_KB_per_step": {"FETCH_SIZE": round(fetch.get(name, {}).get("FETCH_SIZE", (0, 0))[0] / STEPS),
+    out["kernels"][name] = {"units_per_batch": int(units), "raw_KB_per_batch": {"FETCH_SIZE": round(fetch.get(name, {}).get("FETCH_SIZE", (0, 0))[0] / STEPS),
                                                                           "WRITE_SIZE": round(write.get(name, {}).get("WRITE_SIZE", (0, 0))[0] / STEPS)},
                             "correction": f"+{add:g} B per unit read ({why})" if add else why,
                             "bytes_per_unit": {"read": round(rd + add, 1), "write": round(wr, 1), "total": round(rd + add + wr, 1)},
