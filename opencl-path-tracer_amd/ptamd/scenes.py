@@ -149,9 +149,6 @@ class SceneBundle:
             self._flat = self.scene.flatten()
         return self._flat
 
-    def with_resolution(self, width, height, **cam_kw):
-        raise NotImplementedError
-
 
 WHITE, GREEN, RED = (0.73, 0.73, 0.73), (0.12, 0.45, 0.15), (0.65, 0.05, 0.05)
 
