@@ -720,6 +720,28 @@ struct ShadeArgs {
 #define PT_SHADE_MIN_WAVES 4
 #endif
 constexpr int kShadeBlock = PT_SHADE_BLOCK;
+#ifndef PT_SHADE_NT
+#define PT_SHADE_NT 0 // 1: queue entries are read / written with non-temporal accesses (streamed once: no reason to keep them in L2 next to the scene)
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ inline float4 ldQ(const float4* p)
+{
+#if PT_SHADE_NT
+    const f4v v = __builtin_nontemporal_load((const f4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ inline void stQ(float4* p, float4 v)
+{
+#if PT_SHADE_NT
+    const f4v w = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(w, (f4v*)p);
+#else
+    *p = v;
+#endif
+}
 
 // GENERAL = false: the integrator the reference compiles in (neeIsShading, uniform light choice) -- the production kernel;
 // GENERAL = true: integrator and light choice selected by a.fp at run time (MIS, COMPARE_SHADING, weighted lights).
@@ -740,17 +762,17 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     ShadeResult r;
     uint32_t pixel = 0, bounce = 0, plane = 0;
     if (i < count) {
-        const float4 ro = a.in.o[i];
-        const float4 rd = a.in.d[i];
+        const float4 ro = ldQ(&a.in.o[i]);
+        const float4 rd = ldQ(&a.in.d[i]);
         const uint32_t fb = asU(rd.w);
         pixel = asU(ro.w);
         bounce = (fb >> 8) & 0xFFu;
         plane = fb >> 16;
         if (!(fb & FLAG_FINISHED)) {
-            const float4 h = a.hits.h[i];
+            const float4 h = ldQ(&a.hits.h[i]);
             float4 thr = make_float4(1.f, 1.f, 1.f, 0.f);
             if (PARITY || bounce != 0u) // primary rays: 1, not stored (k_gen)
-                thr = a.in.thr[i];
+                thr = ldQ(&a.in.thr[i]);
             const V3 o = xyz(ro), d = xyz(rd), throughput = xyz(thr);
             const int prim = (int)asU(h.w);
             if (prim >= 0) {
@@ -844,15 +866,15 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     const unsigned long long below = (1ull << lane) - 1ull;
     if (emitRay) {
         const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);
-        a.out.o[idx] = make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel));
-        a.out.d[idx] = make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane)));
-        a.out.thr[idx] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, GENERAL ? r.pdf : 0.f);
+        stQ(&a.out.o[idx], make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel)));
+        stQ(&a.out.d[idx], make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane))));
+        stQ(&a.out.thr[idx], make_float4(r.throughput.x, r.throughput.y, r.throughput.z, GENERAL ? r.pdf : 0.f));
     }
     if (emitShadow) {
         const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);
-        a.shadow.o[idx] = make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength);
-        a.shadow.d[idx] = make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel));
-        a.shadow.c[idx] = make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(0u, 0u, plane)));
+        stQ(&a.shadow.o[idx], make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength));
+        stQ(&a.shadow.d[idx], make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel)));
+        stQ(&a.shadow.c[idx], make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(0u, 0u, plane))));
     }
 }
 

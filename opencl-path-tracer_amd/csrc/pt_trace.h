@@ -69,6 +69,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_LEAF_SINGLE
 #define PT_LEAF_SINGLE 0 // 1: a leaf step tests ONE triangle per lane; lanes with more stay in the leaf for the next vote
 #endif
+#ifndef PT_DEFER_LEAF
+#define PT_DEFER_LEAF 0 // 1: a lane that reaches a leaf while the wave votes for an inner step sets the leaf aside (one per lane) and
+#endif                  // goes on with its stack; leaf steps then serve the lanes' pending leaves together
+#ifndef PT_STAGE_RAYS
+#define PT_STAGE_RAYS 0 // 1: a wave's next 64 queue entries are copied into LDS asynchronously (global_load_lds_dwordx4) when it claims them,
+#endif                  // so a hand-out reads LDS instead of stalling on HBM; the world-space ray is re-read from the queue when an instance is left
+#ifndef PT_DEFER_FULL
+#define PT_DEFER_FULL 48 // with PT_DEFER_LEAF: a leaf step also runs once this many lanes have a leaf to test
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
@@ -131,7 +140,11 @@ template <bool ANY_HIT>
 __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
+#if PT_STAGE_RAYS
+    __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
+#else
     __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
+#endif
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
@@ -199,6 +212,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     int hprim = -1, hinst = -1, curInst = -1;
     uint32_t cur = kRefFinish;
     int sp = 0;
+#if PT_DEFER_LEAF
+    uint32_t pend = 0u; // leaf reference set aside (0 = none; a leaf reference has a non-zero count field)
+#endif
     // value of pop() given the prefetched LDS entry `top` (does not move sp)
     auto popTop = [&](uint32_t top) -> uint32_t {
         uint32_t v = sp > 0 ? top : kRefFinish;
@@ -247,6 +263,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
+#if PT_STAGE_RAYS
+        if (poolEnd) { // wave-uniform.  Lane l copies entry l (clamped: the tail of the last packet is never handed out)
+            const uint32_t e = base + min(lane, poolEnd - 1u);
+            // every lane has read its ray of the previous packet (the reads were waited for before the rays were used)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rayO + e), (__attribute__((address_space(3))) void*)&ldsRays[wave][0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rayD + e), (__attribute__((address_space(3))) void*)&ldsRays[wave][1][0], 16, 0, 0);
+        }
+#endif
     };
     requestPacket();
 
@@ -268,10 +292,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     // the packet is only claimed; the lanes that take a ray read it straight from the queue
                     // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
                     ro = rd = make_float4(0, 0, 0, 0);
+#if PT_STAGE_RAYS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the packet's copy into LDS has landed
+                    if (!active && rank < avail) {
+                        ro = ldsRays[wave][0][e];
+                        rd = ldsRays[wave][1][e];
+                    }
+#else
                     if (!active && rank < avail) {
                         ro = a.rayO[poolBase + (uint32_t)e];
                         rd = a.rayD[poolBase + (uint32_t)e];
                     }
+#endif
                     PT_TOC(16, tShfl);
                     PT_TIC(tAssign);
                     if (!active && rank < avail) {
@@ -298,8 +330,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             if (ro.x == 0.0f) ro.x = -FLT_MIN;
                             if (ro.y == 0.0f) ro.y = -FLT_MIN;
                             if (ro.z == 0.0f) ro.z = -FLT_MIN;
+#if !PT_STAGE_RAYS
                             ldsWorld[wave][0][lane] = ro.x, ldsWorld[wave][1][lane] = ro.y, ldsWorld[wave][2][lane] = ro.z;
                             ldsWorld[wave][3][lane] = rd.x, ldsWorld[wave][4][lane] = rd.y, ldsWorld[wave][5][lane] = rd.z;
+#endif
                             setRay(xyz(ro), xyz(rd));
                             tClosest = tMax;
                             hprim = -1;
@@ -309,6 +343,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             cur = sc.rootRef;
                             sp = 0;
                             active = true;
+#if PT_DEFER_LEAF
+                            pend = 0u;
+#endif
                         }
                     }
                     PT_TOC(17, tAssign);
@@ -330,7 +367,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
         // the ray-space registers stay loop-invariant in it.
         while (true) {
+#if PT_DEFER_LEAF
+            // a pending leaf belongs to the ray space the lane is in: it is tested (hot loop) before the lane changes space or retires
+            const bool wantSpecial = active && refCount(cur) == kRefSpecial && pend == 0u;
+#else
             const bool wantSpecial = active && refCount(cur) == kRefSpecial;
+#endif
             const unsigned long long m = __ballot(wantSpecial);
             if (m == 0ull)
                 break;
@@ -369,8 +411,21 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 } else {
                     if (what == kSpecialLeaveInstance) {
                         // -------- back to world space ---------------------------------------------------------
+#if PT_STAGE_RAYS
+                        {   // the world-space ray again, from the queue (instances are rarely entered: ptamd.hip copies them to world space)
+                            float4 wo = a.rayO[rayIdx], wd = a.rayD[rayIdx];
+                            if (wd.x == 0.0f) wd.x = FLT_MIN;
+                            if (wd.y == 0.0f) wd.y = FLT_MIN;
+                            if (wd.z == 0.0f) wd.z = FLT_MIN;
+                            if (wo.x == 0.0f) wo.x = -FLT_MIN;
+                            if (wo.y == 0.0f) wo.y = -FLT_MIN;
+                            if (wo.z == 0.0f) wo.z = -FLT_MIN;
+                            setRay(xyz(wo), xyz(wd));
+                        }
+#else
                         setRay(mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]),
                             mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]));
+#endif
                         curInst = -1;
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     } else {
@@ -412,8 +467,18 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const uint32_t stackTop = ldsStack[wave][min(max(sp - 1, 0), kLdsStack - 1)][lane];
             const uint32_t kindBits = refCount(cur);
             const bool wantInner = active && kindBits == 0u;
+#if PT_DEFER_LEAF
+            const bool curLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
+            const bool hasPend = pend != 0u;
+            const bool canDefer = curLeaf && !hasPend;
+            // lanes that cannot go on without a leaf step: a second leaf reached, or a special step (space change / end) with a leaf pending
+            const bool mustLeaf = active && hasPend && kindBits != 0u;
+            const bool wantLeaf = curLeaf || hasPend;
+            const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf)), nMust = __popcll(__ballot(mustLeaf));
+#else
             const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
             const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
+#endif
             PT_STAT(0, 1);
             PT_STAT(1, nInner + nLeaf);
             // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
@@ -448,12 +513,24 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             }
             const int nSpecial = __popcll(mSpecial);
 #else
+#if PT_DEFER_LEAF
+            const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial && !hasPend));
+#else
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
 #endif
+#endif
+#if PT_DEFER_LEAF
+            const int nWork = __popcll(__ballot(wantInner || wantLeaf));
+#else
             const int nWork = nInner + nLeaf;
+#endif
             if (nWork == 0 || nSpecial >= (ANY_HIT ? kParkedBreakAny : kParkedBreak) || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
+#if PT_DEFER_LEAF
+            if (nInner > 0 && (nInner * PT_VOTE_INNER >= nMust * PT_VOTE_LEAF) && !(nLeaf >= PT_DEFER_FULL)) {
+#else
             if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
+#endif
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
@@ -595,6 +672,13 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         cur = next, sp = max(sp - 1, 0);
 #undef PT_VISIBLE
                 }
+#if PT_DEFER_LEAF
+                else if (canDefer) { // out-voted at a leaf: set it aside, go on with the stack
+                    pend = cur;
+                    cur = popTop(stackTop);
+                    sp = max(sp - 1, 0);
+                }
+#endif
                 PT_TOC(11, tInner);
             } else {
                 PT_STAT(3, 1);
@@ -602,7 +686,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_TIC(tLeaf);
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
+#if PT_DEFER_LEAF
+                    const uint32_t leafRef = hasPend ? pend : cur;
+                    const uint32_t first = refIndex(leafRef), n = refCount(leafRef);
+#else
                     const uint32_t first = refIndex(cur), n = PT_LEAF_SINGLE ? 1u : kindBits;
+#endif
                     bool done = false;
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
@@ -647,6 +736,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             a.occluded[rayIdx] = 1u;
                         active = false;
                         cur = kRefFinish;
+#if PT_DEFER_LEAF
+                        pend = 0u;
+                    } else if (hasPend) {
+                        pend = 0u; // `cur` (an inner node, a second leaf or a special step) is next
+#endif
                     } else if (PT_LEAF_SINGLE && kindBits > 1u) {
                         cur += 1u - (1u << kRefIndexBits); // next triangle of the leaf, one fewer to go
                     } else {

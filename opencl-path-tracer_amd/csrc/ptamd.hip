@@ -540,12 +540,17 @@ int ensureSpill(pt_ctx* c)
         blocksPerCU = std::min(blocksPerCU, b);
     }
     blocksPerCU = std::max(1, blocksPerCU);
+    if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) // diagnostics: a smaller persistent grid leaves wave slots to kernels of other streams / processes
+        blocksPerCU = std::max(1, std::min(blocksPerCU, atoi(e)));
     c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
     {
         int b0 = 0, b1 = 0;
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, (const void*)k_trace_packet<false>, kPacketBlock, 0));
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (const void*)k_trace_packet<true>, kPacketBlock, 0));
-        c->packetBlocks = (uint32_t)(std::max(1, std::min(b0, b1)) * c->numCUs);
+        int pb = std::max(1, std::min(b0, b1));
+        if (const char* e = getenv("PTAMD_PACKET_BLOCKS_PER_CU"))
+            pb = std::max(1, std::min(pb, atoi(e)));
+        c->packetBlocks = (uint32_t)(pb * c->numCUs);
     }
     const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
     HIPCHK(c, c->spill.alloc(threads * kSpillStack));

@@ -53,7 +53,7 @@
 
 enum Kind {
     K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
-    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_COUNT
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_FMAMIX_LO, K_FMAMIX_HI, K_PKFMA16, K_PKMAX16, K_PKMIN16, K_PKADD16, K_PKMUL16, K_CVT16, K_CVT16_SDWA, K_CVTUB_SDWA, K_PKRTZ, K_PKMAXI16, K_PKMADU16, K_CVTPKFP8, K_MED3, K_PKMOV, K_DOT2, K_COUNT
 };
 static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
     "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
@@ -64,7 +64,9 @@ static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v
     "v_cmp_lt_f32 vcc + 4 x v_cndmask_b32_e32 vcc: one compare-exchange of (key, ref) (per instruction)",
     "v_cmp_lt_f32_e64 s[20:21] + 4 x v_cndmask_b32_e64 s[20:21] (per instruction)",
     "compare-exchange by full-rate ops: v_sub_f32, v_ashrrev_i32, 2 x (v_xor, v_and, v_xor, v_xor) (per instruction)", "v_ashrrev_i32", "v_xor_b32", "v_bfi_b32",
-    "compare-exchange of packed keys: v_min_u32 + v_max_u32 (per instruction)", "ds_write_b32 (own lane's slot)", "ds_read_b32 (own lane's slot)" };
+    "compare-exchange of packed keys: v_min_u32 + v_max_u32 (per instruction)", "ds_write_b32 (own lane's slot)", "ds_read_b32 (own lane's slot)",
+    "v_fma_mix_f32 (src0 = low f16 half)", "v_fma_mix_f32 (src0 = high f16 half)", "v_pk_fma_f16", "v_pk_max_f16", "v_pk_min_f16", "v_pk_add_f16", "v_pk_mul_f16", "v_cvt_f32_f16",
+    "v_cvt_f32_f16_sdwa src0_sel:WORD_1", "v_cvt_f32_u32_sdwa src0_sel:BYTE_1", "v_cvt_pkrtz_f16_f32", "v_pk_max_i16", "v_pk_mad_u16", "v_cvt_pk_f32_fp8", "v_med3_f32", "v_pk_mov_b32", "v_dot2_f32_f16" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
@@ -132,7 +134,30 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
         if (KIND == K_MINMAX_SWAP) asm volatile(CM("%0", "%1") CM("%2", "%3") CM("%4", "%5") CM("%6", "%7") CM("%0", "%2") CM("%1", "%3") CM("%4", "%6") CM("%5", "%7") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(s));
         if (KIND == K_DSW) asm volatile(REP32("ds_write_b32 %10, ", "") : OPS : "v"(s), "v"(t), "v"(ldsAddr) : "memory");
         if (KIND == K_DSR) { asm volatile(REP32("ds_read_b32 ", ", %10") "s_waitcnt lgkmcnt(0)\n\t" : OPS : "v"(s), "v"(t), "v"(ldsAddr) : "memory"); }
+        if (KIND == K_FMAMIX_LO) asm volatile(ACC32("v_fma_mix_f32 ", ", %8, %9, ") : OPS : "v"(s), "v"(t)); // default modifiers: all three sources f32
+        if (KIND == K_FMAMIX_HI) asm volatile(REP32("v_fma_mix_f32 ", ", %8, %9, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKFMA16) asm volatile(ACC32("v_pk_fma_f16 ", ", %8, %9, ") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKMAX16) asm volatile(REP32("v_pk_max_f16 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKMIN16) asm volatile(REP32("v_pk_min_f16 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKADD16) asm volatile(REP32("v_pk_add_f16 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKMUL16) asm volatile(REP32("v_pk_mul_f16 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT16) asm volatile(REP32("v_cvt_f32_f16 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVT16_SDWA) asm volatile(REP32("v_cvt_f32_f16_sdwa ", ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1") : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVTUB_SDWA) asm volatile(REP32("v_cvt_f32_u32_sdwa ", ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKRTZ) asm volatile(REP32("v_cvt_pkrtz_f16_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKMAXI16) asm volatile(REP32("v_pk_max_i16 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_PKMADU16) asm volatile(REP32("v_pk_mad_u16 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_MED3) asm volatile(REP32("v_med3_f32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_DOT2) asm volatile(ACC32("v_dot2_f32_f16 ", ", %8, %9, ") : OPS : "v"(s), "v"(t));
 #undef OPS
+        if (KIND == K_CVTPKFP8)
+            asm volatile(REP32("v_cvt_pk_f32_fp8 ", ", %8")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "v"(s));
+        if (KIND == K_PKMOV)
+            asm volatile(REP32("v_pk_mov_b32 ", ", %8, %8")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "v"(ps));
         if (KIND == K_PKFMA)
             asm volatile(ACC32("v_pk_fma_f32 ", ", %8, %8, ")
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
@@ -196,6 +221,7 @@ void runKind(unsigned long long* dOut, int iters, int numCUs, const int* wavesPe
 int main(int argc, char** argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 4096;
+    const int firstKind = argc > 2 ? atoi(argv[2]) : 0; // rows from this one on (K_FMAMIX_LO = the f16 / mixed-precision / SDWA rows added later)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int numCUs = prop.multiProcessorCount;
@@ -208,14 +234,16 @@ int main(int argc, char** argv)
     printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 | shader clock at W=8 (MHz) | class |\n|---|---|---|---|---|---|---|---|---|\n");
     double pw[5], ns[5], mhz[5];
 #define RUN(K)                                                                                                                        \
-    runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND || K == K_CMP64_CND64 ? 16 : (K == K_CMP_4CND || K == K_CMP64_4CND64 || K == K_XORSWAP ? 30 : (K == K_MINMAX_SWAP ? 24 : 32)));                                                      \
-    printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f | %.0f | %s |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
+    if (K >= firstKind) runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND || K == K_CMP64_CND64 ? 16 : (K == K_CMP_4CND || K == K_CMP64_4CND64 || K == K_XORSWAP ? 30 : (K == K_MINMAX_SWAP ? 24 : 32)));                                                      \
+    if (K >= firstKind) printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f | %.0f | %s |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
         pw[3] / 7, pw[4], pw[4] / 8, ns[4], mhz[4], pw[4] / 8 < 1.6 ? "full rate" : (pw[4] / 8 < 3.0 ? "half rate" : "quarter rate or slower"));
     RUN(K_FMA) RUN(K_MUL) RUN(K_ADD) RUN(K_MIN) RUN(K_MAX3) RUN(K_MIN3) RUN(K_CVT_UB0) RUN(K_CVT_UB1) RUN(K_CVT_UB2) RUN(K_CVT_UB3) RUN(K_CVT_U32)
     RUN(K_CNDMASK) RUN(K_CMP) RUN(K_CMP_SGPR) RUN(K_AND) RUN(K_LSHR) RUN(K_BFE) RUN(K_ADDU) RUN(K_MOV) RUN(K_PERM) RUN(K_PKFMA) RUN(K_PKMUL) RUN(K_RCP)
     RUN(K_LSHLOR) RUN(K_ANDOR) RUN(K_MADU24) RUN(K_CMPCND) RUN(K_CND64) RUN(K_OR) RUN(K_MAX) RUN(K_MINU) RUN(K_CMPU) RUN(K_LSHLADD) RUN(K_MAD64) RUN(K_SUB)
     RUN(K_CVTI) RUN(K_FMAC) RUN(K_CND_VCC_SET) RUN(K_CND64_VCC) RUN(K_CMP64_CND64) RUN(K_CMP_4CND) RUN(K_CMP64_4CND64) RUN(K_XORSWAP) RUN(K_ASHR) RUN(K_XOR) RUN(K_BFI)
     RUN(K_MINMAX_SWAP) RUN(K_DSW) RUN(K_DSR)
+    RUN(K_FMAMIX_LO) RUN(K_FMAMIX_HI) RUN(K_PKFMA16) RUN(K_PKMAX16) RUN(K_PKMIN16) RUN(K_PKADD16) RUN(K_PKMUL16) RUN(K_CVT16) RUN(K_CVT16_SDWA) RUN(K_CVTUB_SDWA)
+    RUN(K_PKRTZ) RUN(K_PKMAXI16) RUN(K_PKMADU16) RUN(K_CVTPKFP8) RUN(K_MED3) RUN(K_PKMOV) RUN(K_DOT2)
     CHECK(hipFree(dOut));
     return 0;
 }

@@ -1,7 +1,7 @@
 """Diagnostic: lane-level accounting of the k_trace loop (needs the -DPT_TRACE_STATS build)."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["PTAMD_LIB"] = os.path.join(ROOT, "opencl-path-tracer_amd", "csrc", "variants", "libptamd_stats.so")
+os.environ.setdefault("PTAMD_LIB", os.path.join(ROOT, "opencl-path-tracer_amd", "csrc", "variants", "libptamd_stats.so"))
 sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 import numpy as np
 from ptamd import scenes, device as D
