@@ -721,7 +721,7 @@ struct ShadeArgs {
 #endif
 constexpr int kShadeBlock = PT_SHADE_BLOCK;
 #ifndef PT_SHADE_NT
-#define PT_SHADE_NT 0 // 1: queue entries are read / written with non-temporal accesses (streamed once: no reason to keep them in L2 next to the scene)
+#define PT_SHADE_NT 1 // 1: queue entries are read / written with non-temporal accesses (streamed once: no reason to keep them in L2 next to the scene)
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ inline float4 ldQ(const float4* p)

@@ -9,14 +9,15 @@
 // of two hits at exactly the same t is reported.
 //
 // How it runs is CDNA4-specific (measurements behind every choice: DESIGN.md section 6):
-//  * persistent waves at 7 waves/SIMD (72 VGPRs, 5.5 KB LDS per wave): the grid is sized to the machine; a wave
+//  * persistent waves at 7 waves/SIMD (72 VGPRs, 5 KB LDS per wave): the grid is sized to the machine; a wave
 //    claims queue entries in spans of up to 512 with ONE atomicAdd (a device-scope word sustains only ~88
-//    atomics/us) and idle lanes read their ray straight from the queue, consecutive entries for consecutive
-//    idle lanes (ballot rank) -- no staging registers, so the kernel fits 80 VGPRs without spills;
+//    atomics/us) and copies the 64 entries it will hand out next into LDS ASYNCHRONOUSLY (two global_load_lds_dwordx4:
+//    no staging registers, the kernel stays at 72 VGPRs): a hand-out -- consecutive entries for consecutive idle lanes
+//    (ballot rank) -- reads LDS instead of stalling on HBM, so it can run as soon as 8 lanes are idle;
 //  * ONE traversal stack in LDS, laid out [entry][lane] (a wave's push/pop touches 64 consecutive dwords:
 //    conflict-free ds_read/ds_write_b32), 12 entries; top level and bottom level share it, separated by a
-//    sentinel entry that restores the world-space ray (parked in LDS, [component][lane]); deeper entries spill
-//    to a lane-interleaved region in global memory;
+//    sentinel entry that restores the world-space ray (re-read from the queue: instances are rarely entered, see
+//    below); deeper entries spill to a lane-interleaved region in global memory;
 //  * 4-wide nodes with 8-bit quantised child boxes (WideNode, 64 B = four 16-byte loads for four children) at
 //    both levels, so one code path -- and one slot in the vote below -- serves both; entry/exit plane bytes are
 //    picked per ray-direction sign as whole dwords, planes are one packed FMA per pair
@@ -36,8 +37,8 @@ namespace ptd {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #ifndef PT_REFILL_IDLE
-#define PT_REFILL_IDLE 16
-#endif
+#define PT_REFILL_IDLE 8 // hand out new rays once this many lanes are idle; with (PT_PARKED_BREAK, _ANY) = (32, 48): 4 / 8 / 12 / 16 -> 8 810 / 8 865 /
+#endif                   // 8 867 / 8 803 Mrays/s; (16, 24, 40) with the rays read from the queue at the hand-out, round 1's setting: 8 727
 #ifndef PT_TRACE_MIN_WAVES
 #define PT_TRACE_MIN_WAVES 7
 #endif
@@ -45,38 +46,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_GUIDED_SPANS 1 // > 0: a claim takes at most (entries left) / (waves x this); 0 / 1 / 2 / 4: 8.47 / 8.52 / 8.50 / 8.43 Grays/s
 #endif
 #ifndef PT_PARKED_BREAK
-#define PT_PARKED_BREAK 24
-#endif
+#define PT_PARKED_BREAK 32 // (this, PT_PARKED_BREAK_ANY) at 8 idle lanes: (16, 24) / (24, 40) / (32, 48) / (40, 56) / (48, 60) -> 8 702 / 8 823 / 8 883 /
+#endif                     // 8 860 / 8 733 Mrays/s: every pass over the parked lanes costs the whole wave
 #ifndef PT_ANYHIT_SORT
 #define PT_ANYHIT_SORT 0
 #endif
 #ifndef PT_VOTE_INNER
 #define PT_VOTE_INNER 2 // an inner step runs when 2 * (lanes wanting one) >= 3 * (lanes wanting a leaf): leaf steps are the
 #define PT_VOTE_LEAF 3 // long ones (sequential triangle fetches), so they are not left waiting for a majority
-#endif
-#ifndef PT_INTKEYS
-#define PT_INTKEYS 0 // 1: integer child keys, visibility and push counts by sign-bit arithmetic (no lane masks)
-#endif
-#ifndef PT_CLOSEST_PARTIAL_SORT
-#define PT_CLOSEST_PARTIAL_SORT 0 // 1: closest-hit rays also only bring the nearest visible child to the front
-#endif
-#ifndef PT_INLINE_FINISH
-#define PT_INLINE_FINISH 0 // 1: a ray that has nothing left to traverse retires inside the hot loop (hit record stored at once / its
-#endif                     // index queued in LDS for a batched deposit) instead of parking its lane until the loop breaks
-#ifndef PT_DEPOSIT_BATCH
-#define PT_DEPOSIT_BATCH 40 // any-hit: queued unoccluded rays that trigger a deposit pass
-#endif
-#ifndef PT_LEAF_SINGLE
-#define PT_LEAF_SINGLE 0 // 1: a leaf step tests ONE triangle per lane; lanes with more stay in the leaf for the next vote
-#endif
-#ifndef PT_DEFER_LEAF
-#define PT_DEFER_LEAF 0 // 1: a lane that reaches a leaf while the wave votes for an inner step sets the leaf aside (one per lane) and
-#endif                  // goes on with its stack; leaf steps then serve the lanes' pending leaves together
-#ifndef PT_STAGE_RAYS
-#define PT_STAGE_RAYS 0 // 1: a wave's next 64 queue entries are copied into LDS asynchronously (global_load_lds_dwordx4) when it claims them,
-#endif                  // so a hand-out reads LDS instead of stalling on HBM; the world-space ray is re-read from the queue when an instance is left
-#ifndef PT_DEFER_FULL
-#define PT_DEFER_FULL 48 // with PT_DEFER_LEAF: a leaf step also runs once this many lanes have a leaf to test
 #endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
@@ -85,7 +62,7 @@ constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 constexpr int kSpillStack = 100; // further entries in global memory
 constexpr int kTraceBlock = 256;
 #ifndef PT_PARKED_BREAK_ANY
-#define PT_PARKED_BREAK_ANY 40
+#define PT_PARKED_BREAK_ANY 48
 #endif
 constexpr int kParkedBreakAny = PT_PARKED_BREAK_ANY; // same, any-hit traversal (only unoccluded rays park: they have a deposit to make)
 constexpr int kParkedBreak = PT_PARKED_BREAK; // leave the hot loop once this many lanes are parked on a special step or idle
@@ -140,21 +117,10 @@ template <bool ANY_HIT>
 __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
-#if PT_STAGE_RAYS
     __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
-#else
-    __shared__ float ldsWorld[kTraceBlock / 64][6][64]; // world-space origin and direction per lane
-#endif
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
-#if PT_INLINE_FINISH
-    // any-hit: queue entries of the unoccluded rays that have finished and wait for their deposit (made in batches of
-    // >= PT_DEPOSIT_BATCH: the three dependent memory accesses of a deposit then stall the wave once per batch, and the lanes of
-    // the finished rays are free for new rays at once)
-    __shared__ uint32_t ldsDone[ANY_HIT ? kTraceBlock / 64 : 1][ANY_HIT ? 128 : 1];
-    uint32_t doneCount = 0; // wave-uniform
-#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -184,25 +150,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     unsigned long long statAcc[24] = {};
     PT_TIC(tKernel);
 #endif
-#if PT_INLINE_FINISH
-    auto flushDeposits = [&]() { // any-hit only
-        for (uint32_t base = 0; base < doneCount; base += 64u) {
-            const uint32_t e = base + lane;
-            if (e < doneCount) {
-                const uint32_t idx = ldsDone[ANY_HIT ? wave : 0][ANY_HIT ? e : 0];
-                const float4 contrib = a.rayC[idx];
-                const uint32_t pixel = asU(a.rayD[idx].w);
-                float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
-                float4 px = *ap;
-                px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
-                *ap = px;
-            }
-        }
-        if (lane == 0)
-            ldsDeposits[wave] += doneCount;
-        doneCount = 0;
-    };
-#endif
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
     uint32_t rayIdx = 0;
@@ -212,9 +159,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     int hprim = -1, hinst = -1, curInst = -1;
     uint32_t cur = kRefFinish;
     int sp = 0;
-#if PT_DEFER_LEAF
-    uint32_t pend = 0u; // leaf reference set aside (0 = none; a leaf reference has a non-zero count field)
-#endif
     // value of pop() given the prefetched LDS entry `top` (does not move sp)
     auto popTop = [&](uint32_t top) -> uint32_t {
         uint32_t v = sp > 0 ? top : kRefFinish;
@@ -263,14 +207,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
-#if PT_STAGE_RAYS
         if (poolEnd) { // wave-uniform.  Lane l copies entry l (clamped: the tail of the last packet is never handed out)
             const uint32_t e = base + min(lane, poolEnd - 1u);
             // every lane has read its ray of the previous packet (the reads were waited for before the rays were used)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rayO + e), (__attribute__((address_space(3))) void*)&ldsRays[wave][0][0], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rayD + e), (__attribute__((address_space(3))) void*)&ldsRays[wave][1][0], 16, 0, 0);
         }
-#endif
     };
     requestPacket();
 
@@ -292,18 +234,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     // the packet is only claimed; the lanes that take a ray read it straight from the queue
                     // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
                     ro = rd = make_float4(0, 0, 0, 0);
-#if PT_STAGE_RAYS
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the packet's copy into LDS has landed
                     if (!active && rank < avail) {
                         ro = ldsRays[wave][0][e];
                         rd = ldsRays[wave][1][e];
                     }
-#else
-                    if (!active && rank < avail) {
-                        ro = a.rayO[poolBase + (uint32_t)e];
-                        rd = a.rayD[poolBase + (uint32_t)e];
-                    }
-#endif
                     PT_TOC(16, tShfl);
                     PT_TIC(tAssign);
                     if (!active && rank < avail) {
@@ -330,10 +265,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             if (ro.x == 0.0f) ro.x = -FLT_MIN;
                             if (ro.y == 0.0f) ro.y = -FLT_MIN;
                             if (ro.z == 0.0f) ro.z = -FLT_MIN;
-#if !PT_STAGE_RAYS
-                            ldsWorld[wave][0][lane] = ro.x, ldsWorld[wave][1][lane] = ro.y, ldsWorld[wave][2][lane] = ro.z;
-                            ldsWorld[wave][3][lane] = rd.x, ldsWorld[wave][4][lane] = rd.y, ldsWorld[wave][5][lane] = rd.z;
-#endif
                             setRay(xyz(ro), xyz(rd));
                             tClosest = tMax;
                             hprim = -1;
@@ -343,9 +274,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             cur = sc.rootRef;
                             sp = 0;
                             active = true;
-#if PT_DEFER_LEAF
-                            pend = 0u;
-#endif
                         }
                     }
                     PT_TOC(17, tAssign);
@@ -367,12 +295,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
         // the ray-space registers stay loop-invariant in it.
         while (true) {
-#if PT_DEFER_LEAF
-            // a pending leaf belongs to the ray space the lane is in: it is tested (hot loop) before the lane changes space or retires
-            const bool wantSpecial = active && refCount(cur) == kRefSpecial && pend == 0u;
-#else
             const bool wantSpecial = active && refCount(cur) == kRefSpecial;
-#endif
             const unsigned long long m = __ballot(wantSpecial);
             if (m == 0ull)
                 break;
@@ -397,13 +320,11 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
                         *ap = px;
                     } else {
-#if !PT_INLINE_FINISH
                         if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of an instance: back to (original triangle, instance)
                             const float4 tc = sc.tris[hprim].c;
                             hprim = (int)asU(tc.y);
                             hinst = (int)asU(tc.z);
                         }
-#endif
                         a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
                         a.inst[rayIdx] = hinst;
                     }
@@ -411,7 +332,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 } else {
                     if (what == kSpecialLeaveInstance) {
                         // -------- back to world space ---------------------------------------------------------
-#if PT_STAGE_RAYS
                         {   // the world-space ray again, from the queue (instances are rarely entered: ptamd.hip copies them to world space)
                             float4 wo = a.rayO[rayIdx], wd = a.rayD[rayIdx];
                             if (wd.x == 0.0f) wd.x = FLT_MIN;
@@ -422,10 +342,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             if (wo.z == 0.0f) wo.z = -FLT_MIN;
                             setRay(xyz(wo), xyz(wd));
                         }
-#else
-                        setRay(mk(ldsWorld[wave][0][lane], ldsWorld[wave][1][lane], ldsWorld[wave][2][lane]),
-                            mk(ldsWorld[wave][3][lane], ldsWorld[wave][4][lane], ldsWorld[wave][5][lane]));
-#endif
                         curInst = -1;
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     } else {
@@ -467,70 +383,17 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const uint32_t stackTop = ldsStack[wave][min(max(sp - 1, 0), kLdsStack - 1)][lane];
             const uint32_t kindBits = refCount(cur);
             const bool wantInner = active && kindBits == 0u;
-#if PT_DEFER_LEAF
-            const bool curLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
-            const bool hasPend = pend != 0u;
-            const bool canDefer = curLeaf && !hasPend;
-            // lanes that cannot go on without a leaf step: a second leaf reached, or a special step (space change / end) with a leaf pending
-            const bool mustLeaf = active && hasPend && kindBits != 0u;
-            const bool wantLeaf = curLeaf || hasPend;
-            const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf)), nMust = __popcll(__ballot(mustLeaf));
-#else
             const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
             const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
-#endif
             PT_STAT(0, 1);
             PT_STAT(1, nInner + nLeaf);
             // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
             // enough lanes are idle for a hand-out (and the queue still has rays)
-#if PT_INLINE_FINISH
-            unsigned long long mSpecial = __ballot(active && kindBits == kRefSpecial);
-            if (mSpecial != 0ull) { // wave-uniform
-                const bool fin = active && cur == kRefFinish;
-                const unsigned long long mFin = __ballot(fin);
-                if (mFin != 0ull) {
-                    if (ANY_HIT) {
-                        // unoccluded (an occluded ray retires in its leaf step): queue the deposit, free the lane
-                        if (doneCount + (uint32_t)__popcll(mFin) > 128u)
-                            flushDeposits();
-                        if (fin) {
-                            ldsDone[ANY_HIT ? wave : 0][ANY_HIT ? doneCount + (uint32_t)__popcll(mFin & ((1ull << lane) - 1ull)) : 0] = rayIdx;
-                            if (a.occluded)
-                                a.occluded[rayIdx] = 0u;
-                            active = false;
-                        }
-                        doneCount += (uint32_t)__popcll(mFin);
-                        if (doneCount >= PT_DEPOSIT_BATCH)
-                            flushDeposits();
-                    } else if (fin) {
-                        // closestT != maxT decides hit/miss (scene.cl:257); hprim / hinst already name the original triangle
-                        a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
-                        a.inst[rayIdx] = hinst;
-                        active = false;
-                    }
-                    mSpecial &= ~mFin;
-                }
-            }
-            const int nSpecial = __popcll(mSpecial);
-#else
-#if PT_DEFER_LEAF
-            const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial && !hasPend));
-#else
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
-#endif
-#endif
-#if PT_DEFER_LEAF
-            const int nWork = __popcll(__ballot(wantInner || wantLeaf));
-#else
             const int nWork = nInner + nLeaf;
-#endif
             if (nWork == 0 || nSpecial >= (ANY_HIT ? kParkedBreakAny : kParkedBreak) || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
-#if PT_DEFER_LEAF
-            if (nInner > 0 && (nInner * PT_VOTE_INNER >= nMust * PT_VOTE_LEAF) && !(nLeaf >= PT_DEFER_FULL)) {
-#else
             if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
-#endif
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
@@ -565,44 +428,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                     const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
                     const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
-#if PT_INTKEYS
-                    // Child ordering on INTEGER keys, with no lane mask on the way (measured, profiles/round2 valu_issue: a
-                    // compare whose mask the next instruction selects on stalls the issue port for ~8 cycles; v_sub / shifts /
-                    // and / or / xor are full-rate instructions, compares, selects, min / max half-rate):
-                    //   key = bits of max(tmin, 0) -- ordered like the distances -- or >= 0x7F800000 when the box is not visible.
-                    uint32_t key[4];
-                    uint32_t ref[4] = { D.x, D.y, D.z, D.w };
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
-                        const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
-                        const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
-                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
-                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
-                        const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
-                        const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
-                        // max(tmin, 0) on the bit patterns as signed integers: negative distances (and -0) become +0
-                        const uint32_t tloBits = (uint32_t)max((int32_t)asU(tmin), 0);
-                        const float tlo = asF(tloBits);
-                        // accept test of bvh.cl:72,114 on the (slightly larger) quantised box: tmax >= tmin && tmax >= 0 &&
-                        // tmin < closest  <=>  tmax >= tlo && tlo < closest (closest > 0).  Sign bit of the OR <=> rejected;
-                        // at tlo == closest the box is entered although the reference would not: nothing in it can be
-                        // accepted (a hit needs t < closest), the result is the same.
-                        const uint32_t rejected = asU(tmax - tlo) | asU(tClosest - tlo);
-                        key[k] = tloBits | ((uint32_t)((int32_t)rejected >> 31) & 0x7F800000u);
-                    }
-#define PT_VISIBLE(k) ((key[k] - 0x7F800000u) >> 31) /* 1 when key < 0x7F800000 */
-#define PT_CSWAP(i, j)                                   \
-    {                                                    \
-        const bool sw = key[j] < key[i];                 \
-        const uint32_t tk = sw ? key[j] : key[i];        \
-        key[j] = sw ? key[i] : key[j];                   \
-        key[i] = tk;                                     \
-        const uint32_t tr = sw ? ref[j] : ref[i];        \
-        ref[j] = sw ? ref[i] : ref[j];                   \
-        ref[i] = tr;                                     \
-    }
-#else
                     float key[4];
                     uint32_t ref[4] = { D.x, D.y, D.z, D.w };
 #pragma unroll
@@ -630,9 +455,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
         ref[j] = sw ? ref[i] : ref[j];                   \
         ref[i] = tr;                                     \
     }
-#endif
 #if PT_ANYHIT_SORT == 0
-                    if (ANY_HIT || PT_CLOSEST_PARTIAL_SORT) { // any occluder will do: only move the nearest visible child to the front
+                    if (ANY_HIT) { // any occluder will do: only move the nearest visible child to the front
                         PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2)
                     } else
 #endif
@@ -672,13 +496,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         cur = next, sp = max(sp - 1, 0);
 #undef PT_VISIBLE
                 }
-#if PT_DEFER_LEAF
-                else if (canDefer) { // out-voted at a leaf: set it aside, go on with the stack
-                    pend = cur;
-                    cur = popTop(stackTop);
-                    sp = max(sp - 1, 0);
-                }
-#endif
                 PT_TOC(11, tInner);
             } else {
                 PT_STAT(3, 1);
@@ -686,22 +503,12 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_TIC(tLeaf);
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
-#if PT_DEFER_LEAF
-                    const uint32_t leafRef = hasPend ? pend : cur;
-                    const uint32_t first = refIndex(leafRef), n = refCount(leafRef);
-#else
-                    const uint32_t first = refIndex(cur), n = PT_LEAF_SINGLE ? 1u : kindBits;
-#endif
+                    const uint32_t first = refIndex(cur), n = kindBits;
                     bool done = false;
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
-#if PT_INLINE_FINISH
-                        const float4 tcv = tp->c; // e2.z, and for a world-space copy of an instance: original triangle, instance
-                        const float tcx = tcv.x;
-#else
                         const float tcx = tp->c.x;
-#endif
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
                         const V3 P = cross(cd, e2);
                         const float det = dot(e1, P);
@@ -721,14 +528,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             tClosest = t;
                             hu = u;
                             hv = v;
-#if PT_INLINE_FINISH
-                            // a hit at world level is a hit on a world-space copy: name the original triangle and instance now
-                            hprim = curInst < 0 ? (int)asU(tcv.y) : (int)(first + k);
-                            hinst = curInst < 0 ? (int)asU(tcv.z) : curInst;
-#else
                             hprim = (int)(first + k);
                             hinst = curInst;
-#endif
                         }
                     }
                     if (ANY_HIT && done) { // occluded: nothing to deposit
@@ -736,13 +537,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                             a.occluded[rayIdx] = 1u;
                         active = false;
                         cur = kRefFinish;
-#if PT_DEFER_LEAF
-                        pend = 0u;
-                    } else if (hasPend) {
-                        pend = 0u; // `cur` (an inner node, a second leaf or a special step) is next
-#endif
-                    } else if (PT_LEAF_SINGLE && kindBits > 1u) {
-                        cur += 1u - (1u << kRefIndexBits); // next triangle of the leaf, one fewer to go
                     } else {
                         cur = popTop(stackTop);
                         sp = max(sp - 1, 0);
@@ -752,10 +546,6 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             }
         }
     }
-#if PT_INLINE_FINISH
-    if (ANY_HIT && doneCount)
-        flushDeposits();
-#endif
     if (ANY_HIT && lane == 0 && ldsDeposits[wave])
         atomicAdd(&a.ctl->depositsShadow, ldsDeposits[wave]);
     PT_TOC(10, tKernel);
