@@ -47,6 +47,40 @@ __device__ inline void lanePush(uint32_t& r, uint32_t& lo, uint32_t& hi, uint32_
 }
 constexpr uint32_t kKeyNone = 0x7F800000u; // +inf: no lane sees the child
 
+#ifndef PT_PACKET_BEAM
+#define PT_PACKET_BEAM 1 // 1: packets whose rays all point into one octant test the child boxes against the BEAM (24 lanes, one plane each)
+#endif
+// butterfly reductions over the 64 lanes (ds_bpermute: the LDS crossbar, not the vector ALU's issue port); every lane gets the result
+__device__ inline float waveMin(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ inline float waveMax(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+// max(v[lane], v[lane - 2]) within a row of 16 lanes (lanes 0 / 1 of a row keep v): ONE v_max_f32 with a DPP operand.  Written in
+// assembly: through __builtin_amdgcn_update_dpp + fmaxf the compiler emits a move, the DPP move and a canonicalising max besides
+// (the s_nop covers the two wait states a DPP read needs after a vector write of the same register)
+__device__ inline float maxRowShr2(float v)
+{
+    float r = v;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
+}
+__device__ inline float rowShr1(float v) // v[lane - 1]
+{
+    float r = v;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
+}
+
 template <bool ANY_HIT>
 __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_packet(TraceArgs a)
 {
@@ -131,6 +165,125 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         float hu = 0.f, hv = 0.f;
         int hprim = -1;
 
+        // ---- beam traversal (closest hit, whole packets of rays pointing into one octant) --------------------------------------
+        // The 64 primary rays of a packet are the samples of one pixel: almost one ray.  Testing four child boxes for each of them is
+        // 64 x the same answer at ~85 vector instructions per node.  Here the node is tested ONCE against the beam that holds all 64
+        // rays -- origin interval x reciprocal-direction interval per axis -- with the 24 planes of its four children spread over 24
+        // lanes: lane (child, axis, near | far) computes one bound, t_near >= lower and t_far <= upper for every ray of the packet, two
+        // DPP steps fold the three axes, one compare per child decides (lower bound of the entry <= upper bound of the exit, exit >= 0,
+        // entry < the farthest closest hit in the packet): ~25 vector instructions per node.  Conservative (a box no ray enters
+        // may pass -- its triangles are then tested and missed), never the other way: intervals only widen, and the multipliers carry a
+        // relative slack of 2^-18 against round-off.  Triangle tests are per ray, unchanged.  Packets that are not full, contain
+        // finished rays or straddle a sign change of a direction component take the per-ray path below.
+        bool viaBeam = false;
+#if PT_PACKET_BEAM
+        if (!ANY_HIT) {
+            const unsigned long long all = ~0ull;
+            const unsigned long long sx = __builtin_amdgcn_ballot_w64(nx), sy = __builtin_amdgcn_ballot_w64(ny), sz = __builtin_amdgcn_ballot_w64(nz);
+            viaBeam = __builtin_amdgcn_ballot_w64(active) == all && (sx == 0ull || sx == all) && (sy == 0ull || sy == all) && (sz == 0ull || sz == all);
+        }
+        if (!ANY_HIT && viaBeam) {
+            // lane roles (lanes 32-63 repeat 0-31 and are never read): group of 8 lanes per child, (axis, near | far) inside it
+            const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
+            // the beam: per axis the interval of the origins and of |1 / direction| (signs are uniform)
+            V3 oLo = co, oHi = co;
+            if (__builtin_amdgcn_ballot_w64(co.x != asF(uni(asU(co.x))) || co.y != asF(uni(asU(co.y))) || co.z != asF(uni(asU(co.z)))) != 0ull) { // not a pinhole
+                oLo = mk(waveMin(co.x), waveMin(co.y), waveMin(co.z));
+                oHi = mk(waveMax(co.x), waveMax(co.y), waveMax(co.z));
+            }
+            const V3 aid = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z));
+            const V3 mLo = mk(waveMin(aid.x), waveMin(aid.y), waveMin(aid.z)), mHi = mk(waveMax(aid.x), waveMax(aid.y), waveMax(aid.z));
+            const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+            const float oLoA = axis == 0u ? oLo.x : (axis == 1u ? oLo.y : oLo.z), oHiA = axis == 0u ? oHi.x : (axis == 1u ? oHi.y : oHi.z);
+            const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
+            const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
+            // g = +-(plane - origin corner) is the signed distance along the axis in the ray's sense; t = g * |1/d|.
+            //   entry plane, lower bound: the corner that makes g smallest, times the small multiplier when g >= 0, the large one otherwise
+            //   exit plane, upper bound: the corner that makes g largest, times the large multiplier when g >= 0, the small one otherwise
+            // (exit lanes hold -upper, so that one max folds both)
+            const float S = neg ? -1.f : 1.f;
+            const float corner = (neg != (isFar != 0u)) ? oLoA : oHiA;
+            const float negSO = -(S * corner);
+            const float mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
+            const uint32_t ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar)), ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
+            float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the packet
+            uint32_t stRef = 0u; // the stack: entry e is lane e
+            uint32_t sp = 0u;
+            uint32_t cur = rootRef;
+            while (true) {
+                if (refCount(cur) == 0u) {
+                    const uint32_t ni = refIndex(cur);
+                    const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
+                    const char* nb = (const char*)&sc.wide[ni];
+                    const float originA = *(const float*)(nb + ofsO);
+                    const uint32_t ebits = *(const uint8_t*)(nb + ofsE);
+                    const uint32_t qd = *(const uint32_t*)(nb + ofsQ);
+                    const float q = (float)((qd >> shift) & 0xFFu);
+                    const float g = fmaf(q, S * asF(ebits << 23), fmaf(S, originA, negSO));
+                    float v = g * (g >= 0.f ? mulPos : mulNeg);
+                    v = maxRowShr2(v);
+                    v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
+                    const float tn = rowShr1(v); // lane 5: the entry bound from lane 4
+                    // entry <= exit, exit >= 0, entry < the packet's culling distance: three lane masks and-ed in scalar registers
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= 0.f) & __builtin_amdgcn_ballot_w64(tn < tcMax);
+                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn), 0); // bits of max(tn, 0): negative floats are negative integers
+                    uint32_t key[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        key[k] = ((m >> (8 * k + 5)) & 1ull) ? ((__builtin_amdgcn_readlane(tloBits, 8 * k + 5) & ~3u) | (uint32_t)k) : (kKeyNone | (uint32_t)k);
+                    const bool s01 = key[0] < key[1], s23 = key[2] < key[3];
+                    const uint32_t k01 = s01 ? key[0] : key[1], k23 = s23 ? key[2] : key[3];
+                    const uint32_t r01 = s01 ? D.x : D.y, r23 = s23 ? D.z : D.w;
+                    const bool sl = k01 < k23;
+                    const uint32_t best = sl ? k01 : k23;
+                    if (best < kKeyNone) {
+                        const uint32_t refs[4] = { D.x, D.y, D.z, D.w };
+                        const uint32_t limit = kKeyNone - best - 1u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (key[k] - best - 1u < limit) {
+                                stRef = laneWrite(stRef, uni(refs[k]), uni(sp));
+                                sp++;
+                            }
+                        cur = sl ? r01 : r23;
+                        continue;
+                    }
+                } else {
+                    const uint32_t first = refIndex(cur), n = refCount(cur);
+                    bool any = false;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
+                        const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
+                        const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
+                        const V3 P = cross(cd, e2);
+                        const float det = dot(e1, P);
+                        const float inv = rcpFast(det);
+                        const V3 T = co - v0;
+                        const float u = dot(T, P) * inv;
+                        const V3 Q = cross(T, e1);
+                        const float v = dot(cd, Q) * inv;
+                        const float t = dot(e2, Q) * inv;
+                        const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tClosest;
+                        if (hit) {
+                            tClosest = t;
+                            hu = u;
+                            hv = v;
+                            hprim = (int)(first + k);
+                            any = true;
+                        }
+                    }
+                    // the packet's culling distance shrinks once every ray has a hit
+                    if (__builtin_amdgcn_ballot_w64(any) != 0ull && __builtin_amdgcn_ballot_w64(tClosest == INFINITY) == 0ull)
+                        tcMax = asF(uni(asU(waveMax(tClosest))));
+                }
+                if (sp == 0u)
+                    break;
+                sp--;
+                cur = __builtin_amdgcn_readlane(stRef, sp);
+            }
+        } else
+#endif
+        {
         uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
         uint32_t sp = 0u; // wave-uniform
         uint32_t cur = rootRef;
@@ -234,6 +387,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                 curMask = (unsigned long long)__builtin_amdgcn_readlane(stLo, sp) | ((unsigned long long)__builtin_amdgcn_readlane(stHi, sp) << 32);
             }
 
+        }
         // -------- results: consecutive lanes write consecutive records (scene.cl:257) --------------------------
         if (ANY_HIT) {
             const uint32_t nDep = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));

@@ -107,6 +107,45 @@ def test_edge_cases(gpu, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("thin", [False, True])
+def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin):
+    """Closest-hit packets whose 64 rays point into one octant are walked with ONE conservative beam test per node
+    (pt_packet.h) instead of 64 ray tests.  The beam may enter boxes no ray enters, never skip one a ray enters, and
+    the triangle tests are the per-ray kernel's: hits must be identical (same triangle, same t / u / v bits) except
+    at exact-t ties (duplicated SBVH references).  Three packet shapes: the samples of one pixel (a thin beam), 64 neighbouring pixels (a wide
+    one), and packets that mix rays of distant pixels (many straddle an octant boundary: the per-lane fallback)."""
+    W, Hh = 256, 144
+    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=thin, sky_size=(16, 8))
+    packet = U.make_ctx(gpu, b, W, Hh, flags=gpu.FLAG_PACKET_INTERSECT)
+    per_ray = U.make_ctx(gpu, b, W, Hh)
+    rows = []
+    for sample in range(4):
+        o, d, _ = per_ray.gen_rays(sample, W * Hh)
+        rows.append((o, d))
+    o_n, d_n = rows[0]  # consecutive entries = neighbouring pixels of a row
+    # the samples of one pixel next to each other: entry (pixel, sample) for 64 'samples' made of 4 real samples x 16 jitters
+    rng = np.random.default_rng(3)
+    pix = rng.choice(W * Hh, 600, replace=False)
+    o_s = np.concatenate([np.repeat(rows[k][0][pix], 16, axis=0).reshape(len(pix), 16, 3) for k in range(4)], axis=1).reshape(-1, 3)
+    d_s = np.concatenate([np.repeat(rows[k][1][pix], 16, axis=0).reshape(len(pix), 16, 3) for k in range(4)], axis=1).reshape(-1, 3)
+    d_s = (d_s + rng.normal(0, 2e-4, d_s.shape)).astype(np.float32)
+    perm = rng.permutation(len(o_n))[:20000]
+    for name, o, d in (("neighbours", o_n, d_n), ("one pixel", o_s.astype(np.float32), d_s), ("shuffled", o_n[perm], d_n[perm])):
+        got, want = packet.intersect(o, d), per_ray.intersect(o, d)
+        same = (got["prim"] == want["prim"]) & (got["inst"] == want["inst"])
+        # a differing record is a tie -- both kernels found a hit at the same distance, the traversal order picked the winner: an
+        # SBVH mesh holds the triangles it split once per leaf that references them, the same triangle under two indices
+        diff = ~same
+        assert diff.mean() < 1e-3, (name, diff.sum())
+        assert np.allclose(got["t"][diff], want["t"][diff], rtol=1e-6), name
+        for k in ("t", "u", "v"):
+            assert np.array_equal(got[k][same], want[k][same]), (name, k)
+        assert (got["prim"] >= 0).mean() > 0.3, name
+    assert packet.stats()["packet_launches"] > 0 and per_ray.stats()["packet_launches"] == 0
+    packet.close()
+    per_ray.close()
+
+
 def test_invalid_scenes_are_rejected_not_traversed(gpu):
     b = scenes.cornell_box(16, 16)
     f = b.flat
