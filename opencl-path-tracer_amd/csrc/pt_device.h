@@ -24,9 +24,9 @@ struct PairNode {
     uint32_t _pad0, _pad1;
 };
 
-// 4-wide node with 8-bit quantised child boxes (64 B), built at upload by collapsing the pair-node tree: the two
-// children of a pair node, then -- surface-area greedy -- the largest inner child is replaced by its own two
-// children until four are collected (ptamd.hip, collapseToWide).
+// 4-wide node with 8-bit quantised child boxes (64 B), built at upload by collapsing the pair-node tree: which descendants of a
+// pair node become the (up to four) children of its wide node is chosen by dynamic programming over the binary tree so that the
+// summed surface area of the wide tree's inner nodes is minimal (ptamd.hip, collapseToWide).
 // Child box k = origin + 2^exp * q (per axis), q in [0,255], rounded outwards: a superset of the exact
 // box, so traversal visits at worst a few extra nodes and finds exactly the same triangles.  One step
 // now needs four 16-byte loads for four children instead of eight for the same two levels.
