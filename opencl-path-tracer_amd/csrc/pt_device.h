@@ -63,13 +63,25 @@ struct TriIsect {
     float4 c; // e2.z, -, -, -
 };
 
-// Triangle for shading (64 B): vertex indices + material, the same v0/e1/e2 are re-read from TriIsect.
+// Host-side intermediates of the shading data (caller's indexed layout: not uploaded)
 struct TriShade {
     uint32_t i0, i1, i2, material;
 };
 struct VertexShade { // 32 B
     float4 n_u; // normal.xyz, texCoord.x
     float4 v_pad; // texCoord.y
+};
+// Triangle for shading: everything k_shade needs of a hit triangle in ONE 128-byte line (caller's triangle numbering, object space).
+// The indexed layout it replaces cost an incoherent hit five scattered lines and a dependent fetch (16 B of vertex indices + material,
+// three 32-byte vertex records through them, the 48-byte intersection record for the geometric normal): from the second bounce on
+// k_shade fetched more scene data than queue entries (20 GB against 14 GB for 4.4 x fewer entries, FETCH_SIZE per dispatch).
+struct TriFat {
+    float4 n0u, n1u, n2u; // vertex normal.xyz, texCoord.x of the three vertices
+    float4 vvvm; // texCoord.y of the three vertices, bits(material)
+    float4 e1e; // edge1.xyz, edge2.x          (v0 / edge1 / edge2 exactly as in TriIsect)
+    float4 e2v; // edge2.yz, v0.xy
+    float4 v0z; // v0.z, -, -, -
+    float4 _pad;
 };
 
 // instance (64 B): rows of the 3x4 inverse world transform + root reference of the mesh BVH
@@ -110,9 +122,8 @@ __device__ inline float4 fetchTexel(const Texture& tex, size_t index)
 struct SceneDev {
     const PairNode* nodes; // the reference's binary tree, both boxes per node: host-side intermediate, not uploaded (null)
     const WideNode* wide; // 4-wide tree (k_trace)
-    const TriIsect* tris; // caller's triangle numbering (shading re-reads v0/e1/e2 from here)
-    const TriShade* triShade;
-    const VertexShade* verts;
+    const TriIsect* tris; // caller's triangle numbering, then the world-space copies of baked instances
+    const TriFat* triFat; // caller's triangle numbering
     const Material* materials;
     const Instance* instances;
     const Light* lights;

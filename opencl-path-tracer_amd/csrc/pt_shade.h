@@ -277,13 +277,14 @@ struct ShadeOpts {
 // material-texture fetch for diffuseColour (shading_helper.cl:280-307); x = -1 marks an alpha-0 texel.  Without a texture
 // array the fetch returns opaque white (what the oracle binds by default): only neeMisShading's PBR light sample can get
 // here without one, through its DIFFUSE view of a PBR record (see shadeHit).
-__device__ inline V3 diffuseColourTextured(const SceneDev& sc, const MatView& mat, const VertexShade& a0, const VertexShade& a1, const VertexShade& a2, float u, float v)
+// (f0.w, f1.w, f2.w) / (f3.x, f3.y, f3.z): texCoord.x / .y of the three vertices (TriFat)
+__device__ inline V3 diffuseColourTextured(const SceneDev& sc, const MatView& mat, float4 f0, float4 f1, float4 f2, float4 f3, float u, float v)
 {
     if (!sc.materialTex.texels)
         return mk(1.0f);
-    const float t0x = a0.n_u.w, t0y = a0.v_pad.x;
-    const float tcx = t0x + (a1.n_u.w - t0x) * u + (a2.n_u.w - t0x) * v;
-    const float tcy = t0y + (a1.v_pad.x - t0y) * u + (a2.v_pad.x - t0y) * v;
+    const float t0x = f0.w, t0y = f3.x;
+    const float tcx = t0x + (f1.w - t0x) * u + (f2.w - t0x) * v;
+    const float tcy = t0y + (f3.y - t0y) * u + (f3.z - t0y) * v;
     const float4 c = sampleLinearRepeat(sc.materialTex, tcx, tcy, (float)mat.texId);
     return (c.w == 0.0f) ? mk(-1.0f) : xyz(c);
 }
@@ -326,19 +327,17 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
     V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out, const ShadeOpts& opt)
 {
     const bool MIS = GENERAL && opt.mis;
-    const TriShade ts = sc.triShade[prim];
-    const TriIsect* tp = &sc.tris[prim];
-    const float4 ta = tp->a, tb = tp->b, tc = tp->c;
-    const V3 edge1 = mk(ta.w, tb.x, tb.y), edge2 = mk(tb.z, tb.w, tc.x);
+    const TriFat* fp = &sc.triFat[prim];
+    const float4 f0 = fp->n0u, f1 = fp->n1u, f2 = fp->n2u, f3 = fp->vvvm, f4 = fp->e1e, f5 = fp->e2v;
+    const V3 edge1 = xyz(f4), edge2 = mk(f4.w, f5.x, f5.y);
     const Instance in = sc.instances[instIdx];
     const V3 realNormal = normalize(normalTransform(in, cross(edge1, edge2)));
-    const VertexShade a0 = sc.verts[ts.i0], a1 = sc.verts[ts.i1], a2 = sc.verts[ts.i2];
-    const V3 n0 = xyz(a0.n_u), n1 = xyz(a1.n_u), n2 = xyz(a2.n_u);
+    const V3 n0 = xyz(f0), n1 = xyz(f1), n2 = xyz(f2);
     const V3 shadingNormal = normalize(n0 + (n1 - n0) * u + (n2 - n0) * v); // object space, not instance-transformed (shading.cl:378)
     V3 raySideNormal = shadingNormal;
     if (dot(raySideNormal, -D) < 0.0f)
         raySideNormal = raySideNormal * -1.0f;
-    const MatView mat = loadMaterial(sc, ts.material);
+    const MatView mat = loadMaterial(sc, asU(f3.w));
     out.radiance = mk(0.0f);
     out.flags = 0;
     out.pdf = 0.f;
@@ -349,7 +348,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         if (inFlags & FLAG_LASTSPECULAR) {
             out.radiance = throughput * mat.colour;
         } else if (MIS) { // shading.cl:69-90: a BSDF-sampled direction found the light: balance heuristic against NEE's density
-            const V3 v0 = mk(ta.x, ta.y, ta.z), v1 = v0 + edge1, v2 = v0 + edge2; // object space, as the reference
+            const V3 v0 = mk(f5.z, f5.w, fp->v0z.x), v1 = v0 + edge1, v2 = v0 + edge2; // object space, as the reference
             const V3 A = v1 - v0, B = v2 - v1, C = v0 - v2;
             const float la = sqrtf(dot(A, A)), lb = sqrtf(dot(B, B)), lc = sqrtf(dot(C, C));
             const float hs = (la + lb + lc) / 2.0f;
@@ -369,9 +368,9 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
     // diffuse albedo lookup shared by NEE and the continuation (shading_helper.cl:280-307); x=-1: alpha-0 texel
     V3 albedo = mat.colour;
     if (mat.type == MAT_DIFFUSE && mat.texId != -1) {
-        const float t0x = a0.n_u.w, t0y = a0.v_pad.x;
-        const float tcx = t0x + (a1.n_u.w - t0x) * u + (a2.n_u.w - t0x) * v;
-        const float tcy = t0y + (a1.v_pad.x - t0y) * u + (a2.v_pad.x - t0y) * v;
+        const float t0x = f0.w, t0y = f3.x;
+        const float tcx = t0x + (f1.w - t0x) * u + (f2.w - t0x) * v;
+        const float tcy = t0y + (f3.y - t0y) * u + (f3.z - t0y) * v;
         const float4 c = sampleLinearRepeat(sc.materialTex, tcx, tcy, (float)mat.texId);
         albedo = (c.w == 0.0f) ? mk(-1.0f) : xyz(c);
     }
@@ -410,7 +409,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
                     pdf2 = D_GGX(dot(shadingNormal, halfway), 1.0f - mat.p0);
                 // sic: diffuseColour() of a PBR record -- tex_id is the bit pattern of `smoothness`, never -1, so this is a
                 // material-texture fetch at a clamped layer (pbrBrdf's value, shading.cl:117, is overwritten there)
-                const V3 c = diffuseColourTextured(sc, mat, a0, a1, a2, u, v);
+                const V3 c = diffuseColourTextured(sc, mat, f0, f1, f2, f3, u, v);
                 BRDF = (c.x == -1.0f) ? mk(0.0f) : c / kPI;
             } else if (mat.type == MAT_PBR) {
                 BRDF = pbrBrdfWithDiffuse(-D, L, shadingNormal, mat, mat.p0 > kMaxSmoothness);

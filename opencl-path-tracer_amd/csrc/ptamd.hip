@@ -84,6 +84,7 @@ struct pt_ctx {
     struct DynamicSet {
         DevBuf<WideNode> wide;
         DevBuf<TriIsect> tris;
+        DevBuf<TriFat> fat; // shading records: they hold v0 / edges / normals, which a refitted mesh changes with the trees
         DevBuf<Instance> instances;
         DevBuf<Light> lights;
         // pinned staging the asynchronous copies read from (grow-only, like the device buffers)
@@ -99,7 +100,6 @@ struct pt_ctx {
     int active = 0; // set the render kernels read
     int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
     hipStream_t copyStream = nullptr;
-    bool vertsDirty = false; // pt_update_geometry changed the shading vertices: copied on the render stream at the next tick
     std::vector<VertexShade> hostVerts;
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
@@ -200,8 +200,7 @@ void refreshSceneView(pt_ctx* c)
     const pt_ctx::DynamicSet& d = c->dyn[c->active];
     s.wide = d.wide.p;
     s.tris = d.tris.p;
-    s.triShade = c->triShade.p;
-    s.verts = c->verts.p;
+    s.triFat = d.fat.p;
     s.materials = c->materials.p;
     s.instances = d.instances.p;
     s.lights = d.lights.p;
@@ -1055,9 +1054,9 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->texMaterial.release(), c->texSky.release();
-    c->nodes.release(), c->triShade.release(), c->verts.release(), c->materials.release();
+    c->nodes.release(), c->materials.release();
     for (auto& d : c->dyn) {
-        d.wide.release(), d.tris.release(), d.instances.release(), d.lights.release();
+        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release();
         if (d.stage) (void)hipHostFree(d.stage);
         if (d.uploaded) (void)hipEventDestroy(d.uploaded);
         if (d.lastUse) (void)hipEventDestroy(d.lastUse);
@@ -1234,21 +1233,18 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->hostTris = hTris;
     c->hostBottomNodes = std::move(hNodes);
     if (geometryOnly) {
-        c->hostVerts = std::move(hVerts);
-        c->vertsDirty = true; // copied in stream order at the next pt_frame_tick, together with the flip to the refitted trees
+        c->hostVerts = std::move(hVerts); // the next pt_upload_dynamic builds the shading records of the refitted state from them
         for (uint32_t i = 0; i < nN; i++) // only the boxes may differ
             c->hostSubNodes[i] = nodes[i];
         return PT_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
-    if ((rc = uploadVec(c, c->triShade, hShade)) || (rc = uploadVec(c, c->verts, hVerts))
-        || (rc = uploadVec(c, c->materials, hMats)))
+    if ((rc = uploadVec(c, c->materials, hMats)))
         return rc;
     c->hostTriShade = std::move(hShade);
     c->hostMaterials.assign(mats, mats + nM);
     c->hostSubNodes.assign(nodes, nodes + nN);
     c->hostVerts = std::move(hVerts);
-    c->vertsDirty = false;
     c->numVerts = nV;
     c->numRefNodes = nN;
     c->numTris = nT;
@@ -1296,6 +1292,7 @@ namespace {
 // What the host-side conversion of one dynamic state produces (no device call in it): the arrays of a DynamicSet.
 struct DynamicHost {
     std::vector<TriIsect> tris;
+    std::vector<TriFat> fat;
     std::vector<WideNode> wide;
     std::vector<Instance> instances;
     std::vector<Light> lights;
@@ -1589,6 +1586,24 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
 #else
     packed = hWide;
 #endif
+    // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h), from the host copies of the
+    // vertex / index / intersection arrays -- which pt_update_geometry has already replaced when this state is a refitted one
+    out.fat.resize(c->hostTriShade.size());
+    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
+        const TriShade& ts = c->hostTriShade[t];
+        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
+        const TriIsect& ti = c->hostTris[t];
+        TriFat f {};
+        f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
+        float mbits;
+        std::memcpy(&mbits, &ts.material, 4);
+        f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
+        f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
+        f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
+        f.v0z = make_float4(ti.a.z, 0.f, 0.f, 0.f);
+        f._pad = make_float4(0.f, 0.f, 0.f, 0.f);
+        out.fat[t] = f;
+    }
     out.tris = std::move(allTris);
     out.wide = std::move(packed);
     out.instances = std::move(hInst);
@@ -1637,17 +1652,17 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     if (d.used)
         HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
     bool reallocated = false;
-    const size_t need[4] = { h.wide.size() * sizeof(WideNode), h.tris.size() * sizeof(TriIsect), h.instances.size() * sizeof(Instance),
-        h.lights.size() * sizeof(Light) };
-    const size_t total = need[0] + need[1] + need[2] + need[3];
-    if (d.wide.n < h.wide.size() || d.tris.n < h.tris.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1) || d.lights.n < std::max<size_t>(h.lights.size(), 1)
+    const size_t need[5] = { h.wide.size() * sizeof(WideNode), h.tris.size() * sizeof(TriIsect), h.instances.size() * sizeof(Instance),
+        h.lights.size() * sizeof(Light), h.fat.size() * sizeof(TriFat) };
+    const size_t total = need[0] + need[1] + need[2] + need[3] + need[4];
+    if (d.wide.n < h.wide.size() || d.tris.n < h.tris.size() || d.fat.n < h.fat.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1) || d.lights.n < std::max<size_t>(h.lights.size(), 1)
         || d.stageBytes < total) {
         // growing frees device memory, which the runtime only does once nothing uses it: wait for both streams (rare: the first
         // uploads, or a state with more world-space copies than any before)
         HIPCHK(c, hipStreamSynchronize(c->copyStream));
         if (d.used)
             HIPCHK(c, hipEventSynchronize(d.lastUse));
-        if ((rc = growTo(c, d.wide, h.wide.size(), &reallocated)) || (rc = growTo(c, d.tris, h.tris.size(), &reallocated))
+        if ((rc = growTo(c, d.wide, h.wide.size(), &reallocated)) || (rc = growTo(c, d.tris, h.tris.size(), &reallocated)) || (rc = growTo(c, d.fat, h.fat.size(), &reallocated))
             || (rc = growTo(c, d.instances, h.instances.size(), &reallocated)) || (rc = growTo(c, d.lights, h.lights.size(), &reallocated)))
             return rc;
         if (d.stageBytes < total) {
@@ -1661,9 +1676,9 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         HIPCHK(c, hipStreamSynchronize(c->copyStream)); // the staging memory of this set is about to be rewritten
     }
     unsigned char* st = (unsigned char*)d.stage;
-    const void* src[4] = { h.wide.data(), h.tris.data(), h.instances.data(), h.lights.data() };
-    void* dst[4] = { d.wide.p, d.tris.p, d.instances.p, d.lights.p };
-    for (int k = 0; k < 4; k++) {
+    const void* src[5] = { h.wide.data(), h.tris.data(), h.instances.data(), h.lights.data(), h.fat.data() };
+    void* dst[5] = { d.wide.p, d.tris.p, d.instances.p, d.lights.p, d.fat.p };
+    for (int k = 0; k < 5; k++) {
         if (need[k] == 0)
             continue;
         std::memcpy(st, src[k], need[k]);
@@ -1698,10 +1713,6 @@ int pt_frame_tick(pt_ctx* c)
     }
     next.used = true;
     HIPCHK(c, hipEventRecord(next.lastUse, c->stream));
-    if (c->vertsDirty) { // refitted geometry (pt_update_geometry): shading normals / texture coordinates, in stream order
-        HIPCHK(c, hipMemcpyAsync(c->verts.p, c->hostVerts.data(), c->hostVerts.size() * sizeof(VertexShade), hipMemcpyHostToDevice, c->stream));
-        c->vertsDirty = false;
-    }
     c->active = c->pending;
     c->pending = -1;
     c->haveDynamic = true;
