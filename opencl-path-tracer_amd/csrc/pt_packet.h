@@ -50,14 +50,28 @@ constexpr uint32_t kKeyNone = 0x7F800000u; // +inf: no lane sees the child
 #ifndef PT_PACKET_BEAM
 #define PT_PACKET_BEAM 1 // 1: packets whose rays all point into one octant test the child boxes against the BEAM (24 lanes, one plane each)
 #endif
-// butterfly reductions over the 64 lanes (ds_bpermute: the LDS crossbar, not the vector ALU's issue port); every lane gets the result
-__device__ inline float waveMin(float v)
+// min of a0, a1, a2 and max of b0, b1, b2 over the 64 lanes, six DPP steps each (row_shr 1 / 2 / 4 / 8 leave a row's result in its
+// lane 15 -- min and max do not mind an element counted twice --, row_bcast 15 / 31 carry it on to lane 63), the six chains
+// interleaved so that no step reads a register the previous instruction wrote (a DPP read needs two wait states after a vector
+// write).  36 vector instructions per packet; through ds_bpermute butterflies the same cost 36 LDS round trips and 108 instructions.
+#define PT_BEAM_STEP(m)                            \
+    "v_min_f32_dpp %0, %0, %0 " m "\n\t"           \
+    "v_min_f32_dpp %1, %1, %1 " m "\n\t"           \
+    "v_min_f32_dpp %2, %2, %2 " m "\n\t"           \
+    "v_max_f32_dpp %3, %3, %3 " m "\n\t"           \
+    "v_max_f32_dpp %4, %4, %4 " m "\n\t"           \
+    "v_max_f32_dpp %5, %5, %5 " m "\n\t"
+__device__ inline void waveMin3Max3(float& a0, float& a1, float& a2, float& b0, float& b1, float& b2)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fminf(v, __shfl_xor(v, m));
-    return v;
+    asm volatile("s_nop 1\n\t" PT_BEAM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") PT_BEAM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+            PT_BEAM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") PT_BEAM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                PT_BEAM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") PT_BEAM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
+    a0 = asF(__builtin_amdgcn_readlane(asU(a0), 63)), a1 = asF(__builtin_amdgcn_readlane(asU(a1), 63)), a2 = asF(__builtin_amdgcn_readlane(asU(a2), 63));
+    b0 = asF(__builtin_amdgcn_readlane(asU(b0), 63)), b1 = asF(__builtin_amdgcn_readlane(asU(b1), 63)), b2 = asF(__builtin_amdgcn_readlane(asU(b2), 63));
 }
+#undef PT_BEAM_STEP
+// butterfly reduction over the 64 lanes (ds_bpermute); every lane gets the result
 __device__ inline float waveMax(float v)
 {
 #pragma unroll
@@ -188,11 +202,10 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
             // the beam: per axis the interval of the origins and of |1 / direction| (signs are uniform)
             V3 oLo = co, oHi = co;
             if (__builtin_amdgcn_ballot_w64(co.x != asF(uni(asU(co.x))) || co.y != asF(uni(asU(co.y))) || co.z != asF(uni(asU(co.z)))) != 0ull) { // not a pinhole
-                oLo = mk(waveMin(co.x), waveMin(co.y), waveMin(co.z));
-                oHi = mk(waveMax(co.x), waveMax(co.y), waveMax(co.z));
+                waveMin3Max3(oLo.x, oLo.y, oLo.z, oHi.x, oHi.y, oHi.z);
             }
-            const V3 aid = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z));
-            const V3 mLo = mk(waveMin(aid.x), waveMin(aid.y), waveMin(aid.z)), mHi = mk(waveMax(aid.x), waveMax(aid.y), waveMax(aid.z));
+            V3 mLo = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z)), mHi = mLo;
+            waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z);
             const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
             const float oLoA = axis == 0u ? oLo.x : (axis == 1u ? oLo.y : oLo.z), oHiA = axis == 0u ? oHi.x : (axis == 1u ? oHi.y : oHi.z);
             const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
@@ -251,6 +264,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                 } else {
                     const uint32_t first = refIndex(cur), n = refCount(cur);
                     bool any = false;
+                    // (fetching triangle k + 1 while triangle k is tested was measured: +0.4 ms per batch -- scalar registers are short here)
                     for (uint32_t k = 0; k < n; k++) {
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
                         const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
