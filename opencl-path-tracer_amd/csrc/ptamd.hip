@@ -863,7 +863,11 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // k_shade: no k_gen launch (3.3 ms of a 121 ms batch, HBM-write-bound) and no read of 32 B per ray in a kernel that has
     // bandwidth to spare for the two stores instead.  (k_shade regenerating the rays as well, so that they are never stored,
     // was measured too: its 70 extra instructions per entry cost 2.3 ms per batch, more than the reads they replace.)
-    const bool packetsFirst = fp.interleave >= 16u && c->dyn[c->active].packetOk && (c->packetUse & 1u);
+    // The packet kernel serves the first pass when consecutive queue entries are >= 16 samples of one pixel.  (Packets of 8x8 pixel
+    // blocks -- what the default pixel order would give a 1-spp frame -- were measured too: the beam test handles them, but a
+    // 1280x720 frame is 14 k packets for 8 k persistent waves claiming 16 at a time: 2.2-2.4 ms per frame instead of 1.4-1.6.)
+    const bool coherentFirst = fp.interleave >= 16u;
+    const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
     prof.begin(0);
     if (fused)
@@ -874,7 +878,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
-        const bool coherent = b == 0 && fp.interleave >= 16u;
+        const bool coherent = b == 0 && coherentFirst;
         if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
         launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr);

@@ -17,6 +17,10 @@ for step in "$@"; do
     tests) timeout -k 10 1500 python -m pytest tests -m gpu -q -x --durations=15 > $out/pytest.log 2>&1; rc=$?; tail -5 $out/pytest.log ;;
     testsall) timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=15 > $out/pytest.log 2>&1; rc=$?; tail -15 $out/pytest.log ;;
     bench) timeout -k 10 420 python bench.py > $out/bench.json 2> $out/bench.err; rc=$?; head -c 700 $out/bench.json; echo; tail -3 $out/bench.err ;;
+    frame) timeout -k 10 300 python bench.py --mode frame > $out/frame.json 2> $out/frame.err; rc=$?; python3 -c "
+import json; d=json.load(open('$out/frame.json')); print({k: v['ms_per_frame'] for k, v in d['frame']['scenes'].items()})" ;;
+    vframe:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#vframe:}.so timeout -k 10 300 python bench.py --mode frame > $out/frame_${step#vframe:}.json 2> $out/frame_${step#vframe:}.err; rc=$?; python3 -c "
+import json; d=json.load(open('$out/frame_${step#vframe:}.json')); print('${step#vframe:}', {k: v['ms_per_frame'] for k, v in d['frame']['scenes'].items()})" ;;
     quick) timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 4 --warmup 1 --rounds 1 > $out/bench_quick.json 2> $out/bench_quick.err; rc=$?; head -c 400 $out/bench_quick.json; echo ;;
     pytest:*) timeout -k 10 900 python -m pytest ${step#pytest:} -m gpu -q -x > $out/pytest_sel.log 2>&1; rc=$?; tail -8 $out/pytest_sel.log ;;
     vtest:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#vtest:}.so timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py tests/test_gpu_fullsize.py -m gpu -q -x > $out/vtest_${step#vtest:}.log 2>&1; rc=$?; tail -5 $out/vtest_${step#vtest:}.log ;;
