@@ -708,6 +708,7 @@ struct ShadeArgs {
     uint4* streams; // parity mode
     // parity mode: un-compacted staging + active flags for the stable compaction pass
     uint32_t* activeFlag;
+    uint32_t firstTile; // first 512-entry tile this launch is responsible for
 };
 
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
@@ -748,14 +749,23 @@ __device__ inline void stQ(float4* p, float4 v)
 // covers the queue's capacity, while the queue of a later bounce holds 5-30 % of that: a workgroup whose tile lies beyond the
 // live entries leaves at once, before any ballot, LDS traffic or barrier.  (A grid sized to the machine with every workgroup
 // walking tiles in a loop was built too: the loop keeps the scene pointers live across iterations -- 128 instead of 96 VGPRs and
-// spills.)
-template <bool PARITY, bool GENERAL = false>
+// spills; used only for the later passes of a batch, where 75-99 % of the workgroups leave at once -- 0.6 ms of dispatch per launch --
+// it still loses: k_shade 26.8 instead of 25.75 ms per batch.)
+// LOOP = true: a small grid whose workgroups walk tiles from a.firstTile on (tile += gridDim.x) -- the safety net behind a launch that
+// covers only the head of the queue (ptamd.hip, launchShade).  Slower per entry than the one-tile kernel (128 VGPRs and spills: the
+// loop keeps the scene pointers live), so it is never the main path.
+template <bool PARITY, bool GENERAL = false, bool LOOP = false>
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
+    static_assert(!(PARITY && LOOP), "the parity kernel stages at the input slot: one tile per workgroup");
     const uint32_t count = *a.inCount;
-    if (blockIdx.x * kShadeBlock >= count) // uniform for the workgroup
+    uint32_t tile = a.firstTile + blockIdx.x;
+    if (tile * kShadeBlock >= count) // uniform for the workgroup
         return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t sCount[kShadeBlock / 64][4];
+    __shared__ uint32_t sBase[4];
+  do {
+    const uint32_t i = tile * kShadeBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     bool emitRay = false, emitShadow = false, shaded = false, deposited = false;
     ShadeResult r;
@@ -836,8 +846,6 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     // kShadeBlock entries) against waves idling at the two barriers: 1024 / 768 / 640 / 512 / 384 / 256 threads ->
     // 17.8 / 20.1 / 22.3 / 14.3 / 17.4 / 16.3 ms of k_shade per 128-sample batch at 1080p (256-thread blocks sit
     // exactly on the atomic rate: 1.36 M blocks per word in 16 ms = 85 atomics/us).
-    __shared__ uint32_t sCount[kShadeBlock / 64][4];
-    __shared__ uint32_t sBase[4];
     const unsigned long long mRay = __ballot(emitRay);
     const unsigned long long mSh = __ballot(emitShadow);
     const unsigned long long mHit = __ballot(shaded);
@@ -875,6 +883,11 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
         stQ(&a.shadow.d[idx], make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel)));
         stQ(&a.shadow.c[idx], make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(0u, 0u, plane))));
     }
+    if (!LOOP)
+        break;
+    __syncthreads(); // the counters in LDS are reused by the next tile
+    tile += gridDim.x;
+  } while (tile * kShadeBlock < count);
 }
 
 // Parity mode: stable (slot-ordered) compaction of the staged shade outputs -- the order the

@@ -124,6 +124,7 @@ struct pt_ctx {
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks = 0;
+    uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
     uint64_t packetLaunches = 0;
     float4* accum = nullptr;
@@ -747,6 +748,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #ifndef PT_FUSED_PRIMARY
 #define PT_FUSED_PRIMARY 1 // primary rays regenerated by the packet kernel and the first k_shade instead of queued by k_gen
 #endif
+#ifndef PT_SHADE_SPLIT
+#define PT_SHADE_SPLIT 1
+#endif
 #ifndef PT_PACKET_USE
 #define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
 #endif
@@ -839,10 +843,25 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     } else {
         a.out = c->rays[out].view();
         a.shadow = c->shadow.view();
+        // The queue of pass b holds what survived b bounces -- 23 / 6 / 1.3 % of the capacity on the benchmark scene -- but how much is a
+        // device word, and a million workgroups that leave at once cost 0.6 ms per launch to dispatch.  So pass b >= 1 launches the
+        // one-tile kernel over the first capacity / 2^b tiles only and, behind it, a 512-workgroup grid of the tile-walking kernel for
+        // whatever lies beyond (nothing, unless paths survive better than one in two per bounce: then that part runs ~10 % slower).
+        uint32_t head = blocks;
+        if (PT_SHADE_SPLIT && pass > 0)
+            head = std::max(1u, blocks >> std::min(pass + c->shadeHeadShift, 24u));
         if (generalShading(c))
-            hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+            hipLaunchKernelGGL((k_shade<false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
         else
-            hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(kShadeBlock), 0, c->stream, a);
+            hipLaunchKernelGGL((k_shade<false, false>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
+        if (head < blocks) {
+            a.firstTile = head;
+            const uint32_t rest = std::min(blocks - head, 512u);
+            if (generalShading(c))
+                hipLaunchKernelGGL((k_shade<false, true, true>), dim3(rest), dim3(kShadeBlock), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL((k_shade<false, false, true>), dim3(rest), dim3(kShadeBlock), 0, c->stream, a);
+        }
     }
 }
 
@@ -1000,6 +1019,8 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     c->packetUse = (cfg->flags & PT_FLAG_NO_PACKETS) ? 0u : kPacketUseDefault;
     if (cfg->flags & PT_FLAG_PACKET_INTERSECT)
         c->packetUse |= 4u;
+    if (const char* hs = getenv("PTAMD_SHADE_HEAD_SHIFT"))
+        c->shadeHeadShift = (uint32_t)std::max(0, atoi(hs));
     if (const char* pk = getenv("PTAMD_PACKET")) // diagnostics: which launches may use k_trace_packet (bit 0 primary, 1 shadow, 2 pt_intersect)
         c->packetUse = (uint32_t)atoi(pk);
     c->device = cfg->device;

@@ -315,3 +315,23 @@ def test_dynamic_scene_reupload_matches_a_fresh_context(gpu, two_level):
     assert info["n"] > 3000 and info["flips"] == 0
     ctx.close()
     fresh.close()
+
+
+def test_later_shade_passes_beyond_the_head_launch(gpu, monkeypatch):
+    """From the second bounce on k_shade is launched over the head of the queue only (capacity / 2^bounce tiles) with a small
+    tile-walking grid behind it for whatever lies beyond.  Here the head is shrunk to a sliver so that nearly every entry of
+    the later passes goes through the tile-walking kernel: images and ray counts must not change by a bit."""
+    b = scenes.cornell_box(96, 64)
+    def run():
+        ctx = U.make_ctx(gpu, b, 96, 64, seed=5, samples_in_flight=64)
+        ctx.render(128)
+        img, st = ctx.read_accum(), ctx.stats()
+        ctx.close()
+        return img, st
+    ref_img, ref_st = run()
+    monkeypatch.setenv("PTAMD_SHADE_HEAD_SHIFT", "9")
+    img, st = run()
+    assert np.array_equal(img, ref_img)
+    for k in ("rays_extension", "rays_shadow", "shade_hits", "deposits"):
+        assert st[k] == ref_st[k], k
+    assert ref_st["rays_extension"] > 2 * 96 * 64 * 128
