@@ -21,7 +21,7 @@ mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mi
 def table(name):
     out = {}
     for line in open(f"{src}/pmc_{name}.txt"):
-        line = line.replace("k_shade<false, false>", "k_shade<false>")  # the production instantiation (not the general integrator kernel)
+        line = line.replace("k_shade<false, false, false>", "k_shade<false>").replace("k_shade<false, false>", "k_shade<false>")  # the production instantiation (one tile per workgroup); k_shade<false, false, true> is the tile-walking safety net  # the production instantiation (not the general integrator kernel)
         m = re.match(r"(?:void )?ptd::(\S+)\s+(\S+)\s+(\d+)\s+per-dispatch\s+(\d+)\s+\((\d+) dispatches\)", line)
         if m:
             out.setdefault(m.group(1), {})[m.group(2)] = (float(m.group(3)), int(m.group(5)))
