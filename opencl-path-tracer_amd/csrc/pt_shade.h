@@ -324,7 +324,7 @@ __device__ inline int pickWeightedLight(const SceneDev& sc, V3 X, Rng& rng, floa
 // what is kept and what is fixed of the reference's MIS code: oracle/oracle.cpp, neeShading) and weighted light choice
 template <bool GENERAL>
 __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u, float v, uint32_t prim, uint32_t instIdx,
-    V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out, const ShadeOpts& opt)
+    V3 throughput, uint32_t inFlags, Rng& rng, ShadeResult& out, const ShadeOpts& opt, float* park = nullptr, uint32_t parkStride = 0)
 {
     const bool MIS = GENERAL && opt.mis;
     const TriFat* fp = &sc.triFat[prim];
@@ -430,10 +430,17 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
             else
                 Ld = (float)sc.numLights * lightColour * BRDF * solidAngle * dot(shadingNormal, L);
             out.shadowFlags = 0;
-            out.shadowContribution = Ld * throughput;
-            out.shadowOrigin = X + L * kEPS;
-            out.shadowDirection = L;
-            out.shadowLength = dist - 2 * kEPS;
+            if (park) { // the shadow ray waits in LDS for the workgroup's compaction: ten registers less while the continuation is sampled
+                const V3 sc_ = Ld * throughput, so_ = X + L * kEPS;
+                park[0 * parkStride] = so_.x, park[1 * parkStride] = so_.y, park[2 * parkStride] = so_.z, park[3 * parkStride] = dist - 2 * kEPS;
+                park[4 * parkStride] = L.x, park[5 * parkStride] = L.y, park[6 * parkStride] = L.z;
+                park[7 * parkStride] = sc_.x, park[8 * parkStride] = sc_.y, park[9 * parkStride] = sc_.z;
+            } else {
+                out.shadowContribution = Ld * throughput;
+                out.shadowOrigin = X + L * kEPS;
+                out.shadowDirection = L;
+                out.shadowLength = dist - 2 * kEPS;
+            }
         }
     }
 
@@ -717,9 +724,13 @@ struct ShadeArgs {
 #define PT_SHADE_BLOCK 512
 #endif
 #ifndef PT_SHADE_MIN_WAVES
-#define PT_SHADE_MIN_WAVES 4
-#endif
+#define PT_SHADE_MIN_WAVES 6 // waves per SIMD of the production instantiation: 3 workgroups of 512 per CU need <= 80 VGPRs -- 94 before the shadow
+#endif                       // ray of an entry was parked in LDS (33 spilled at 80, 35.5 vs 27.1 ms); 80 with 2 spilled after: k_shade 24.9 -> 23.0 ms.
+                             // The general (MIS / COMPARE_SHADING) and parity instantiations stay at 4 waves (102-110 VGPRs)
 constexpr int kShadeBlock = PT_SHADE_BLOCK;
+#ifndef PT_SHADE_PARK
+#define PT_SHADE_PARK 1 // 1: the shadow ray of an entry waits in LDS (10 dwords per thread) instead of registers while the continuation is sampled
+#endif
 #ifndef PT_SHADE_NT
 #define PT_SHADE_NT 1 // 1: queue entries are read / written with non-temporal accesses (streamed once: no reason to keep them in L2 next to the scene)
 #endif
@@ -755,7 +766,7 @@ __device__ inline void stQ(float4* p, float4 v)
 // covers only the head of the queue (ptamd.hip, launchShade).  Slower per entry than the one-tile kernel (128 VGPRs and spills: the
 // loop keeps the scene pointers live), so it is never the main path.
 template <bool PARITY, bool GENERAL = false, bool LOOP = false>
-__global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
+__global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 : PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
     static_assert(!(PARITY && LOOP), "the parity kernel stages at the input slot: one tile per workgroup");
     const uint32_t count = *a.inCount;
@@ -767,6 +778,9 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
   do {
     const uint32_t i = tile * kShadeBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+#if PT_SHADE_PARK
+    __shared__ float sPark[PARITY ? 1 : 10][PARITY ? 1 : kShadeBlock];
+#endif
     bool emitRay = false, emitShadow = false, shaded = false, deposited = false;
     ShadeResult r;
     uint32_t pixel = 0, bounce = 0, plane = 0;
@@ -797,7 +811,12 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
                     opt.rayOrigin = o;
                     opt.inPdf = thr.w; // 0 for primary rays (they carry LASTSPECULAR: never consulted)
                 }
+#if PT_SHADE_PARK
+                shadeHit<GENERAL>(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r, opt,
+                    PARITY ? nullptr : &sPark[0][threadIdx.x], PARITY ? 0u : (uint32_t)kShadeBlock);
+#else
                 shadeHit<GENERAL>(a.sc, X, normalize(d), h.x, h.y, h.z, (uint32_t)prim, (uint32_t)a.hits.inst[i], throughput, fb & 0xFFu, rng, r, opt);
+#endif
                 if (PARITY)
                     rngLfsrStore(a.streams, i, rng);
                 if (r.radiance.x != 0.f || r.radiance.y != 0.f || r.radiance.z != 0.f) {
@@ -879,9 +898,17 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_MIN_WAVES) k_shade(Shade
     }
     if (emitShadow) {
         const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);
+#if PT_SHADE_PARK
+        const float* pk = &sPark[0][PARITY ? 0 : threadIdx.x];
+        constexpr uint32_t S = PARITY ? 0 : kShadeBlock;
+        stQ(&a.shadow.o[idx], make_float4(pk[0 * S], pk[1 * S], pk[2 * S], pk[3 * S]));
+        stQ(&a.shadow.d[idx], make_float4(pk[4 * S], pk[5 * S], pk[6 * S], asF(pixel)));
+        stQ(&a.shadow.c[idx], make_float4(pk[7 * S], pk[8 * S], pk[9 * S], asF(packState(0u, 0u, plane))));
+#else
         stQ(&a.shadow.o[idx], make_float4(r.shadowOrigin.x, r.shadowOrigin.y, r.shadowOrigin.z, r.shadowLength));
         stQ(&a.shadow.d[idx], make_float4(r.shadowDirection.x, r.shadowDirection.y, r.shadowDirection.z, asF(pixel)));
         stQ(&a.shadow.c[idx], make_float4(r.shadowContribution.x, r.shadowContribution.y, r.shadowContribution.z, asF(packState(0u, 0u, plane))));
+#endif
     }
     if (!LOOP)
         break;
