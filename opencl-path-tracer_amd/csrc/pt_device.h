@@ -71,7 +71,7 @@ struct VertexShade { // 32 B
     float4 n_u; // normal.xyz, texCoord.x
     float4 v_pad; // texCoord.y
 };
-// Triangle for shading: everything k_shade needs of a hit triangle in ONE 128-byte line (caller's triangle numbering, object space).
+// Triangle for shading: everything k_shade needs of a hit triangle -- its material included -- in ONE 128-byte line (caller's triangle numbering, object space).
 // The indexed layout it replaces cost an incoherent hit five scattered lines and a dependent fetch (16 B of vertex indices + material,
 // three 32-byte vertex records through them, the 48-byte intersection record for the geometric normal): from the second bounce on
 // k_shade fetched more scene data than queue entries (20 GB against 14 GB for 4.4 x fewer entries, FETCH_SIZE per dispatch).
@@ -80,8 +80,8 @@ struct TriFat {
     float4 vvvm; // texCoord.y of the three vertices, bits(material)
     float4 e1e; // edge1.xyz, edge2.x          (v0 / edge1 / edge2 exactly as in TriIsect)
     float4 e2v; // edge2.yz, v0.xy
-    float4 v0z; // v0.z, -, -, -
-    float4 _pad;
+    float4 v0c; // v0.z, material colour.xyz                  } the triangle's material record (48 B in the caller's array, 28 B of it
+    float4 mat; // material params.xyz, bits(material type)   } used): no second, dependent fetch through the material index
 };
 
 // instance (64 B): rows of the 3x4 inverse world transform + root reference of the mesh BVH

@@ -187,16 +187,16 @@ struct MatView {
     bool metallic;
     int type;
 };
-__device__ inline MatView loadMaterial(const SceneDev& sc, uint32_t index)
+// the material as TriFat carries it: (.., colour.xyz) and (params.xyz, bits(type)) of the caller's 48-byte record
+__device__ inline MatView loadMaterial(float4 v0c, float4 mat)
 {
-    const Material m = sc.materials[index];
     MatView v;
-    v.colour = xyz(m.colour);
-    v.p0 = m.params.x;
-    v.p1 = m.params.y;
-    v.texId = (int)asU(m.params.x);
-    v.metallic = (asU(m.params.z) & 0xFFu) != 0u;
-    v.type = (int)asU(m.typeAndPad.x);
+    v.colour = mk(v0c.y, v0c.z, v0c.w);
+    v.p0 = mat.x;
+    v.p1 = mat.y;
+    v.texId = (int)asU(mat.x);
+    v.metallic = (asU(mat.z) & 0xFFu) != 0u;
+    v.type = (int)asU(mat.w);
     return v;
 }
 __device__ inline V3 pbrF0(const MatView& m) { return m.metallic ? m.colour : mk(m.p1); }
@@ -328,7 +328,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
 {
     const bool MIS = GENERAL && opt.mis;
     const TriFat* fp = &sc.triFat[prim];
-    const float4 f0 = fp->n0u, f1 = fp->n1u, f2 = fp->n2u, f3 = fp->vvvm, f4 = fp->e1e, f5 = fp->e2v;
+    const float4 f0 = fp->n0u, f1 = fp->n1u, f2 = fp->n2u, f3 = fp->vvvm, f4 = fp->e1e, f5 = fp->e2v, f6 = fp->v0c, f7 = fp->mat;
     const V3 edge1 = xyz(f4), edge2 = mk(f4.w, f5.x, f5.y);
     const Instance in = sc.instances[instIdx];
     const V3 realNormal = normalize(normalTransform(in, cross(edge1, edge2)));
@@ -337,7 +337,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
     V3 raySideNormal = shadingNormal;
     if (dot(raySideNormal, -D) < 0.0f)
         raySideNormal = raySideNormal * -1.0f;
-    const MatView mat = loadMaterial(sc, asU(f3.w));
+    const MatView mat = loadMaterial(f6, f7);
     out.radiance = mk(0.0f);
     out.flags = 0;
     out.pdf = 0.f;
@@ -348,7 +348,7 @@ __device__ inline void shadeHit(const SceneDev& sc, V3 X, V3 D, float t, float u
         if (inFlags & FLAG_LASTSPECULAR) {
             out.radiance = throughput * mat.colour;
         } else if (MIS) { // shading.cl:69-90: a BSDF-sampled direction found the light: balance heuristic against NEE's density
-            const V3 v0 = mk(f5.z, f5.w, fp->v0z.x), v1 = v0 + edge1, v2 = v0 + edge2; // object space, as the reference
+            const V3 v0 = mk(f5.z, f5.w, f6.x), v1 = v0 + edge1, v2 = v0 + edge2; // object space, as the reference
             const V3 A = v1 - v0, B = v2 - v1, C = v0 - v2;
             const float la = sqrtf(dot(A, A)), lb = sqrtf(dot(B, B)), lc = sqrtf(dot(C, C));
             const float hs = (la + lb + lc) / 2.0f;

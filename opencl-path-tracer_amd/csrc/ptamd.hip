@@ -1625,8 +1625,10 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
         f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
         f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
-        f.v0z = make_float4(ti.a.z, 0.f, 0.f, 0.f);
-        f._pad = make_float4(0.f, 0.f, 0.f, 0.f);
+        float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
+        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
+        f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
+        f.mat = make_float4(m[4], m[5], m[6], m[8]);
         out.fat[t] = f;
     }
     out.tris = std::move(allTris);
