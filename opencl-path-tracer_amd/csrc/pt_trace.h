@@ -397,6 +397,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
+#ifdef PT_TRACE_STATS
+                bool statInside = false;
+#endif
                 if (wantInner) {
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
@@ -430,6 +433,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                     const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
                     float key[4];
                     uint32_t ref[4] = { D.x, D.y, D.z, D.w };
+#ifdef PT_TRACE_STATS
+                    bool inside = false;
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
@@ -442,7 +448,14 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         // accept test of bvh.cl:72,114 on the (slightly larger) quantised box
                         const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tClosest;
                         key[k] = vis ? tmin : INFINITY;
+#ifdef PT_TRACE_STATS
+                        inside = inside || (vis && tmin <= 0.f); // the ray starts inside this child's box
+#endif
                     }
+#ifdef PT_TRACE_STATS
+                    // [18] lane-steps whose node has a child that contains the ray's origin ("re-finding the surface the ray starts on")
+                    statInside = inside;
+#endif
 #define PT_VISIBLE(k) (key[k] < INFINITY ? 1 : 0)
                     // sort the four (entry distance, reference) pairs: nearest first (5-comparator network)
 #define PT_CSWAP(i, j)                                   \
@@ -496,6 +509,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         cur = next, sp = max(sp - 1, 0);
 #undef PT_VISIBLE
                 }
+#ifdef PT_TRACE_STATS
+                PT_STAT(18, __popcll(__ballot(statInside)));
+#endif
                 PT_TOC(11, tInner);
             } else {
                 PT_STAT(3, 1);

@@ -18,6 +18,8 @@ def report(tag, s, nrays):
         return
     print(f"{tag:12s} rays {nrays:8d} wave-iters/ray*64 {it*64/max(nrays,1):6.1f}  active/iter {act/max(it,1):5.1f}  iters inner/leaf/special {ki/it:.2f}/{kl/it:.2f}/{ks/it:.2f} "
           f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
+    if s[18]:
+        print(f"             inner lane-steps at a node one of whose children contains the ray origin: {s[18] / max(li, 1):.3f} of all inner lane-steps")
     if s[16]:
         print(f"             triangles tested per ray {s[16]/max(nrays,1):5.2f} (lane-level count / 64 lanes: {s[16]} per-wave loops)")
     tot, tin, tle, tsp, tha = s[10], s[11], s[12], s[13], s[14]
