@@ -3,15 +3,17 @@
 // k_gen hands consecutive queue entries the samples of one pixel (pt_shade.h), so the 64 primary rays of a wave are
 // almost the same ray, and the shadow rays their hits spawn leave from one spot.  k_trace (pt_trace.h) would walk
 // them in lock-step anyway but pays for 64 private traversals: a per-lane stack, a per-lane sort of the children, a
-// vote per iteration.  Here the traversal state is wave-uniform:
-//   * the current node reference lives in an SGPR, the node's origin / exponents / child references arrive through
-//     the scalar cache (one s_load instead of 64 lanes x 4 vector loads);
-//   * the stack is three VGPRs: entry e is LANE e of them (v_writelane / v_readlane): the child reference and the
-//     64-bit mask of lanes whose ray saw that child's box;
-//   * a lane only takes part in a node or leaf whose box its own ray passed, with the same accept test and the same
-//     arithmetic as k_trace, so every ray tests exactly the boxes and triangles it would test there (the order can
-//     differ, which matters for exact-t ties only);
-//   * the nearest child (entry distance of the first lane that sees it) is descended into, the others are pushed.
+// vote per iteration.  Here the traversal state is wave-uniform -- the current node reference lives in an SGPR, the stack is
+// LANES of a VGPR (entry e is lane e: v_writelane / v_readlane), the nearest child is picked by a scalar tournament -- and there
+// are two ways to test a node:
+//   * BEAM (closest hit; full packets whose rays all point into one octant -- the primary rays): the node against the interval
+//     bundle that holds all 64 rays, the 24 planes of its four children on 24 lanes, one bound each, axes folded by two DPP steps:
+//     ~21 vector instructions per node.  Conservative: a box no ray enters may pass, never the reverse; every ray tests the
+//     triangles of every leaf the packet visits, with k_trace's arithmetic.
+//   * PER LANE (any-hit packets, ragged or mixed-octant ones): every lane tests the four child boxes for its own ray (~85
+//     instructions per node) and only takes part in a node or leaf whose box its ray passed (64-bit lane masks ride on the stack
+//     entries): per ray exactly the boxes and triangles it would test in k_trace.
+// In both the order of traversal can differ from k_trace's, which matters for exact-t ties only.
 // Correct for any 64 rays; fast when they are coherent.  Used for the first pass of the fixed schedule when the
 // scene is one world-space tree (every instance copied at upload, ptamd.hip) whose worst-case stack fits 64 entries.
 //
