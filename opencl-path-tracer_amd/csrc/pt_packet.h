@@ -191,6 +191,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         // may pass -- its triangles are then tested and missed), never the other way: intervals only widen, and the multipliers carry a
         // relative slack of 2^-18 against round-off.  Triangle tests are per ray, unchanged.  Packets that are not full, contain
         // finished rays or straddle a sign change of a direction component take the per-ray path below.
+#ifdef PT_TRACE_STATS
+        uint32_t statNodes = 0u, statLeaves = 0u; // wave-uniform: per-lane path of this packet
+#endif
         bool viaBeam = false;
 #if PT_PACKET_BEAM
         if (!ANY_HIT) {
@@ -308,6 +311,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
             while (true) {
                 const bool here = __builtin_amdgcn_inverse_ballot_w64(curMask) && (!ANY_HIT || active);
                 if (refCount(cur) == 0u) {
+#ifdef PT_TRACE_STATS
+                    statNodes++;
+#endif
                     // -------- inner node: four quantised child boxes (scene.cl:197-231 / bvh.cl:76-115) ----------
                     const uint32_t ni = refIndex(cur);
                     const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u]; // scalar: origin + exponents, child references
@@ -366,6 +372,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                 } else {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = refCount(cur);
+#ifdef PT_TRACE_STATS
+                    statLeaves++;
+#endif
                     for (uint32_t k = 0; k < n; k++) {
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
                         const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
@@ -404,6 +413,12 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
             }
 
         }
+#ifdef PT_TRACE_STATS
+        if (ANY_HIT && lane == 0) { // histogram of what a shadow packet touches: [0..23] leaves, [24..47] nodes / 4
+            atomicAdd(&g_traceStats[min(statLeaves, 23u)], 1ull);
+            atomicAdd(&g_traceStats[24u + min(statNodes / 4u, 23u)], 1ull);
+        }
+#endif
         // -------- results: consecutive lanes write consecutive records (scene.cl:257) --------------------------
         if (ANY_HIT) {
             const uint32_t nDep = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));
