@@ -17,6 +17,16 @@ device queues.
 35.6-56.8 ms per 1-spp 1280x720 frame, src/main.cpp:106-119): RayTracer::rayTrace = one sample per pixel + the
 accumulate kernel, on the 82k-triangle mesh in the five-wall room.
 
+`--gpus N` without WORLD_SIZE in the environment starts the N ranks itself (fresh child processes through
+torch.distributed.run, before this process has touched the GPU) and relays rank 0's line; under torchrun it is a rank.
+`--scaling strong` fixes the job instead of the per-rank load: `in_flight x rounds` samples per pixel of the WHOLE image per
+step whatever N is, every rank tracing its 1/N of the pixels (time-to-image; the line says which mode ran).
+
+Secondary objects of the N = 1 line (each its own short measurement on the same box, none inside the timed region of `value`):
+`two_level` -- the same scene with every instance ENTERED instead of copied to world space (PT_FLAG_NO_BAKED_INSTANCES; and with
+only the single-leaf meshes copied, PT_FLAG_TWO_LEVEL_ONLY), `dynamic` -- host and device time of one pt_upload_dynamic_async
+per frame tick, `configs` -- BASELINE configs 2, 3 and 5 on this GPU, `frame` -- the 1-spp interactive frame.
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the render stream in a separate,
 profiled pass, for every kernel of the path (`roofline.kernels`); its top-level fields are those of the kernel
 with the largest share of device time (k_trace<true>, the any-hit traversal of the shadow rays);
@@ -96,8 +106,9 @@ def reference_kernels_baseline(O, sc, bundle, width, height, seconds=3.0):
 
 
 def cpu_baseline(bundle, seconds, width, height):
-    """Oracle (kind 'port') on all host cores: 1 spp over 8x8 pixel blocks spread over the frame,
-    extended block by block until `seconds` of wall time are used."""
+    """Oracle (kind 'port') on all host cores: 1 spp over 8x8 pixel blocks spread over the frame.  One warm-up pass (page-in, thread
+    pool, the rate estimate that sizes the chunks) is excluded; then `seconds` of wall time in three equal segments of equally sized
+    chunks, whose rates give the spread stated next to the value."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orclib as O  # checker / reported baseline only
     O.build(fast=True, ref=False)  # -O3 -march=native for THIS host
@@ -106,33 +117,47 @@ def cpu_baseline(bundle, seconds, width, height):
     bx, by = width // 8, height // 8
     order = np.random.default_rng(0).permutation(bx * by)
     yy, xx = np.mgrid[0:8, 0:8]
-    rays, pixels_done, t_used, chunk, pos, sample = 0, 0, 0.0, 256, 0, 0
+    state = {"pos": 0, "sample": 0}
     work = {"innerSteps": 0, "triangleTests": 0, "topVisits": 0}  # reference-layout traversal work (SURVEY 8d, L2-level model)
-    while t_used < seconds:
-        if pos >= len(order):  # the whole frame is done: next sample index
-            pos, sample = 0, sample + 1
-        blocks = order[pos:pos + chunk]
-        pos += len(blocks)
+
+    def run(nblocks, count_work=True):
+        if state["pos"] + nblocks > len(order):  # the whole frame is done: next sample index
+            state["pos"], state["sample"] = 0, state["sample"] + 1
+        blocks = order[state["pos"]:state["pos"] + nblocks]
+        state["pos"] += len(blocks)
         px = (((blocks // bx)[:, None, None] * 8 + yy) * width + (blocks % bx)[:, None, None] * 8 + xx).reshape(-1)
         t0 = time.perf_counter()
-        _, cnt = O.render(sc, bundle.camera, width, height, 1, seed=1, first_sample=sample, pixels=px.astype(np.uint32),
+        _, cnt = O.render(sc, bundle.camera, width, height, 1, seed=1, first_sample=state["sample"], pixels=px.astype(np.uint32),
                           threads=cores, fast=True)
-        t_used += time.perf_counter() - t0
-        rays += cnt["raysExtension"] + cnt["raysShadow"]
-        for k in work:
-            work[k] += cnt[k]
-        pixels_done += len(px)
-        chunk = min(chunk * 2, 8192)
+        dt = time.perf_counter() - t0
+        if count_work:
+            for k in work:
+                work[k] += cnt[k]
+        return cnt["raysExtension"] + cnt["raysShadow"], len(px), dt
+
+    rays_w, _, dt_w = run(1024, count_work=False)  # warm-up, excluded
+    chunk = int(min(8192, max(256, 1024 * 0.5 / max(dt_w, 1e-3))))  # ~0.5 s of work per call
+    segments, rays, pixels_done, t_used = [], 0, 0, 0.0
+    for _ in range(3):
+        r_seg, t_seg = 0, 0.0
+        while t_seg < seconds / 3.0:
+            r, npx, dt = run(chunk)
+            r_seg, t_seg, pixels_done = r_seg + r, t_seg + dt, pixels_done + npx
+        segments.append(r_seg / t_seg / 1e6)
+        rays, t_used = rays + r_seg, t_used + t_seg
     ref = None
     try:  # the reference's own kernels, compiled for the host and run one work-item at a time (oracle/_ref): 1 core
         ref = reference_kernels_baseline(O, sc, bundle, width, height)
     except Exception as e:  # never let the secondary figure take the bench down
         ref = {"error": str(e)[:200]}
-    return {"value": round(rays / t_used / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    value = rays / t_used / 1e6
+    return {"value": round(value, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "segments_mrays_per_s": [round(x, 3) for x in segments],
+            "spread": round((max(segments) - min(segments)) / value, 4),
             "reference_kernels": ref,
             "per_ray": {k: round(work[k] / max(rays, 1), 2) for k in ("innerSteps", "triangleTests", "topVisits")},
-            "sample": f"{pixels_done} pixel-samples (random 8x8 blocks of the {width}x{height} frame, 1 spp each pass), "
-                      f"{rays} rays in {t_used:.1f} s, oracle -O3 -march=native, {cores} threads"}
+            "sample": f"{pixels_done} pixel-samples (random 8x8 blocks of the {width}x{height} frame, 1 spp each pass; one warm-up pass of "
+                      f"65 536 pixel-samples excluded), {rays} rays in {t_used:.1f} s (three segments), oracle -O3 -march=native, {cores} threads"}
 
 
 def plan_in_flight(requested, world, owned_pixels, max_entries=MAX_ENTRIES):
@@ -199,6 +224,121 @@ def frame_times(D, H, scenes, L, device, frames, width=1280, height=720):
             "scenes": out, "reference_published_ms_per_frame": "35.6 - 56.8 (images/*.png overlays, hardware not stated; BASELINE.md 1a)"}
 
 
+def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=1, rounds=1, what=""):
+    """Throughput of one scene / flag set on this GPU, the way the headline is measured (warm-up, clear, K steps between two
+    synchronisations), plus the per-kernel-family device times of one extra, profiled step.  Its own context, closed before it returns."""
+    ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=in_flight, flags=flags)
+    try:
+        t0 = time.perf_counter()
+        ctx.upload_scene(bundle.flat, sky=bundle.sky, material_textures=bundle.material_textures)
+        ctx.synchronize()
+        upload_s = time.perf_counter() - t0
+        ctx.set_camera(bundle.camera)
+        spp = in_flight * rounds
+        for _ in range(warmup):
+            ctx.render(spp, sync=False)
+        ctx.synchronize()
+        ctx.clear()
+        ctx.reset_stats()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.render(spp, sync=False)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        rays = st["rays_extension"] + st["rays_shadow"]
+        ctx.reset_stats()
+        ctx.profile_kernels(True)
+        ctx.render(spp, sync=True)
+        ps = ctx.stats()
+        ctx.profile_kernels(False)
+        pr = ps["rays_extension"] + ps["rays_shadow"]
+        out = {"what": what, "mrays_per_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+               "spp_per_step": spp, "samples_in_flight": in_flight, "rays_per_step": int(rays / steps),
+               "rays_per_primary": round(rays / max(st["rays_generated"], 1), 3),
+               "packet_kernel_for_primary_rays": ps["packet_launches"] > 0, "scene_upload_s": round(upload_s, 3),
+               "kernel_ms_per_step": {"gen": round(ps["ms_gen"], 2), "closest_hit": round(ps["ms_intersect"], 2),
+                                      "of_which_packet": round(ps["ms_packet"], 2), "shade": round(ps["ms_shade"], 2),
+                                      "any_hit": round(ps["ms_shadow"], 2)},
+               "shade_ns_per_entry": round(ps["ms_shade"] * 1e6 / max(ps["shade_hits"], 1), 3),
+               "mrays_per_s_profiled_step": round(pr / max(ps["ms_last_render"], 1e-6) / 1e3, 1)}
+        return out
+    finally:
+        ctx.close()
+
+
+def dynamic_update_times(D, bundle, W, Hh, device, ticks=12):
+    """RayTracer::frameTick's cost (src/raytracer.cpp:183-189,497-595): per tick the host time pt_upload_dynamic_async blocks the
+    calling thread and the time until the upload's event has fired on the copy stream (pt_frame_tick + a synchronisation, nothing
+    rendering meanwhile), for the benchmark scene with every instance moved a little each tick; baked (the default: instances
+    are copied to world space) and two-level (PT_FLAG_NO_BAKED_INSTANCES).  The reference refits and re-uploads its dynamic data in
+    4-6 ms per frame (lab report)."""
+    out = {}
+    flat = bundle.flat
+    for name, flags in (("baked", 0), ("two_level", D.FLAG_NO_BAKED_INSTANCES)):
+        ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=1, flags=flags)
+        try:
+            ctx.upload_scene(flat, sky=None)
+            ctx.set_camera(bundle.camera)
+            ctx.render(1)
+            host_ms, total_ms = [], []
+            for k in range(ticks + 2):
+                t0 = time.perf_counter()
+                ctx.upload_dynamic_async(flat)
+                t1 = time.perf_counter()
+                ctx.frame_tick()
+                ctx.synchronize()
+                t2 = time.perf_counter()
+                if k >= 2:  # the first two ticks size the two buffer sets
+                    host_ms.append((t1 - t0) * 1e3)
+                    total_ms.append((t2 - t0) * 1e3)
+            out[name] = {"host_ms_per_upload": round(float(np.median(host_ms)), 3), "ms_until_adopted": round(float(np.median(total_ms)), 3),
+                         "host_ms_min_max": [round(min(host_ms), 3), round(max(host_ms), 3)]}
+        finally:
+            ctx.close()
+    out["what"] = (f"median over {ticks} ticks of pt_upload_dynamic_async (host time) and upload + pt_frame_tick + synchronise (until adopted), "
+                   f"{len(flat.top_nodes)} top-level nodes, {flat.instanced_triangles} instanced triangles")
+    out["reference_ms_per_frame"] = "4 - 6 (refit + dynamic upload, lab report; hardware not stated)"
+    return out
+
+
+def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
+    """The N = 1 line's secondary objects.  Every entry is guarded: a failure is reported in place and never takes the headline down."""
+    W, Hh = args.width, args.height
+    out = {}
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:
+            out[key] = {"error": str(e)[:300]}
+
+    guarded("two_level", lambda: {
+        "every_instance_entered": measure_scene(D, bundle, W, Hh, device, in_flight, flags=D.FLAG_NO_BAKED_INSTANCES,
+                                                what="PT_FLAG_NO_BAKED_INSTANCES: all 14 instances (12 meshes, ground quad, light quad) are entered "
+                                                     "(scene.cl:116-139), nothing is copied to world space"),
+        "single_leaf_meshes_copied": measure_scene(D, bundle, W, Hh, device, in_flight, flags=D.FLAG_TWO_LEVEL_ONLY,
+                                                   what="PT_FLAG_TWO_LEVEL_ONLY: the 12 mesh instances are entered; the two quads (single-leaf meshes) "
+                                                        "hang off the top level as world-space leaves"),
+        "instances_copied_to_world_space": measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, what="the headline's configuration, measured the same way")})
+    guarded("dynamic", lambda: dynamic_update_times(D, bundle, W, Hh, device))
+
+    def configs():
+        c = {}
+        room = scenes.blob_room(W, Hh, level=args.level, builder=H.BVH_BINNED_SAH)
+        c["config2"] = measure_scene(D, room, W, Hh, device, in_flight, what="configs[1]: 81 920-triangle mesh (binned SAH), diffuse, five-wall room + area light, 1080p")
+        glass = scenes.blob_room(W, Hh, level=args.level, builder=H.BVH_SPATIAL_SPLIT, material=L.material_refractive(0.9, 1.5, (1.0, 0.6, 0.6), 5.0))
+        c["config3"] = measure_scene(D, glass, W, Hh, device, in_flight, what="configs[2]: the same mesh as rough glass (SBVH), NEE towards the area light, 1080p")
+        W4, H4 = 2 * W, 2 * Hh
+        big = scenes.instanced_grid(W4, H4, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT, thin_lens=True)
+        n4 = plan_in_flight(args.in_flight, 1, W4 * H4, args.max_entries)
+        c["config5_one_gpu"] = measure_scene(D, big, W4, H4, device, n4, steps=2, what=f"configs[4] on ONE GPU: the headline scene at {W4}x{H4}, thin lens f/2")
+        return c
+    guarded("configs", configs)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +350,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--level", type=int, default=6, help="icosphere subdivision of the instanced mesh (6 = 81 920 tris)")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--cpu-seconds", type=float, default=9.0, help="wall time of the CPU baseline's timed part (a warm-up pass comes on top)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1-spp 720p frame-time figure")
@@ -218,14 +358,32 @@ def main():
     ap.add_argument("--mode", default="throughput", choices=["throughput", "frame"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: in_flight x N samples in flight per rank on 1/N of the pixels (per-rank load fixed); strong: in_flight x rounds "
+                         "samples per pixel of the whole image per step whatever N is (job fixed)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the two_level / dynamic / configs objects of the N = 1 line")
+    ap.add_argument("--flags", type=int, default=0, help="pt_config.flags of the render context (2 = PT_FLAG_NO_BAKED_INSTANCES: two-level traversal)")
     ap.add_argument("--dump-accum", default=None, help="rank 0 saves the (reduced) HDR accumulator as .npy (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: start the ranks ourselves, as fresh child processes (this process has not touched the GPU -- torch
+        # is not even imported yet -- and never will: it only waits for the children and passes rank 0's line through).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or "
+                         f"without a launcher (bench.py then starts the ranks itself)")
 
     import torch
     import torch.distributed as dist
@@ -259,6 +417,8 @@ def main():
     rects = tile_rects(W, Hh, rank, world) if world > 1 else []
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
     in_flight = plan_in_flight(args.in_flight, world, owned, args.max_entries)
+    if args.scaling == "strong":  # the job is `in_flight x rounds` samples per pixel: a rank cannot keep more of them in flight than that
+        in_flight = min(in_flight, args.in_flight * args.rounds)
     if world > 1:  # every rank must use the same batch: the smallest share decides
         t = torch.tensor([in_flight], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -268,7 +428,7 @@ def main():
     # would mean "the library's own non-blocking stream", which the collective would NOT be ordered after.)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight)
+        ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight, flags=args.flags)
         ctx.set_stream(stream.cuda_stream)
         ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
         ctx.set_camera(bundle.camera)
@@ -276,7 +436,7 @@ def main():
             ctx.set_tiles(rects)
         accum = torch.zeros(W * Hh, 4, device="cuda", dtype=torch.float32)
         ctx.set_accum_buffer(accum.data_ptr())
-        spp_step = in_flight * args.rounds
+        spp_step = in_flight * args.rounds if args.scaling == "weak" else args.in_flight * args.rounds
 
         def barrier():
             torch.cuda.synchronize()
@@ -314,6 +474,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
     ctx.close()
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_measurements(D, H, L, scenes, bundle, args, local_rank, in_flight)
     frame = None
     if rank == 0 and world == 1 and not args.no_frame:
         try:
@@ -331,14 +494,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"configs[3]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
                             f"SBVH meshes = {flat.instanced_triangles} instanced triangles, PBR metal/dielectric, procedural HDR sky + "
-                            f"emissive quad), two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG",
+                            f"emissive quad), scene handed over as the reference's two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG; "
+                            + ("every instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES)" if args.flags & 2 else
+                               "mesh instances entered at traversal, single-leaf meshes copied (PT_FLAG_TWO_LEVEL_ONLY)" if args.flags & 4 else
+                               "instances copied to world space at upload (the library's default while they fit a 2 GB budget; the `two_level` "
+                               "object times the same scene with the instances entered instead)"),
+                "scene_flags": args.flags,
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
                 "pixels_per_rank": owned, "paths_per_step_per_rank": owned * spp_step,
@@ -351,6 +519,8 @@ def main():
             "cpu_baseline": cpu,
             "frame": frame,
         }
+        if secondary:
+            out.update(secondary)
         if cpu:
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
         print(json.dumps(out), flush=True)

@@ -130,12 +130,12 @@ typedef struct {
     int32_t device; /* HIP device ordinal */
     uint32_t flags; /* PT_FLAG_* */
     uint32_t samples_in_flight; /* samples of one pixel traced concurrently, each into its own accumulator
-                                   plane (folded after the batch); 0 = auto (~32M path segments per launch), max 1024.
+                                   plane (folded at the end of pt_render); 0 = auto (~32M path segments per launch), max 4096.
                                    Only with max_active_rays == 0 and PT_RNG_COUNTER. */
 } pt_config;
 
 #define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */
-#define PT_FLAG_NO_BAKED_INSTANCES 2u /* keep every instance two-level: no world-space copies at all (diagnostics) */
+#define PT_FLAG_NO_BAKED_INSTANCES 2u /* every instance is ENTERED at traversal like in the reference (scene.cl:116-139): no world-space copies at all */
 #define PT_FLAG_TWO_LEVEL_ONLY 4u /* copy only single-leaf instances (quads, lights) to world space, not whole meshes */
 #define PT_FLAG_NO_PACKETS 8u /* never use the packet traversal kernel (primary rays then go through the per-ray kernel) */
 #define PT_FLAG_PACKET_INTERSECT 16u /* pt_intersect (test hook) uses the packet kernel where the scene allows it */
@@ -230,6 +230,7 @@ int pt_resolve(pt_ctx* ctx, float* rgba_out);
 /* same kernel, output left in DEVICE memory (width*height float4) -- the analogue of the GL texture the reference's
  * accumulate kernel writes (src/raytracer.cpp:432-450); NULL: a buffer owned by the context.  Asynchronous. */
 int pt_resolve_device(pt_ctx* ctx, void* device_rgba);
+void* pt_resolve_device_ptr(pt_ctx* ctx); /* the context-owned image pt_resolve_device(ctx, NULL) writes; NULL before the first such call */
 int pt_read_accum(pt_ctx* ctx, float* out_float4); /* width*height*4 floats: HDR sums (host) */
 int pt_write_accum(pt_ctx* ctx, const float* in_float4, uint32_t spp); /* restore a checkpoint */
 void* pt_accum_device_ptr(pt_ctx* ctx);

@@ -1,0 +1,164 @@
+// World-space copies of instances, made ON THE DEVICE (the dynamic part of a scene state, pt_upload_dynamic_async).
+//
+// The reference re-uploads its top-level BVH, lights and the dynamic tail of its vertex / node buffers every frame tick
+// (src/raytracer.cpp:497-595).  Here the bottom-level trees are converted ONCE, at pt_upload_static: collapsed to 4-wide nodes,
+// packed breadth-first per mesh root (a mesh's nodes are one contiguous run), with the exact child boxes and the per-leaf
+// offsets a copy needs kept next to them.  A tick then uploads the top level, the instance table and the lights (a few KB) and --
+// where instances are copied to world space, the library's default while a byte budget lasts -- launches two kernels on the copy
+// stream: one thread per (instance, node) re-fits and re-quantises the node's child boxes around their transformed corners, one
+// thread per (instance, triangle reference) transforms a triangle.  Round 2 did all of this on the host, single-threaded, and
+// copied the result (110 MB for the benchmark scene) through pinned staging: 240 ms per tick.
+#pragma once
+#include "pt_device.h"
+#include <cmath>
+
+namespace ptd {
+
+// Quantise up to four child boxes into a WideNode (pt_device.h): origin = min corner of their union, per-axis power-of-two scale
+// with (extent / scale) <= 255, planes rounded OUTWARDS and then verified with the exact expression the traversal kernels evaluate
+// (origin + scale * q).  An empty slot gets an inverted box and `emptyRef`.  Shared by the host (collapse of the caller's binary
+// trees) and the device (world-space copies), so that both produce the same bytes from the same boxes.
+__host__ __device__ inline void quantiseWideNode(const float (*lo)[3], const float (*hi)[3], const uint32_t* refs, const bool* empty, uint32_t emptyRef, WideNode* out)
+{
+    float nlo[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f }, nhi[3] = { -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f };
+    for (int k = 0; k < 4; k++)
+        for (int a = 0; a < 3; a++)
+            if (!empty[k] && lo[k][a] <= hi[k][a]) {
+                nlo[a] = fminf(nlo[a], lo[k][a]);
+                nhi[a] = fmaxf(nhi[a], hi[k][a]);
+            }
+    WideNode w {};
+    uint32_t ex[3];
+    float scale[3];
+    for (int a = 0; a < 3; a++) {
+        if (!(nlo[a] <= nhi[a]))
+            nlo[a] = nhi[a] = 0.f;
+        // smallest power of two s with (hi - lo) / s <= 255, evaluated in float like the kernel does
+        int e = 0;
+        const float extent = nhi[a] - nlo[a];
+        (void)frexpf(extent / 255.0f, &e); // extent/255 = m * 2^e, m in [0.5,1)  =>  2^e >= extent/255
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        scale[a] = ldexpf(1.0f, e);
+        while (extent > 0.f && nlo[a] + scale[a] * 255.0f < nhi[a] && e < 127) // guard float round-off
+            scale[a] = ldexpf(1.0f, ++e);
+        ex[a] = (uint32_t)(e + 127);
+    }
+    w.ox = nlo[0], w.oy = nlo[1], w.oz = nlo[2];
+    w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+    uint32_t q[6] = { 0, 0, 0, 0, 0, 0 }; // qlox, qhix, qloy, qhiy, qloz, qhiz
+    for (int k = 0; k < 4; k++) {
+        w.child[k] = empty[k] ? emptyRef : refs[k];
+        for (int a = 0; a < 3; a++) {
+            uint32_t ql = 255, qh = 0;
+            if (!empty[k]) {
+                const float fl = floorf((lo[k][a] - nlo[a]) / scale[a]);
+                const float fh = ceilf((hi[k][a] - nlo[a]) / scale[a]);
+                ql = (uint32_t)fmaxf(0.f, fminf(255.f, fl));
+                qh = (uint32_t)fmaxf(0.f, fminf(255.f, fh));
+                while (ql > 0 && nlo[a] + scale[a] * (float)ql > lo[k][a])
+                    ql--;
+                while (qh < 255 && nlo[a] + scale[a] * (float)qh < hi[k][a])
+                    qh++;
+            }
+            q[a * 2] |= ql << (8 * k);
+            q[a * 2 + 1] |= qh << (8 * k);
+        }
+    }
+    w.qlox = q[0], w.qhix = q[1], w.qloy = q[2], w.qhiy = q[3], w.qloz = q[4], w.qhiz = q[5];
+    *out = w;
+}
+
+// What a world-space copy of one instance needs (built on the host per tick, a few dozen bytes per instance).
+struct BakeJob {
+    double m[12]; // rows 0..2 of the WORLD transform (inverse of the top-level leaf's invTransform), row-major 3 x 4
+    uint32_t srcNode, numNodes; // the mesh's run of packed bottom-level nodes (0 nodes: the mesh is a single leaf)
+    uint32_t dstNode; // where the copy's nodes go (same order)
+    uint32_t srcRef, numRefs; // the mesh's run in the table of triangle references (leaf order; an SBVH references a triangle more than once)
+    uint32_t dstTri; // where the copy's triangles go
+    uint32_t instance; // instance index reported for hits on the copy
+    uint32_t _pad;
+};
+
+// exact boxes of a packed node's (up to) four children, object space -- the quantised planes of the node itself are already rounded
+struct WideBoxes {
+    float lo[4][3], hi[4][3];
+};
+
+struct BakeArgs {
+    const BakeJob* jobs;
+    const WideNode* srcWide; // the mesh trees, object space
+    const WideBoxes* srcBoxes;
+    const uint32_t* srcLeafOfs; // [node][child]: offset of a leaf child's first triangle reference inside the mesh's run
+    const uint32_t* refTri; // triangle reference -> caller's triangle index
+    const TriIsect* srcTris; // caller's numbering, object space
+    WideNode* dstWide;
+    TriIsect* dstTris;
+    uint32_t emptyRef;
+};
+
+// one thread per (job = blockIdx.y, node): child boxes re-fitted around their transformed corners (looser for rotated instances, still
+// conservative), two ulps outwards for the rounding of the transformed triangles themselves, then quantised like any other node
+__global__ void __launch_bounds__(128) k_bake_nodes(BakeArgs a)
+{
+    const BakeJob& j = a.jobs[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.numNodes)
+        return;
+    const WideNode src = a.srcWide[j.srcNode + i];
+    const WideBoxes bx = a.srcBoxes[j.srcNode + i];
+    float lo[4][3], hi[4][3];
+    uint32_t refs[4];
+    bool empty[4];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t r = src.child[k];
+        empty[k] = r == a.emptyRef || !(bx.lo[k][0] <= bx.hi[k][0]);
+        refs[k] = a.emptyRef;
+        for (int ax = 0; ax < 3; ax++)
+            lo[k][ax] = 1.f, hi[k][ax] = -1.f;
+        if (empty[k])
+            continue;
+        double wlo[3] = { 1e300, 1e300, 1e300 }, whi[3] = { -1e300, -1e300, -1e300 };
+        for (int corner = 0; corner < 8; corner++) {
+            const double p[3] = { (corner & 1) ? bx.hi[k][0] : bx.lo[k][0], (corner & 2) ? bx.hi[k][1] : bx.lo[k][1], (corner & 4) ? bx.hi[k][2] : bx.lo[k][2] };
+            for (int ax = 0; ax < 3; ax++) {
+                const double q = j.m[ax * 4 + 0] * p[0] + j.m[ax * 4 + 1] * p[1] + j.m[ax * 4 + 2] * p[2] + j.m[ax * 4 + 3];
+                wlo[ax] = fmin(wlo[ax], q), whi[ax] = fmax(whi[ax], q);
+            }
+        }
+        for (int ax = 0; ax < 3; ax++) {
+            lo[k][ax] = nextafterf(nextafterf((float)wlo[ax], -INFINITY), -INFINITY);
+            hi[k][ax] = nextafterf(nextafterf((float)whi[ax], INFINITY), INFINITY);
+        }
+        refs[k] = refCount(r) == 0u ? makeRef(j.dstNode + (refIndex(r) - j.srcNode), 0u) : makeRef(j.dstTri + a.srcLeafOfs[(size_t)(j.srcNode + i) * 4 + k], refCount(r));
+    }
+    WideNode out;
+    quantiseWideNode(lo, hi, refs, empty, a.emptyRef, &out);
+    a.dstWide[j.dstNode + i] = out;
+}
+
+// one thread per (job, triangle reference): v0 and the two edges through the world transform (double, rounded once); the copy remembers
+// (caller's triangle, instance) so that a hit on it is reported like a hit inside the instance ((t, u, v) are the same in both spaces:
+// the reference never renormalises the transformed direction, scene.cl:118-121)
+__global__ void __launch_bounds__(256) k_bake_tris(BakeArgs a)
+{
+    const BakeJob& j = a.jobs[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.numRefs)
+        return;
+    const uint32_t orig = a.refTri[j.srcRef + i];
+    const TriIsect t = a.srcTris[orig];
+    const double v0[3] = { t.a.x, t.a.y, t.a.z }, e1[3] = { t.a.w, t.b.x, t.b.y }, e2[3] = { t.b.z, t.b.w, t.c.x };
+    float V0[3], E1[3], E2[3];
+    for (int r = 0; r < 3; r++) {
+        V0[r] = (float)(j.m[r * 4 + 0] * v0[0] + j.m[r * 4 + 1] * v0[1] + j.m[r * 4 + 2] * v0[2] + j.m[r * 4 + 3]);
+        E1[r] = (float)(j.m[r * 4 + 0] * e1[0] + j.m[r * 4 + 1] * e1[1] + j.m[r * 4 + 2] * e1[2]);
+        E2[r] = (float)(j.m[r * 4 + 0] * e2[0] + j.m[r * 4 + 1] * e2[1] + j.m[r * 4 + 2] * e2[2]);
+    }
+    TriIsect b;
+    b.a = make_float4(V0[0], V0[1], V0[2], E1[0]);
+    b.b = make_float4(E1[1], E1[2], E2[0], E2[1]);
+    b.c = make_float4(E2[2], __uint_as_float(orig), __uint_as_float(j.instance), 0.f);
+    a.dstTris[j.dstTri + i] = b;
+}
+
+} // namespace ptd

@@ -47,6 +47,7 @@ __device__ inline void lanePush(uint32_t& r, uint32_t& lo, uint32_t& hi, uint32_
                  : "+v"(r), "+v"(lo), "+v"(hi)
                  : "s"(ref), "s"(mlo), "s"(mhi), "s"(laneIndex));
 }
+typedef uint32_t u4v_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kKeyNone = 0x7F800000u; // +inf: no lane sees the child
 
 #ifndef PT_PACKET_BEAM
@@ -97,9 +98,56 @@ __device__ inline float rowShr1(float v) // v[lane - 1]
     return r;
 }
 
-template <bool ANY_HIT>
-__global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_packet(TraceArgs a)
+// TWO_LEVEL: the tree holds instance references.  The current reference is wave-uniform, so entering an instance is a uniform event:
+// the twelve matrix coefficients arrive by scalar loads, every lane takes its own ray into the instance's space (scene.cl:116-139), the
+// beam is rebuilt from the transformed rays (for a pinhole packet the origins stay one point: one interval reduction instead of two) and a
+// sentinel goes onto the stack; popping it brings the world-space ray and beam back from LDS, where they were put when the packet started
+// (14 dwords per lane).  A transform that turns the packet's directions into more than one octant (a rotation can, for the few packets that
+// look along one of the instance's axes) ends the beam walk: the packet starts over on the per-lane path with the hits it has found.
+#ifndef PT_PACKET_MIN_WAVES_TL
+#define PT_PACKET_MIN_WAVES_TL 8
+#endif
+constexpr int kPacketSave = 14; // world-space state of a lane while its packet is inside an instance
+// The beam of 64 rays whose directions point into one octant: per axis the interval of the origins and of |1 / direction|, and from
+// them the constants of the lane's role (axis, entry | exit plane) in the node test of k_trace_packet.
+__device__ inline void beamSetup(const V3 co, const V3 cid, bool nx, bool ny, bool nz, uint32_t axis, uint32_t isFar, float& S, float& negSO, float& mulPos,
+    float& mulNeg, uint32_t& ofsQ)
 {
+    V3 oLo = co, oHi = co;
+    if (__builtin_amdgcn_ballot_w64(co.x != asF(uni(asU(co.x))) || co.y != asF(uni(asU(co.y))) || co.z != asF(uni(asU(co.z)))) != 0ull) { // not a pinhole
+        waveMin3Max3(oLo.x, oLo.y, oLo.z, oHi.x, oHi.y, oHi.z);
+    }
+    V3 mLo = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z)), mHi = mLo;
+    waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z);
+    const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+    const float oLoA = axis == 0u ? oLo.x : (axis == 1u ? oLo.y : oLo.z), oHiA = axis == 0u ? oHi.x : (axis == 1u ? oHi.y : oHi.z);
+    const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
+    const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
+    // g = +-(plane - origin corner) is the signed distance along the axis in the ray's sense; t = g * |1/d|.
+    //   entry plane, lower bound: the corner that makes g smallest, times the small multiplier when g >= 0, the large one otherwise
+    //   exit plane, upper bound: the corner that makes g largest, times the large multiplier when g >= 0, the small one otherwise
+    // (exit lanes hold -upper, so that one max folds both)
+    S = neg ? -1.f : 1.f;
+    const float corner = (neg != (isFar != 0u)) ? oLoA : oHiA;
+    negSO = -(S * corner);
+    mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
+    ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
+}
+// the ray of every lane in the space of instance `what` (wave-uniform): the coefficients arrive by scalar loads
+__device__ inline void packetIntoInstance(const Instance* instances, uint32_t what, const V3 co, const V3 cd, V3* to, V3* td, uint32_t* root)
+{
+    typedef const u4v_t __attribute__((address_space(4)))* ScalarU4i;
+    const ScalarU4i m = (ScalarU4i)(unsigned long long)&instances[what];
+    const u4v_t r0 = m[0], r1 = m[1], r2 = m[2];
+    rayIntoInstance(make_float4(asF(r0.x), asF(r0.y), asF(r0.z), asF(r0.w)), make_float4(asF(r1.x), asF(r1.y), asF(r1.z), asF(r1.w)),
+        make_float4(asF(r2.x), asF(r2.y), asF(r2.z), asF(r2.w)), co, cd, to, td);
+    *root = m[3].x;
+}
+template <bool ANY_HIT, bool TWO_LEVEL>
+__global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_TL : PT_PACKET_MIN_WAVES) k_trace_packet(TraceArgs a)
+{
+    __shared__ uint32_t ldsSave[TWO_LEVEL ? kPacketBlock / 64 : 1][TWO_LEVEL ? kPacketSave : 1][64];
+    const uint32_t pwave = threadIdx.x >> 6;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef const u4v __attribute__((address_space(4)))* ScalarU4; // uniform address + constant space = scalar loads
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -175,11 +223,17 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         if (ro.x == 0.0f) ro.x = -FLT_MIN;
         if (ro.y == 0.0f) ro.y = -FLT_MIN;
         if (ro.z == 0.0f) ro.z = -FLT_MIN;
-        const V3 co = xyz(ro), cd = xyz(rd);
-        const V3 cid = mk(rcpSlab(cd.x), rcpSlab(cd.y), rcpSlab(cd.z));
-        const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+        V3 co = xyz(ro), cd = xyz(rd);
+        V3 cid = mk(rcpSlab(cd.x), rcpSlab(cd.y), rcpSlab(cd.z));
+        bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
         float hu = 0.f, hv = 0.f;
-        int hprim = -1;
+        int hprim = -1, hinst = -1;
+        int curInst = -1; // wave-uniform
+        if (TWO_LEVEL) { // the world-space ray, for the way back out of an instance
+            ldsSave[pwave][0][lane] = asU(co.x), ldsSave[pwave][1][lane] = asU(co.y), ldsSave[pwave][2][lane] = asU(co.z);
+            ldsSave[pwave][3][lane] = asU(cd.x), ldsSave[pwave][4][lane] = asU(cd.y), ldsSave[pwave][5][lane] = asU(cd.z);
+            ldsSave[pwave][6][lane] = asU(cid.x), ldsSave[pwave][7][lane] = asU(cid.y), ldsSave[pwave][8][lane] = asU(cid.z);
+        }
 
         // ---- beam traversal (closest hit, whole packets of rays pointing into one octant) --------------------------------------
         // The 64 primary rays of a packet are the samples of one pixel: almost one ray.  Testing four child boxes for each of them is
@@ -204,32 +258,51 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         if (!ANY_HIT && viaBeam) {
             // lane roles (lanes 32-63 repeat 0-31 and are never read): group of 8 lanes per child, (axis, near | far) inside it
             const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
-            // the beam: per axis the interval of the origins and of |1 / direction| (signs are uniform)
-            V3 oLo = co, oHi = co;
-            if (__builtin_amdgcn_ballot_w64(co.x != asF(uni(asU(co.x))) || co.y != asF(uni(asU(co.y))) || co.z != asF(uni(asU(co.z)))) != 0ull) { // not a pinhole
-                waveMin3Max3(oLo.x, oLo.y, oLo.z, oHi.x, oHi.y, oHi.z);
+            const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
+            float S, negSO, mulPos, mulNeg;
+            uint32_t ofsQ;
+            // the beam of the rays as they are now (co, cid; signs uniform): per axis the interval of the origins and of |1 / direction|
+            beamSetup(co, cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+            if (TWO_LEVEL) { // the world-space beam, next to the world-space ray
+                ldsSave[pwave][9][lane] = asU(S), ldsSave[pwave][10][lane] = asU(negSO), ldsSave[pwave][11][lane] = asU(mulPos);
+                ldsSave[pwave][12][lane] = asU(mulNeg), ldsSave[pwave][13][lane] = ofsQ;
             }
-            V3 mLo = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z)), mHi = mLo;
-            waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z);
-            const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
-            const float oLoA = axis == 0u ? oLo.x : (axis == 1u ? oLo.y : oLo.z), oHiA = axis == 0u ? oHi.x : (axis == 1u ? oHi.y : oHi.z);
-            const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
-            const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
-            // g = +-(plane - origin corner) is the signed distance along the axis in the ray's sense; t = g * |1/d|.
-            //   entry plane, lower bound: the corner that makes g smallest, times the small multiplier when g >= 0, the large one otherwise
-            //   exit plane, upper bound: the corner that makes g largest, times the large multiplier when g >= 0, the small one otherwise
-            // (exit lanes hold -upper, so that one max folds both)
-            const float S = neg ? -1.f : 1.f;
-            const float corner = (neg != (isFar != 0u)) ? oLoA : oHiA;
-            const float negSO = -(S * corner);
-            const float mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
-            const uint32_t ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar)), ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
             float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the packet
             uint32_t stRef = 0u; // the stack: entry e is lane e
             uint32_t sp = 0u;
             uint32_t cur = rootRef;
             while (true) {
-                if (refCount(cur) == 0u) {
+                if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
+                    if (cur != kRefLeaveInstance) {
+                        // -------- enter instance refIndex(cur): instances are only ever entered from world space ---------------
+                        V3 to, td;
+                        uint32_t root;
+                        packetIntoInstance(sc.instances, refIndex(cur), co, cd, &to, &td, &root);
+                        const V3 tid = mk(rcpSlab(td.x), rcpSlab(td.y), rcpSlab(td.z));
+                        const unsigned long long all = ~0ull;
+                        const unsigned long long sx = __builtin_amdgcn_ballot_w64(tid.x < 0.f), sy = __builtin_amdgcn_ballot_w64(tid.y < 0.f), sz = __builtin_amdgcn_ballot_w64(tid.z < 0.f);
+                        if (!((sx == 0ull || sx == all) && (sy == 0ull || sy == all) && (sz == 0ull || sz == all))) {
+                            viaBeam = false; // the packet no longer points into one octant: start over, per lane (the rays are still the world-space ones)
+                            break;
+                        }
+                        co = to, cd = td, cid = tid;
+                        nx = sx != 0ull, ny = sy != 0ull, nz = sz != 0ull;
+                        beamSetup(co, cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                        curInst = (int)refIndex(cur);
+                        stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
+                        sp++;
+                        cur = uni(root);
+                        continue;
+                    }
+                    // -------- the sentinel: back to the world-space ray and beam ----------------------------------------------
+                    co = mk(asF(ldsSave[pwave][0][lane]), asF(ldsSave[pwave][1][lane]), asF(ldsSave[pwave][2][lane]));
+                    cd = mk(asF(ldsSave[pwave][3][lane]), asF(ldsSave[pwave][4][lane]), asF(ldsSave[pwave][5][lane]));
+                    cid = mk(asF(ldsSave[pwave][6][lane]), asF(ldsSave[pwave][7][lane]), asF(ldsSave[pwave][8][lane]));
+                    nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                    S = asF(ldsSave[pwave][9][lane]), negSO = asF(ldsSave[pwave][10][lane]), mulPos = asF(ldsSave[pwave][11][lane]);
+                    mulNeg = asF(ldsSave[pwave][12][lane]), ofsQ = ldsSave[pwave][13][lane];
+                    curInst = -1;
+                } else if (refCount(cur) == 0u) {
                     const uint32_t ni = refIndex(cur);
                     const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
                     const char* nb = (const char*)&sc.wide[ni];
@@ -288,6 +361,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                             hu = u;
                             hv = v;
                             hprim = (int)(first + k);
+                            hinst = curInst;
                             any = true;
                         }
                     }
@@ -300,9 +374,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                 sp--;
                 cur = __builtin_amdgcn_readlane(stRef, sp);
             }
-        } else
+        }
 #endif
-        {
+        if (ANY_HIT || !viaBeam) {
         uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
         uint32_t sp = 0u; // wave-uniform
         uint32_t cur = rootRef;
@@ -310,7 +384,27 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
         if (curMask != 0ull)
             while (true) {
                 const bool here = __builtin_amdgcn_inverse_ballot_w64(curMask) && (!ANY_HIT || active);
-                if (refCount(cur) == 0u) {
+                if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
+                    if (cur != kRefLeaveInstance) {
+                        // -------- enter instance refIndex(cur): every lane transforms its ray, the lanes of curMask walk the subtree
+                        V3 to, td;
+                        uint32_t root;
+                        packetIntoInstance(sc.instances, refIndex(cur), co, cd, &to, &td, &root);
+                        co = to, cd = td, cid = mk(rcpSlab(td.x), rcpSlab(td.y), rcpSlab(td.z));
+                        nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                        curInst = (int)refIndex(cur);
+                        lanePush(stRef, stLo, stHi, kRefLeaveInstance, 0u, 0u, uni(sp));
+                        sp++;
+                        cur = uni(root);
+                        continue; // same lane mask
+                    }
+                    // -------- the sentinel: back to the world-space ray ---------------------------------------------------
+                    co = mk(asF(ldsSave[pwave][0][lane]), asF(ldsSave[pwave][1][lane]), asF(ldsSave[pwave][2][lane]));
+                    cd = mk(asF(ldsSave[pwave][3][lane]), asF(ldsSave[pwave][4][lane]), asF(ldsSave[pwave][5][lane]));
+                    cid = mk(asF(ldsSave[pwave][6][lane]), asF(ldsSave[pwave][7][lane]), asF(ldsSave[pwave][8][lane]));
+                    nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                    curInst = -1;
+                } else if (refCount(cur) == 0u) {
 #ifdef PT_TRACE_STATS
                     statNodes++;
 #endif
@@ -399,6 +493,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                                 hu = u;
                                 hv = v;
                                 hprim = (int)(first + k);
+                                hinst = curInst;
                             }
                         }
                     }
@@ -435,8 +530,7 @@ __global__ void __launch_bounds__(kPacketBlock, PT_PACKET_MIN_WAVES) k_trace_pac
                 *ap = px;
             }
         } else if (active) {
-            int hinst = -1;
-            if (hprim >= 0) { // a world-space copy of an instance: back to (original triangle, instance)
+            if (hprim >= 0 && hinst < 0) { // a world-space copy of an instance: back to (original triangle, instance)
                 const float4 tc = sc.tris[hprim].c;
                 hprim = (int)asU(tc.y);
                 hinst = (int)asU(tc.z);

@@ -66,6 +66,12 @@ constexpr int kTraceBlock = 256;
 #endif
 constexpr int kParkedBreakAny = PT_PARKED_BREAK_ANY; // same, any-hit traversal (only unoccluded rays park: they have a deposit to make)
 constexpr int kParkedBreak = PT_PARKED_BREAK; // leave the hot loop once this many lanes are parked on a special step or idle
+// the instantiations that enter instances park far more often (every instance entry and exit): they are served a little earlier.
+// Benchmark scene, every instance entered, (closest, any hit) = (16, 32) / (24, 40) / (32, 48): 7 663 / 7 682 / 7 563 Mrays/s
+#ifndef PT_PARKED_BREAK_TL
+#define PT_PARKED_BREAK_TL 24
+#define PT_PARKED_BREAK_ANY_TL 40
+#endif
 constexpr int kRefillIdleLanes = PT_REFILL_IDLE; // hand out new rays once this many lanes are idle
 
 struct TraceArgs {
@@ -113,7 +119,25 @@ __device__ inline float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); } //
 // sign -- instead of the inf - inf = NaN the one-FMA form would produce from an infinite reciprocal.
 __device__ inline float rcpSlab(float x) { return fminf(fmaxf(rcpFast(x), -1e18f), 1e18f); }
 
-template <bool ANY_HIT>
+// A ray taken into an instance's space (scene.cl:116-139): rows r0..r2 of the inverse transform; the direction is NOT
+// renormalised, so t is shared between the two spaces; exactly-zero components are nudged (NO_PARALLEL_RAYS, scene.cl:123-137).
+// One spelling (explicit FMAs) for every kernel that enters instances, so that they produce the same bits.
+__device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const float4 r2, const V3 o, const V3 d, V3* to, V3* td)
+{
+    *to = mk(fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w))), fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w))),
+        fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w))));
+    *td = mk(fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z)), fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z)), fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z)));
+    if (td->x == 0.0f) td->x = FLT_MIN;
+    if (td->y == 0.0f) td->y = FLT_MIN;
+    if (td->z == 0.0f) td->z = FLT_MIN;
+    if (to->x == 0.0f) to->x = -FLT_MIN;
+    if (to->y == 0.0f) to->y = -FLT_MIN;
+    if (to->z == 0.0f) to->z = -FLT_MIN;
+}
+
+// TWO_LEVEL: the tree holds instance references (instances that were not copied to world space at upload); scenes that are one
+// world-space tree run the instantiation without the instance code.
+template <bool ANY_HIT, bool TWO_LEVEL>
 __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
@@ -329,7 +353,7 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         a.inst[rayIdx] = hinst;
                     }
                     active = false;
-                } else {
+                } else if (TWO_LEVEL) {
                     if (what == kSpecialLeaveInstance) {
                         // -------- back to world space ---------------------------------------------------------
                         {   // the world-space ray again, from the queue (instances are rarely entered: ptamd.hip copies them to world space)
@@ -345,20 +369,10 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
                         curInst = -1;
                         cur = sp > 0 ? pop(--sp) : kRefFinish;
                     } else {
-                        const V3 o = co, d = cd; // instances are only ever entered from world space
-                        // -------- enter instance `what` (scene.cl:116-139) ---------------------------------
+                        // -------- enter instance `what` (scene.cl:116-139); instances are only ever entered from world space
                         const Instance in = sc.instances[what];
-                        V3 to = mk(in.r0.x * o.x + in.r0.y * o.y + in.r0.z * o.z + in.r0.w, in.r1.x * o.x + in.r1.y * o.y + in.r1.z * o.z + in.r1.w,
-                            in.r2.x * o.x + in.r2.y * o.y + in.r2.z * o.z + in.r2.w);
-                        V3 td = mk(in.r0.x * d.x + in.r0.y * d.y + in.r0.z * d.z, in.r1.x * d.x + in.r1.y * d.y + in.r1.z * d.z,
-                            in.r2.x * d.x + in.r2.y * d.y + in.r2.z * d.z);
-                        // NO_PARALLEL_RAYS fix-up (scene.cl:123-137)
-                        if (td.x == 0.0f) td.x = FLT_MIN;
-                        if (td.y == 0.0f) td.y = FLT_MIN;
-                        if (td.z == 0.0f) td.z = FLT_MIN;
-                        if (to.x == 0.0f) to.x = -FLT_MIN;
-                        if (to.y == 0.0f) to.y = -FLT_MIN;
-                        if (to.z == 0.0f) to.z = -FLT_MIN;
+                        V3 to, td;
+                        rayIntoInstance(in.r0, in.r1, in.r2, co, cd, &to, &td);
                         setRay(to, td);
                         curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
                         push(sp, kRefLeaveInstance);
@@ -391,7 +405,8 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             // enough lanes are idle for a hand-out (and the queue still has rays)
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
             const int nWork = nInner + nLeaf;
-            if (nWork == 0 || nSpecial >= (ANY_HIT ? kParkedBreakAny : kParkedBreak) || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
+            constexpr int parkedBreak = TWO_LEVEL ? (ANY_HIT ? PT_PARKED_BREAK_ANY_TL : PT_PARKED_BREAK_TL) : (ANY_HIT ? kParkedBreakAny : kParkedBreak);
+            if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
                 break;
             if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
                 PT_STAT(2, 1);

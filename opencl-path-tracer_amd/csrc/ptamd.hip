@@ -5,6 +5,7 @@
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_packet.h"
+#include "pt_bake.h"
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
 #endif
@@ -87,16 +88,48 @@ struct pt_ctx {
         DevBuf<TriFat> fat; // shading records: they hold v0 / edges / normals, which a refitted mesh changes with the trees
         DevBuf<Instance> instances;
         DevBuf<Light> lights;
+        DevBuf<BakeJob> jobs; // world-space copies to make (pt_bake.h)
+        uint64_t staticVersion = 0; // version of the static arrays this set holds (0: none)
         // pinned staging the asynchronous copies read from (grow-only, like the device buffers)
         void* stage = nullptr;
         size_t stageBytes = 0;
+        hipEvent_t stageRead = nullptr; // recorded on the copy stream after the copies out of `stage`
+        bool stageBusy = false;
         uint32_t numLights = 0, rootRef = 0;
         bool packetOk = false;
+        bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
         std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
         hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
         hipEvent_t lastUse = nullptr; // recorded on the render stream when the set stopped being the active one
         bool used = false;
     } dyn[2];
+    // The static part: the bottom-level trees as packed 4-wide nodes, object-space triangles and shading records.  Converted on the
+    // host once per pt_upload_static / pt_update_geometry (buildStaticGeom); one master copy on the device, from which a dynamic
+    // set refreshes its own copy (device to device) when its version is stale.
+    struct StaticGeom {
+        std::vector<WideNode> wide; // packed, object space
+        std::vector<WideBoxes> boxes; // exact child boxes of every packed node
+        std::vector<uint32_t> leafOfs; // [node][child]: offset of a leaf child's first triangle reference in its mesh's run
+        std::vector<uint32_t> refTri; // triangle references in leaf order, mesh by mesh -> caller's triangle index
+        std::vector<uint32_t> stackNeed; // per packed node
+        std::vector<TriFat> fat;
+        struct Root {
+            uint32_t ref; // device reference of the mesh root (a packed node, or a leaf)
+            uint32_t nodeBase, numNodes, refBase, numRefs;
+            bool bakeable; // its nodes are one run of their own
+        };
+        std::vector<Root> roots;
+        std::vector<int32_t> rootOfNode; // caller's node index -> roots[] slot, -1: not a root
+        std::vector<uint32_t> extraRoots; // interior nodes a top-level leaf has named
+        uint32_t emptyRef = 0;
+        uint64_t version = 0;
+        bool onDevice = false;
+        DevBuf<WideNode> dWide;
+        DevBuf<WideBoxes> dBoxes;
+        DevBuf<uint32_t> dLeafOfs, dRefTri;
+        DevBuf<TriIsect> dTris;
+        DevBuf<TriFat> dFat;
+    } sg;
     int active = 0; // set the render kernels read
     int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
     hipStream_t copyStream = nullptr;
@@ -117,13 +150,14 @@ struct pt_ctx {
     // frame state
     CameraDev camera {};
     DevBuf<uint32_t> pixelList;
+    std::vector<uint32_t> hostPixelList; // what pixelList holds (pt_set_tiles with the same list again is a no-op)
     DevBuf<uint32_t> pixelOrdinal; // global pixel -> position in pixelList (only when the context owns part of the frame)
     DevBuf<float4> resolveTmp; // pt_resolve's output staging (allocated at first use)
     uint32_t numOwned = 0;
     uint32_t capacity = 0;
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
-    uint32_t packetBlocks = 0;
+    uint32_t packetBlocks[2] = { 0, 0 };
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
     uint64_t packetLaunches = 0;
@@ -141,7 +175,7 @@ struct pt_ctx {
     DevBuf<Control> control;
     DevBuf<Totals> totals;
     DevBuf<uint32_t> spill;
-    uint32_t traceBlocks = 0;
+    uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
 
@@ -250,16 +284,20 @@ void lfsrJump(uint32_t g[4])
     g[3] = z;
 }
 
-// Collapse the pair-node tree into 4-wide nodes with 8-bit quantised child boxes (pt_device.h, WideNode).
-// wide[i] describes the same subtree as pair[i], so child references keep their indices.
-// `emptyRef`: what an unused child slot refers to (its box is inverted, so it is never entered unless
-// round-off makes the inverted box look non-empty; the reference must therefore be harmless to visit)
+// Collapse the pair-node tree into 4-wide nodes (pt_device.h, WideNode): which descendants of pair node i become the (up to four)
+// children of its wide node.  kids[i] describes the same subtree as pair[i], so child references keep their indices; the boxes are the
+// exact ones (quantiseWideNode, pt_bake.h, makes the 8-bit planes; the world-space copies of instances are re-fitted from the exact boxes).
 #ifndef PT_COLLAPSE_OPTIMAL
 #define PT_COLLAPSE_OPTIMAL 1
 #endif
-std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t emptyRef)
+struct WideKids {
+    float lo[4][3], hi[4][3];
+    uint32_t ref[4];
+    bool empty[4];
+};
+std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
 {
-    std::vector<WideNode> wide(pair.size());
+    std::vector<WideKids> out(pair.size());
     struct Child {
         float lo[3], hi[3];
         uint32_t ref;
@@ -411,56 +449,18 @@ std::vector<WideNode> collapseToWide(const std::vector<PairNode>& pair, uint32_t
             kids[n++] = childOf(g, 1);
         }
 #endif
-        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-        for (int k = 0; k < n; k++)
-            for (int a = 0; a < 3; a++) {
-                if (kids[k].lo[a] <= kids[k].hi[a]) { // ignore empty boxes (pads)
-                    lo[a] = std::min(lo[a], kids[k].lo[a]);
-                    hi[a] = std::max(hi[a], kids[k].hi[a]);
-                }
-            }
-        WideNode w {};
-        uint32_t ex[3];
-        float scale[3];
-        for (int a = 0; a < 3; a++) {
-            if (!(lo[a] <= hi[a]))
-                lo[a] = hi[a] = 0.f;
-            // smallest power of two s with (hi - lo) / s <= 255, evaluated in float like the kernel does
-            int e = 0;
-            float extent = hi[a] - lo[a];
-            std::frexp(extent / 255.0f, &e); // extent/255 = m * 2^e, m in [0.5,1)  =>  2^e >= extent/255
-            e = std::max(-126, std::min(e, 127));
-            scale[a] = std::ldexp(1.0f, e);
-            while (extent > 0.f && lo[a] + scale[a] * 255.0f < hi[a] && e < 127) // guard float round-off
-                scale[a] = std::ldexp(1.0f, ++e);
-            ex[a] = (uint32_t)(e + 127);
-        }
-        w.ox = lo[0], w.oy = lo[1], w.oz = lo[2];
-        w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-        uint32_t* q[6] = { &w.qlox, &w.qhix, &w.qloy, &w.qhiy, &w.qloz, &w.qhiz };
+        WideKids wk {};
         for (int k = 0; k < 4; k++) {
-            const bool empty = k >= n || !(kids[k].lo[0] <= kids[k].hi[0]) || kids[k].ref == kRefNone;
-            w.child[k] = empty ? emptyRef : kids[k].ref;
+            wk.empty[k] = k >= n || !(kids[k].lo[0] <= kids[k].hi[0]) || kids[k].ref == kRefNone;
+            wk.ref[k] = wk.empty[k] ? kRefNone : kids[k].ref;
             for (int a = 0; a < 3; a++) {
-                uint32_t ql = 255, qh = 0;
-                if (!empty) {
-                    // outward rounding, then verify with the exact expression the kernel evaluates (origin + scale*q)
-                    float fl = std::floor((kids[k].lo[a] - lo[a]) / scale[a]);
-                    float fh = std::ceil((kids[k].hi[a] - lo[a]) / scale[a]);
-                    ql = (uint32_t)std::max(0.f, std::min(255.f, fl));
-                    qh = (uint32_t)std::max(0.f, std::min(255.f, fh));
-                    while (ql > 0 && lo[a] + scale[a] * (float)ql > kids[k].lo[a])
-                        ql--;
-                    while (qh < 255 && lo[a] + scale[a] * (float)qh < kids[k].hi[a])
-                        qh++;
-                }
-                *q[a * 2] |= ql << (8 * k);
-                *q[a * 2 + 1] |= qh << (8 * k);
+                wk.lo[k][a] = wk.empty[k] ? 1.f : kids[k].lo[a];
+                wk.hi[k][a] = wk.empty[k] ? -1.f : kids[k].hi[a];
             }
         }
-        wide[i] = w;
+        out[i] = wk;
     }
-    return wide;
+    return out;
 }
 
 // world = inverse(invTransform) by Gauss-Jordan in double; m is column-major (TopBvhNode::invTransform).
@@ -494,67 +494,146 @@ bool invertTransform(const float* m, double w[4][8])
     return true;
 }
 
-// Worst-case number of pending stack entries while traversing the 4-wide tree from `rootRef`: visiting a node
-// can leave all its other children on the stack, and entering an instance adds the leave-instance sentinel.
-// (Children are visited nearest first, so any order can occur: the bound takes the deepest child first.)
-uint32_t wideStackNeed(const std::vector<WideNode>& wide, const std::vector<Instance>& inst, uint32_t rootRef, uint32_t emptyRef)
+// ---- the static part of a scene: bottom-level trees, converted once per pt_upload_static / pt_update_geometry -----------------------
+// Collapse every mesh tree to 4-wide nodes and pack them breadth-first root by root: the four children of a node get neighbouring
+// slots (half the footprint in the 4 MB-per-XCD L2, siblings share 128-byte lines) and a mesh's nodes are ONE contiguous run, which is
+// what a world-space copy of an instance (pt_bake.h) is made from.  Roots are the caller's nodes no other node refers to, plus any
+// node a top-level leaf has ever named (`extraRoots`).
+int buildStaticGeom(pt_ctx* c)
 {
-    constexpr uint32_t kUnset = 0xFFFFFFFFu;
-    std::vector<uint32_t> need(wide.size(), kUnset);
-    auto childRefs = [&](uint32_t ref, uint32_t out[4]) { // references below `ref` that still have to be sized
-        int n = 0;
-        if (refCount(ref) == 0u && refIndex(ref) < wide.size()) {
-            for (uint32_t r : wide[refIndex(ref)].child)
-                if (r != emptyRef)
-                    out[n++] = r;
-        } else if (refCount(ref) == kRefSpecial && refIndex(ref) < inst.size()) {
-            out[n++] = inst[refIndex(ref)].rootRef;
-        }
-        return n;
-    };
-    auto known = [&](uint32_t ref, uint32_t* v) { // leaves need nothing; inner nodes are memoised; instances are derived
-        if (refCount(ref) == 0u && refIndex(ref) < wide.size()) {
-            *v = need[refIndex(ref)];
-            return *v != kUnset;
-        }
-        if (refCount(ref) == kRefSpecial && refIndex(ref) < inst.size()) {
-            uint32_t below = 0;
-            const uint32_t rr = inst[refIndex(ref)].rootRef;
-            if (refCount(rr) == 0u && refIndex(rr) < wide.size()) {
-                below = need[refIndex(rr)];
-                if (below == kUnset)
-                    return false;
-            }
-            *v = 1u + below;
-            return true;
-        }
-        *v = 0u;
-        return true;
-    };
-    std::vector<uint32_t> todo { rootRef };
-    while (!todo.empty()) {
-        const uint32_t ref = todo.back();
-        uint32_t kids[4], v = 0;
-        const int n = childRefs(ref, kids);
-        bool ready = true;
-        uint32_t deepest = 0;
-        for (int k = 0; k < n; k++) {
-            if (known(kids[k], &v))
-                deepest = std::max(deepest, v);
-            else {
-                ready = false;
-                todo.push_back(refCount(kids[k]) == kRefSpecial ? inst[refIndex(kids[k])].rootRef : kids[k]);
-            }
-        }
-        if (!ready)
-            continue;
-        todo.pop_back();
-        if (refCount(ref) == 0u && refIndex(ref) < wide.size())
-            need[refIndex(ref)] = (n > 0 ? (uint32_t)(n - 1) : 0u) + deepest;
+    pt_ctx::StaticGeom& g = c->sg;
+    const uint32_t nN = c->numRefNodes, nT = c->numTris;
+    const std::vector<WideKids> kids = collapseKids(c->hostBottomNodes);
+    const uint32_t emptyRef = makeRef(nT, 1u); // the all-zero triangle stored right after the caller's triangles (det == 0: never hit)
+    std::vector<uint8_t> isChild(nN, 0);
+    for (uint32_t i = 0; i < nN; i++) {
+        const pt_sub_bvh_node& n = c->hostSubNodes[i];
+        const uint32_t l = n.leftChildOrFirstTriangle;
+        if (n.triangleCount == 0 && c->nodeRef[i] != kRefNone && (uint64_t)l + 1 < nN)
+            isChild[l] = isChild[l + 1] = 1;
     }
-    uint32_t v = 0;
-    known(rootRef, &v);
-    return v;
+    std::vector<uint32_t> rootNodes;
+    for (uint32_t i = 0; i < nN; i++)
+        if (c->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
+            rootNodes.push_back(i);
+    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear();
+    g.rootOfNode.assign(nN, -1);
+    constexpr uint32_t kUnset = 0xFFFFFFFFu;
+    std::vector<uint32_t> newIndex(kids.size(), kUnset), order;
+    auto isInner = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < kids.size(); };
+    for (uint32_t rn : rootNodes) {
+        pt_ctx::StaticGeom::Root root {};
+        const uint32_t rref = c->nodeRef[rn];
+        root.nodeBase = (uint32_t)order.size();
+        root.refBase = (uint32_t)g.refTri.size();
+        root.bakeable = true;
+        if (isInner(rref)) {
+            if (newIndex[refIndex(rref)] != kUnset) { // reachable from an earlier root too (a top-level leaf names an interior node): shares its run
+                root.ref = makeRef(newIndex[refIndex(rref)], 0u);
+                root.bakeable = false;
+            } else {
+                const size_t first = order.size();
+                newIndex[refIndex(rref)] = (uint32_t)order.size();
+                order.push_back(refIndex(rref));
+                for (size_t q = first; q < order.size(); q++) // breadth first
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r = kids[order[q]].ref[k];
+                        if (kids[order[q]].empty[k] || !isInner(r))
+                            continue;
+                        if (newIndex[refIndex(r)] != kUnset) {
+                            root.bakeable = false; // shares nodes with another tree: not one run
+                            continue;
+                        }
+                        newIndex[refIndex(r)] = (uint32_t)order.size();
+                        order.push_back(refIndex(r));
+                    }
+                root.ref = makeRef(root.nodeBase, 0u);
+            }
+            root.numNodes = (uint32_t)order.size() - root.nodeBase;
+        } else {
+            root.ref = rref; // the mesh is a single leaf
+            for (uint32_t k = 0; k < refCount(rref); k++)
+                g.refTri.push_back(refIndex(rref) + k);
+        }
+        // nodes of this run: remapped references, exact boxes, triangle-reference offsets of the leaves
+        g.wide.resize(order.size());
+        g.boxes.resize(order.size());
+        g.leafOfs.resize(order.size() * 4, 0u);
+        for (size_t q = root.nodeBase; q < order.size(); q++) {
+            const WideKids& wk = kids[order[q]];
+            uint32_t refs[4];
+            for (int k = 0; k < 4; k++) {
+                refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+                if (!wk.empty[k] && !isInner(wk.ref[k])) {
+                    g.leafOfs[q * 4 + k] = (uint32_t)g.refTri.size() - root.refBase;
+                    for (uint32_t t = 0; t < refCount(wk.ref[k]); t++)
+                        g.refTri.push_back(refIndex(wk.ref[k]) + t);
+                }
+                for (int a = 0; a < 3; a++)
+                    g.boxes[q].lo[k][a] = wk.lo[k][a], g.boxes[q].hi[k][a] = wk.hi[k][a];
+            }
+            quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, emptyRef, &g.wide[q]);
+        }
+        root.numRefs = (uint32_t)g.refTri.size() - root.refBase;
+        g.rootOfNode[rn] = (int32_t)g.roots.size();
+        g.roots.push_back(root);
+    }
+    // worst-case number of pending stack entries below every packed node: visiting a node can leave all its other children on the
+    // stack (children are visited nearest first, so any order can occur: the bound takes the deepest child first).  Children sit
+    // after their parent in a run, so one reverse sweep does it.
+    g.stackNeed.assign(g.wide.size(), 0u);
+    for (size_t q = g.wide.size(); q-- > 0;) {
+        uint32_t n = 0, deepest = 0;
+        for (uint32_t r : g.wide[q].child) {
+            if (r == emptyRef)
+                continue;
+            n++;
+            if (refCount(r) == 0u && refIndex(r) < g.wide.size())
+                deepest = std::max(deepest, refIndex(r) > q ? g.stackNeed[refIndex(r)] : 0u);
+        }
+        g.stackNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
+    }
+    // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h)
+    g.fat.resize(c->hostTriShade.size());
+    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
+        const TriShade& ts = c->hostTriShade[t];
+        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
+        const TriIsect& ti = c->hostTris[t];
+        TriFat f {};
+        f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
+        float mbits;
+        std::memcpy(&mbits, &ts.material, 4);
+        f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
+        f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
+        f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
+        float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
+        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
+        f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
+        f.mat = make_float4(m[4], m[5], m[6], m[8]);
+        g.fat[t] = f;
+    }
+    g.emptyRef = emptyRef;
+    g.version++;
+    g.onDevice = false;
+    return PT_OK;
+}
+
+// the static arrays' master copy in device memory (the two dynamic sets take theirs from it, device to device)
+int uploadStaticGeom(pt_ctx* c)
+{
+    pt_ctx::StaticGeom& g = c->sg;
+    if (g.onDevice)
+        return PT_OK;
+    // the copy stream may still be reading the old master (a set being refreshed from it)
+    HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    std::vector<TriIsect> tris = c->hostTris;
+    tris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) }); // what an unused child slot refers to
+    int rc;
+    if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dBoxes, g.boxes)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs))
+        || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat)))
+        return rc;
+    g.onDevice = true;
+    return PT_OK;
 }
 
 int resetStreams(pt_ctx* c)
@@ -591,6 +670,15 @@ int ensureQueues(pt_ctx* c)
             (unsigned long long)cap64, c->numOwned, c->planes);
     uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;
     {
+        // the buffers of the previous tiling are re-made below anyway: give their memory back first, so that the budget check sees it
+        // (a context whose queues use more than half of HBM -- 512 samples in flight at 1080p, two ranks sharing a GPU -- could not be re-tiled)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 2; k++)
+            c->rays[k].o.release(), c->rays[k].d.release(), c->rays[k].thr.release();
+        c->shadow.o.release(), c->shadow.d.release(), c->shadow.c.release(), c->hitH.release(), c->hitInst.release(), c->accumPlanes.release();
+        c->stagedRays.o.release(), c->stagedRays.d.release(), c->stagedRays.thr.release();
+        c->stagedShadow.o.release(), c->stagedShadow.d.release(), c->stagedShadow.c.release(), c->activeFlag.release();
+        c->foldPlanes = 0;
         // Memory budget, checked before anything is allocated so that an oversized configuration fails HERE with a
         // message instead of somewhere in a later hipMalloc: per queue entry two extension queues (3 x 16 B each), the
         // shadow queue (3 x 16 B) and the hit records (20 B); per owned pixel one 16-byte accumulator plane for every
@@ -643,39 +731,57 @@ int ensureSpill(pt_ctx* c)
 {
     if (c->spill.p)
         return PT_OK;
-    int blocksPerCU = 0;
-    blocksPerCU = 8;
-    const void* variants[2] = { (const void*)k_trace<false>, (const void*)k_trace<true> };
-    for (const void* fn : variants) {
-        int b = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
-        blocksPerCU = std::min(blocksPerCU, b);
-    }
-    blocksPerCU = std::max(1, blocksPerCU);
-    if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) // diagnostics: a smaller persistent grid leaves wave slots to kernels of other streams / processes
-        blocksPerCU = std::max(1, std::min(blocksPerCU, atoi(e)));
-    c->traceBlocks = (uint32_t)(blocksPerCU * c->numCUs);
-    {
-        int b0 = 0, b1 = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, (const void*)k_trace_packet<false>, kPacketBlock, 0));
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (const void*)k_trace_packet<true>, kPacketBlock, 0));
-        int pb = std::max(1, std::min(b0, b1));
+    // persistent grids sized to the machine, per instantiation pair ([0]: scenes that are one world-space tree, [1]: scenes with
+    // instance references -- pt_trace.h, TWO_LEVEL)
+    const void* variants[2][2] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false> },
+        { (const void*)k_trace<false, true>, (const void*)k_trace<true, true> } };
+    const void* packetVariants[2][2] = { { (const void*)k_trace_packet<false, false>, (const void*)k_trace_packet<true, false> },
+        { (const void*)k_trace_packet<false, true>, (const void*)k_trace_packet<true, true> } };
+    for (int tl = 0; tl < 2; tl++) {
+        int blocksPerCU = 8;
+        for (const void* fn : variants[tl]) {
+            int b = 0;
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kTraceBlock, 0));
+            blocksPerCU = std::min(blocksPerCU, b);
+        }
+        blocksPerCU = std::max(1, blocksPerCU);
+        if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) // diagnostics: a smaller persistent grid leaves wave slots to kernels of other streams / processes
+            blocksPerCU = std::max(1, std::min(blocksPerCU, atoi(e)));
+        c->traceBlocks[tl] = (uint32_t)(blocksPerCU * c->numCUs);
+        int pb = 8;
+        for (const void* fn : packetVariants[tl]) {
+            int b = 0;
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, kPacketBlock, 0));
+            pb = std::min(pb, b);
+        }
+        pb = std::max(1, pb);
         if (const char* e = getenv("PTAMD_PACKET_BLOCKS_PER_CU"))
             pb = std::max(1, std::min(pb, atoi(e)));
-        c->packetBlocks = (uint32_t)(pb * c->numCUs);
+        c->packetBlocks[tl] = (uint32_t)(pb * c->numCUs);
     }
-    const size_t threads = (size_t)c->traceBlocks * kTraceBlock;
+    const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(threads * kSpillStack));
     return PT_OK;
 }
 
+inline int sceneKind(const pt_ctx* c) { return c->dyn[c->active].hasInstances ? 1 : 0; }
+
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
-    const dim3 grid(c->traceBlocks), block(kTraceBlock);
-    if (anyHit)
-        hipLaunchKernelGGL(k_trace<true>, grid, block, 0, c->stream, a);
-    else
-        hipLaunchKernelGGL(k_trace<false>, grid, block, 0, c->stream, a);
+    // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
+    const bool twoLevel = sceneKind(c) != 0;
+    const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
+    if (anyHit) {
+        if (twoLevel)
+            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, a);
+    } else {
+        if (twoLevel)
+            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, a);
+    }
 }
 
 TraceArgs traceArgsBase(pt_ctx* c)
@@ -683,7 +789,7 @@ TraceArgs traceArgsBase(pt_ctx* c)
     TraceArgs a {};
     a.sc = c->scene;
     a.spill = c->spill.p;
-    a.totalThreads = c->traceBlocks * kTraceBlock;
+    a.totalThreads = c->traceBlocks[sceneKind(c)] * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
     return a;
 }
@@ -758,12 +864,20 @@ constexpr uint32_t kPacketUseDefault = PT_PACKET_USE;
 
 void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
-    const dim3 grid(c->packetBlocks), block(kPacketBlock);
+    const bool twoLevel = sceneKind(c) != 0;
+    const dim3 grid(c->packetBlocks[twoLevel ? 1 : 0]), block(kPacketBlock);
     c->packetLaunches++;
-    if (anyHit)
-        hipLaunchKernelGGL(k_trace_packet<true>, grid, block, 0, c->stream, a);
-    else
-        hipLaunchKernelGGL(k_trace_packet<false>, grid, block, 0, c->stream, a);
+    if (anyHit) {
+        if (twoLevel)
+            hipLaunchKernelGGL((k_trace_packet<true, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace_packet<true, false>), grid, block, 0, c->stream, a);
+    } else {
+        if (twoLevel)
+            hipLaunchKernelGGL((k_trace_packet<false, true>), grid, block, 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_trace_packet<false, false>), grid, block, 0, c->stream, a);
+    }
 }
 
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
@@ -1044,7 +1158,8 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         return bail(e, "hipEventCreate");
     for (auto& d : c->dyn)
         if ((e = hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming)) != hipSuccess
-            || (e = hipEventCreateWithFlags(&d.lastUse, hipEventDisableTiming)) != hipSuccess)
+            || (e = hipEventCreateWithFlags(&d.lastUse, hipEventDisableTiming)) != hipSuccess
+            || (e = hipEventCreateWithFlags(&d.stageRead, hipEventDisableTiming)) != hipSuccess)
             return bail(e, "hipEventCreate");
     if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream)) != hipSuccess)
         return bail(e, "alloc totals");
@@ -1073,6 +1188,8 @@ void pt_destroy(pt_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    if (c->copyStream) // a never-adopted upload may still be copying into the sets released below
+        (void)hipStreamSynchronize(c->copyStream);
     DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
         &c->rays[1].d, &c->rays[1].thr, &c->stagedRays.o, &c->stagedRays.d, &c->stagedRays.thr, &c->shadow.o, &c->shadow.d, &c->shadow.c,
         &c->stagedShadow.o, &c->stagedShadow.d, &c->stagedShadow.c };
@@ -1081,11 +1198,13 @@ void pt_destroy(pt_ctx* c)
     c->texMaterial.release(), c->texSky.release();
     c->nodes.release(), c->materials.release();
     for (auto& d : c->dyn) {
-        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release();
+        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release(), d.jobs.release();
         if (d.stage) (void)hipHostFree(d.stage);
+        if (d.stageRead) (void)hipEventDestroy(d.stageRead);
         if (d.uploaded) (void)hipEventDestroy(d.uploaded);
         if (d.lastUse) (void)hipEventDestroy(d.lastUse);
     }
+    c->sg.dWide.release(), c->sg.dBoxes.release(), c->sg.dLeafOfs.release(), c->sg.dRefTri.release(), c->sg.dTris.release(), c->sg.dFat.release();
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
@@ -1258,10 +1377,10 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->hostTris = hTris;
     c->hostBottomNodes = std::move(hNodes);
     if (geometryOnly) {
-        c->hostVerts = std::move(hVerts); // the next pt_upload_dynamic builds the shading records of the refitted state from them
+        c->hostVerts = std::move(hVerts);
         for (uint32_t i = 0; i < nN; i++) // only the boxes may differ
             c->hostSubNodes[i] = nodes[i];
-        return PT_OK;
+        return buildStaticGeom(c); // new version: the sets take it in with their next upload; what is on the device stays valid meanwhile
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
     if ((rc = uploadVec(c, c->materials, hMats)))
@@ -1276,6 +1395,9 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->haveStatic = true;
     c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
     c->pending = -1;
+    c->sg.extraRoots.clear();
+    if ((rc = buildStaticGeom(c)))
+        return rc;
     refreshSceneView(c);
     return PT_OK;
     }
@@ -1314,193 +1436,125 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
 
 namespace {
 
-// What the host-side conversion of one dynamic state produces (no device call in it): the arrays of a DynamicSet.
+// What the host-side conversion of one dynamic state produces (no device call in it): the top level, the instance table, the lights,
+// and the list of world-space copies the device is to make.  Everything below the top level is static (pt_ctx::StaticGeom).
 struct DynamicHost {
-    std::vector<TriIsect> tris;
-    std::vector<TriFat> fat;
-    std::vector<WideNode> wide;
+    std::vector<WideNode> topWide; // goes to wide[staticNodes ...]
     std::vector<Instance> instances;
     std::vector<Light> lights;
+    std::vector<BakeJob> jobs;
     std::vector<uint32_t> instanceTopNode;
     uint32_t numLights = 0, rootRef = 0;
-    bool packetOk = false;
+    uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
+    uint32_t bakedNodes = 0, bakedTris = 0;
+    bool packetOk = false, hasInstances = false;
 };
 
 int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
 {
+    pt_ctx::StaticGeom& sg = c->sg;
+    // a top-level leaf may name any node of the caller's sub-BVH array; the ones that are not mesh roots become roots of their own
+    {
+        bool grown = false;
+        for (uint32_t i = 0; i < nTop; i++) {
+            const pt_top_bvh_node& n = topNodes[i];
+            if (!n.isLeaf)
+                continue;
+            if (n.a >= c->numRefNodes || c->nodeRef[n.a] == kRefNone)
+                return fail(c, PT_ERR_INVALID, "top-level leaf %u: sub-BVH root %u is not a valid node", i, n.a);
+            if (sg.rootOfNode[n.a] < 0 && std::find(sg.extraRoots.begin(), sg.extraRoots.end(), n.a) == sg.extraRoots.end()) {
+                sg.extraRoots.push_back(n.a);
+                grown = true;
+            }
+        }
+        if (grown) {
+            int rc = buildStaticGeom(c);
+            if (rc)
+                return rc;
+        }
+    }
+    const uint32_t staticNodes = (uint32_t)sg.wide.size();
+    const uint32_t staticTris = c->numTris + 1u; // the caller's triangles + the all-zero one
     // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
-    std::vector<Instance> hInst;
+    std::vector<Instance>& hInst = out.instances;
+    hInst.clear();
     std::vector<uint32_t> topRef(nTop, kRefNone); // reference of top node i as a child
-    std::vector<TriIsect> baked; // world-space copies of the triangles of baked instances
-    std::vector<PairNode> bakedNodes; // ... and of their BVH nodes (boxes re-fitted around the transformed child boxes)
-    struct BakeCandidate {
-        uint32_t topNode, inst;
-    };
-    std::vector<BakeCandidate> bakeCandidates;
+    std::vector<int32_t> instRoot; // instance -> roots[] slot
     out.instanceTopNode.clear();
+    out.jobs.clear();
     uint32_t numTopInner = 0, maxBottomDepth = 0;
-    const uint32_t bottomCount = (uint32_t)c->hostBottomNodes.size();
     for (uint32_t i = 0; i < nTop; i++) {
         const pt_top_bvh_node& n = topNodes[i];
         if (n.isLeaf) {
-            if (n.a >= c->numRefNodes || c->nodeRef[n.a] == kRefNone)
-                return fail(c, PT_ERR_INVALID, "top-level leaf %u: sub-BVH root %u is not a valid node", i, n.a);
             maxBottomDepth = std::max(maxBottomDepth, c->subtreeDepth[n.a] + 1);
+            const pt_ctx::StaticGeom::Root& root = sg.roots[sg.rootOfNode[n.a]];
             Instance in {};
             const float* m = n.invTransform; // column-major
             in.r0 = make_float4(m[0], m[4], m[8], m[12]);
             in.r1 = make_float4(m[1], m[5], m[9], m[13]);
             in.r2 = make_float4(m[2], m[6], m[10], m[14]);
-            in.rootRef = c->nodeRef[n.a];
+            in.rootRef = root.ref;
             in.topNode = i;
             if (hInst.size() >= kSpecialLeaveInstance)
                 return fail(c, PT_ERR_UNSUPPORTED, "too many instances");
-            const uint32_t instIndex = (uint32_t)hInst.size();
-            topRef[i] = makeRef(instIndex, kRefSpecial);
+            topRef[i] = makeRef((uint32_t)hInst.size(), kRefSpecial);
             hInst.push_back(in);
+            instRoot.push_back(sg.rootOfNode[n.a]);
             out.instanceTopNode.push_back(i);
-            // A mesh that is a single leaf (a ground quad, an area light) is not worth an instance entry + leave
-            // per ray: its triangles are copied to world space and referenced from the top level as a plain
-            // leaf.  (t,u,v) are the same in both spaces (the reference never renormalises the transformed
-            // direction, scene.cl:118-121); k_trace maps the copy back to (original triangle, instance).
-            if (!(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES))
-                bakeCandidates.push_back({ i, instIndex });
         } else {
             if (n.a >= nTop || n.b >= nTop)
                 return fail(c, PT_ERR_INVALID, "top-level node %u: child out of range", i);
-            topRef[i] = makeRef(bottomCount + numTopInner, 0);
+            topRef[i] = makeRef(staticNodes + numTopInner, 0u);
             numTopInner++;
         }
     }
-    // ---- bake instances into world space -----------------------------------------------------------------
-    // An instance costs every ray that enters it two parked steps (transform in, restore out) on top of the
-    // traversal proper.  With 288 GB of HBM the instanced geometry of scenes like the benchmark's (12 x 82 k
-    // triangles: ~110 MB of nodes and triangles) simply fits as world-space copies, so instances are baked while
-    // a byte budget lasts -- single-leaf meshes (a ground quad, an area light) first, they cost almost nothing --
-    // and the rest stay two-level.  (t,u,v) are the same in both spaces (the reference never renormalises the
-    // transformed direction, scene.cl:118-121); k_trace maps a hit on a copy back to (original triangle,
-    // instance).  Boxes of rotated instances are re-fitted around the transformed corners: looser, still conservative.
+    out.topSlots = numTopInner;
+    // ---- instances copied to world space --------------------------------------------------------------------
+    // An instance costs every ray that enters it a transform in and a restore out on top of the traversal proper.  With 288 GB of
+    // HBM the instanced geometry of scenes like the benchmark's (12 x 82 k triangles: ~110 MB of nodes and triangles) simply fits
+    // as world-space copies, so instances are copied while a byte budget lasts -- single-leaf meshes (a ground quad, an area light)
+    // first, they cost almost nothing -- and the rest stay two-level.  (t,u,v) are the same in both spaces (the reference never
+    // renormalises the transformed direction, scene.cl:118-121); the traversal kernels map a hit on a copy back to (original
+    // triangle, instance).  The copies themselves are made on the device (pt_bake.h); this only lays them out.
     {
         const uint64_t budgetBytes = 2ull << 30;
         uint64_t usedBytes = 0;
-        const uint32_t bakedNodeBase = bottomCount + numTopInner;
-        std::stable_sort(bakeCandidates.begin(), bakeCandidates.end(), [&](const BakeCandidate& a, const BakeCandidate& b) {
-            return (refCount(hInst[a.inst].rootRef) != 0u) > (refCount(hInst[b.inst].rootRef) != 0u); // single leaves first
-        });
-        for (const BakeCandidate& bc : bakeCandidates) {
+        uint32_t nextNode = staticNodes + numTopInner, nextTri = staticTris;
+        auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
+            const pt_ctx::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
+            const bool single = root.numNodes == 0;
+            if (single != !wholeTrees)
+                return;
+            if (!single && (!root.bakeable || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))) // parity mode follows the reference to the letter
+                return;
             double w[4][8]; // [r][4..7] = row r of the world transform
-            const bool singular = !invertTransform(topNodes[bc.topNode].invTransform, w);
-            if (singular)
-                continue;
-            const uint32_t instIndex = bc.inst;
-            auto bakeTriangles = [&](uint32_t first, uint32_t cnt) -> uint32_t { // returns the reference of the copies
-                const uint32_t bakedFirst = (uint32_t)(c->hostTris.size() + baked.size());
-                for (uint32_t k = 0; k < cnt; k++) {
-                    const TriIsect& t = c->hostTris[first + k];
-                    const double v0[3] = { t.a.x, t.a.y, t.a.z }, e1[3] = { t.a.w, t.b.x, t.b.y }, e2[3] = { t.b.z, t.b.w, t.c.x };
-                    float V0[3], E1[3], E2[3];
-                    for (int r = 0; r < 3; r++) {
-                        V0[r] = (float)(w[r][4] * v0[0] + w[r][5] * v0[1] + w[r][6] * v0[2] + w[r][7]);
-                        E1[r] = (float)(w[r][4] * e1[0] + w[r][5] * e1[1] + w[r][6] * e1[2]);
-                        E2[r] = (float)(w[r][4] * e2[0] + w[r][5] * e2[1] + w[r][6] * e2[2]);
-                    }
-                    TriIsect b {};
-                    uint32_t orig = first + k;
-                    float fo, fi;
-                    std::memcpy(&fo, &orig, 4);
-                    std::memcpy(&fi, &instIndex, 4);
-                    b.a = make_float4(V0[0], V0[1], V0[2], E1[0]);
-                    b.b = make_float4(E1[1], E1[2], E2[0], E2[1]);
-                    b.c = make_float4(E2[2], fo, fi, 0.f);
-                    baked.push_back(b);
-                }
-                return makeRef(bakedFirst, cnt);
-            };
-            const uint32_t rr = hInst[instIndex].rootRef;
-            if (refCount(rr) >= 1u && refCount(rr) <= kMaxLeafTris) { // the mesh is one leaf
-                if ((uint64_t)c->hostTris.size() + baked.size() + refCount(rr) < kRefIndexMask - 4u)
-                    topRef[bc.topNode] = bakeTriangles(refIndex(rr), refCount(rr));
-                continue;
-            }
-            // parity mode follows the reference to the letter: instances are entered, not copied
-            if (refCount(rr) != 0u || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))
-                continue;
-            // whole subtree: size it first
-            uint64_t nNodes = 0, nTris = 0;
-            {
-                std::vector<uint32_t> todo { refIndex(rr) };
-                while (!todo.empty()) {
-                    const PairNode& pn = c->hostBottomNodes[todo.back()];
-                    todo.pop_back();
-                    nNodes++;
-                    for (uint32_t r : { pn.left, pn.right }) {
-                        if (r == kRefNone)
-                            continue;
-                        if (refCount(r) == 0u)
-                            todo.push_back(refIndex(r));
-                        else
-                            nTris += refCount(r);
-                    }
-                }
-            }
-            const uint64_t bytes = nNodes * (sizeof(PairNode) + sizeof(WideNode)) + nTris * sizeof(TriIsect);
-            if (usedBytes + bytes > budgetBytes || bakedNodeBase + bakedNodes.size() + nNodes >= kRefIndexMask - 4u
-                || c->hostTris.size() + baked.size() + nTris >= kRefIndexMask - 4u)
-                continue;
+            if (!invertTransform(topNodes[hInst[instIndex].topNode].invTransform, w))
+                return; // singular: stays an instance
+            const uint64_t bytes = (uint64_t)root.numNodes * sizeof(WideNode) + (uint64_t)root.numRefs * sizeof(TriIsect);
+            if ((!single && usedBytes + bytes > budgetBytes) || (uint64_t)nextNode + root.numNodes >= kRefIndexMask - 4u
+                || (uint64_t)nextTri + root.numRefs >= kRefIndexMask - 4u)
+                return;
             usedBytes += bytes;
-            // copy the subtree, parents before children (the collapse and the packing only follow references)
-            struct Item {
-                uint32_t src, dst;
-            };
-            const uint32_t rootDst = (uint32_t)bakedNodes.size();
-            bakedNodes.emplace_back();
-            std::vector<Item> todo { { refIndex(rr), rootDst } };
-            while (!todo.empty()) {
-                const Item it = todo.back();
-                todo.pop_back();
-                const PairNode& src = c->hostBottomNodes[it.src];
-                PairNode dst {};
-                const float* bx = &src.bx.x;
-                const float* by = &src.by.x;
-                const float* bz = &src.bz.x;
-                float* ox = &dst.bx.x;
-                float* oy = &dst.by.x;
-                float* oz = &dst.bz.x;
-                for (int side = 0; side < 2; side++) {
-                    const uint32_t r = side ? src.right : src.left;
-                    uint32_t& outRef = side ? dst.right : dst.left;
-                    outRef = kRefNone;
-                    ox[side * 2] = oy[side * 2] = oz[side * 2] = 1.f; // empty (inverted) box
-                    ox[side * 2 + 1] = oy[side * 2 + 1] = oz[side * 2 + 1] = -1.f;
-                    if (r == kRefNone || bx[side * 2] > bx[side * 2 + 1])
-                        continue;
-                    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
-                    for (int corner = 0; corner < 8; corner++) {
-                        const double p[3] = { bx[side * 2 + (corner & 1)], by[side * 2 + ((corner >> 1) & 1)], bz[side * 2 + ((corner >> 2) & 1)] };
-                        for (int a = 0; a < 3; a++) {
-                            const double q = w[a][4] * p[0] + w[a][5] * p[1] + w[a][6] * p[2] + w[a][7];
-                            lo[a] = std::min(lo[a], q), hi[a] = std::max(hi[a], q);
-                        }
-                    }
-                    // to float, outwards, plus an ulp for the rounding of the transformed triangles themselves
-                    float* o[3] = { ox, oy, oz };
-                    for (int a = 0; a < 3; a++) {
-                        o[a][side * 2] = std::nextafter(std::nextafter((float)lo[a], -INFINITY), -INFINITY);
-                        o[a][side * 2 + 1] = std::nextafter(std::nextafter((float)hi[a], INFINITY), INFINITY);
-                    }
-                    if (refCount(r) == 0u) {
-                        const uint32_t childDst = (uint32_t)bakedNodes.size();
-                        bakedNodes.emplace_back();
-                        outRef = makeRef(bakedNodeBase + childDst, 0u);
-                        todo.push_back({ refIndex(r), childDst });
-                    } else {
-                        outRef = bakeTriangles(refIndex(r), refCount(r));
-                    }
-                }
-                bakedNodes[it.dst] = dst;
-            }
-            topRef[bc.topNode] = makeRef(bakedNodeBase + rootDst, 0u);
+            BakeJob j {};
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 4; k++)
+                    j.m[r * 4 + k] = w[r][4 + k];
+            j.srcNode = root.nodeBase, j.numNodes = root.numNodes, j.dstNode = nextNode;
+            j.srcRef = root.refBase, j.numRefs = root.numRefs, j.dstTri = nextTri;
+            j.instance = instIndex;
+            out.jobs.push_back(j);
+            topRef[hInst[instIndex].topNode] = single ? makeRef(nextTri, refCount(root.ref)) : makeRef(nextNode, 0u);
+            nextNode += root.numNodes;
+            nextTri += root.numRefs;
+        };
+        if (!(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES)) {
+            for (uint32_t k = 0; k < hInst.size(); k++) // single leaves first
+                tryBake(k, false);
+            for (uint32_t k = 0; k < hInst.size(); k++)
+                tryBake(k, true);
         }
+        out.bakedNodes = nextNode - (staticNodes + numTopInner);
+        out.bakedTris = nextTri - staticTris;
     }
     uint32_t topDepth = 0;
     { // depth / cycle check from the root
@@ -1521,11 +1575,12 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     // one pending entry per level of either tree + the leave-instance sentinel
     if (topDepth + 1 + maxBottomDepth > (uint32_t)(kLdsStack + kSpillStack))
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kLdsStack + kSpillStack);
-    if ((uint64_t)bottomCount + numTopInner + bakedNodes.size() > kRefIndexMask)
+    if ((uint64_t)staticNodes + numTopInner + out.bakedNodes > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
-    std::vector<PairNode> hNodes = c->hostBottomNodes;
-    hNodes.resize(bottomCount + numTopInner);
-    hNodes.insert(hNodes.end(), bakedNodes.begin(), bakedNodes.end());
+    // ---- the top level: pair nodes -> 4-wide, packed breadth-first into the slots behind the static nodes -----------------
+    std::vector<PairNode> topPairs(numTopInner);
+    auto local = [&](uint32_t ref) { return refIndex(ref) - staticNodes; }; // top-level inner reference -> index into topPairs
+    auto isTopInner = [&](uint32_t ref) { return ref != kRefNone && refCount(ref) == 0u && refIndex(ref) >= staticNodes && refIndex(ref) < staticNodes + numTopInner; };
     for (uint32_t i = 0; i < nTop; i++) {
         const pt_top_bvh_node& n = topNodes[i];
         if (n.isLeaf)
@@ -1536,11 +1591,79 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         pn.bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
         pn.by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
         pn.bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
-        pn.left = topRef[n.a];
-        pn.right = topRef[n.b];
-        hNodes[refIndex(topRef[i])] = pn;
+        // inside the collapse the top-level children are indices into topPairs; every other reference is opaque to it (instance
+        // references and leaves by their count, the roots of world-space copies by an index beyond the array: they start behind the
+        // top level's slots)
+        pn.left = isTopInner(topRef[n.a]) ? makeRef(local(topRef[n.a]), 0u) : topRef[n.a];
+        pn.right = isTopInner(topRef[n.b]) ? makeRef(local(topRef[n.b]), 0u) : topRef[n.b];
+        topPairs[local(topRef[i])] = pn;
     }
-    std::vector<Light> hLights(nL);
+    const std::vector<WideKids> kids = collapseKids(topPairs);
+    // breadth-first packing of the top-level nodes the collapse kept
+    uint32_t rootRef = topRef[topRoot];
+    constexpr uint32_t kUnset = 0xFFFFFFFFu;
+    std::vector<uint32_t> newIndex(numTopInner, kUnset), order;
+    auto isKept = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < numTopInner; };
+    if (isTopInner(rootRef)) {
+        newIndex[local(rootRef)] = 0;
+        order.push_back(local(rootRef));
+        for (size_t q = 0; q < order.size(); q++)
+            for (int k = 0; k < 4; k++) {
+                const uint32_t r = kids[order[q]].ref[k];
+                if (!kids[order[q]].empty[k] && isKept(r) && newIndex[refIndex(r)] == kUnset) {
+                    newIndex[refIndex(r)] = (uint32_t)order.size();
+                    order.push_back(refIndex(r));
+                }
+            }
+        rootRef = makeRef(staticNodes, 0u);
+    }
+    out.topWide.resize(order.size());
+    out.hasInstances = refCount(rootRef) == kRefSpecial;
+    for (size_t q = 0; q < order.size(); q++) {
+        const WideKids& wk = kids[order[q]];
+        uint32_t refs[4];
+        for (int k = 0; k < 4; k++) {
+            refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(staticNodes + newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+            if (!wk.empty[k] && refCount(refs[k]) == kRefSpecial)
+                out.hasInstances = true;
+        }
+        quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[q]);
+    }
+    // ---- worst-case traversal stack: the top level on top of the deepest thing below it (an entered instance adds its sentinel)
+    std::vector<uint32_t> topNeed(order.size(), 0u);
+    // the copies' roots are looked up by node index: a map for scenes with many of them
+    std::vector<std::pair<uint32_t, uint32_t>> copyRoots;
+    for (const BakeJob& j : out.jobs)
+        if (j.numNodes)
+            copyRoots.push_back({ j.dstNode, sg.stackNeed[j.srcNode] });
+    std::sort(copyRoots.begin(), copyRoots.end());
+    auto needOf = [&](uint32_t ref) -> uint32_t {
+        if (refCount(ref) == 0u && refIndex(ref) >= staticNodes && refIndex(ref) < staticNodes + order.size())
+            return topNeed[refIndex(ref) - staticNodes];
+        if (refCount(ref) == 0u) {
+            auto it = std::lower_bound(copyRoots.begin(), copyRoots.end(), std::make_pair(refIndex(ref), 0u));
+            return it != copyRoots.end() && it->first == refIndex(ref) ? it->second : 0u;
+        }
+        if (refCount(ref) == kRefSpecial) { // an entered instance: its sentinel + its mesh tree
+            const uint32_t rr = hInst[refIndex(ref)].rootRef;
+            return 1u + (refCount(rr) == 0u ? sg.stackNeed[refIndex(rr)] : 0u);
+        }
+        return 0u;
+    };
+    for (size_t q = order.size(); q-- > 0;) {
+        uint32_t n = 0, deepest = 0;
+        for (uint32_t r : out.topWide[q].child)
+            if (r != sg.emptyRef)
+                n++, deepest = std::max(deepest, needOf(r));
+        topNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
+    }
+    const uint32_t stackNeed = needOf(rootRef);
+    if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
+    // k_trace_packet keeps its stack in the 64 lanes of a register (instance references are entered there too, pt_packet.h)
+    out.packetOk = stackNeed <= kPacketStack;
+    std::vector<Light>& hLights = out.lights;
+    hLights.resize(nL);
     for (uint32_t i = 0; i < nL; i++) {
         const pt_emissive_triangle& e = lights[i];
         const V3 v0 = mk(e.vertices[0][0], e.vertices[0][1], e.vertices[0][2]);
@@ -1558,95 +1681,17 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         hLights[i].normal = make_float4(nrm.x, nrm.y, nrm.z, 0.f);
         hLights[i].colour = make_float4(e.material.u.emissive.emissiveColour[0], e.material.u.emissive.emissiveColour[1], e.material.u.emissive.emissiveColour[2], 0.f);
     }
-    std::vector<TriIsect> allTris = c->hostTris;
-    allTris.insert(allTris.end(), baked.begin(), baked.end());
-    // one all-zero triangle (det == 0: never hit) for the unused child slots of the 4-wide nodes to refer to
-    if (allTris.size() >= kRefIndexMask - 2u)
-        return fail(c, PT_ERR_UNSUPPORTED, "pt_upload_dynamic: too many triangle references");
-    const uint32_t emptyRef = makeRef((uint32_t)allTris.size(), 1u);
-    allTris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) });
-    const std::vector<WideNode> hWide = collapseToWide(hNodes, emptyRef);
-    const uint32_t stackNeed = wideStackNeed(hWide, hInst, topRef[topRoot], emptyRef);
-    if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
-        return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
-    // k_trace_packet walks one world-space tree: no instance left to enter, the root an inner node, 64 stack entries
-    out.packetOk = stackNeed <= kPacketStack && refCount(topRef[topRoot]) == 0u;
-    for (const WideNode& w : hWide)
-        for (int k = 0; k < 4; k++)
-            if (refCount(w.child[k]) == kRefSpecial)
-                out.packetOk = false;
-    // ---- pack the 4-wide nodes: only the ones the collapse kept (about half of the pair-node indices), each node's
-    // children next to each other, level by level from every root -- half the footprint in the 4 MB-per-XCD L2 and
-    // sibling nodes share 128-byte lines
-    uint32_t packedRoot = topRef[topRoot];
-    std::vector<WideNode> packed;
-#if PT_PACK_WIDE
-    {
-        constexpr uint32_t kUnset = 0xFFFFFFFFu;
-        std::vector<uint32_t> newIndex(hWide.size(), kUnset), order;
-        auto isInner = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < hWide.size(); };
-        auto visit = [&](uint32_t ref) {
-            if (isInner(ref) && newIndex[refIndex(ref)] == kUnset) {
-                newIndex[refIndex(ref)] = (uint32_t)order.size();
-                order.push_back(refIndex(ref));
-            }
-        };
-        visit(packedRoot);
-        for (const Instance& in : hInst)
-            visit(in.rootRef);
-        for (size_t q = 0; q < order.size(); q++) // breadth first: the four children of a node get consecutive slots
-            for (uint32_t r : hWide[order[q]].child)
-                visit(r);
-        auto remap = [&](uint32_t r) { return isInner(r) ? makeRef(newIndex[refIndex(r)], 0u) : r; };
-        packed.resize(order.size());
-        for (size_t q = 0; q < order.size(); q++) {
-            packed[q] = hWide[order[q]];
-            for (uint32_t& r : packed[q].child)
-                r = remap(r);
-        }
-        for (Instance& in : hInst)
-            in.rootRef = remap(in.rootRef);
-        packedRoot = remap(packedRoot);
-    }
-#else
-    packed = hWide;
-#endif
-    // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h), from the host copies of the
-    // vertex / index / intersection arrays -- which pt_update_geometry has already replaced when this state is a refitted one
-    out.fat.resize(c->hostTriShade.size());
-    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
-        const TriShade& ts = c->hostTriShade[t];
-        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
-        const TriIsect& ti = c->hostTris[t];
-        TriFat f {};
-        f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
-        float mbits;
-        std::memcpy(&mbits, &ts.material, 4);
-        f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
-        f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
-        f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
-        float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
-        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
-        f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
-        f.mat = make_float4(m[4], m[5], m[6], m[8]);
-        out.fat[t] = f;
-    }
-    out.tris = std::move(allTris);
-    out.wide = std::move(packed);
-    out.instances = std::move(hInst);
-    out.lights = std::move(hLights);
     out.numLights = nL;
-    out.rootRef = packedRoot;
+    out.rootRef = rootRef;
     return PT_OK;
 }
 
 template <typename T>
-int growTo(pt_ctx* c, DevBuf<T>& buf, size_t count, bool* reallocated)
+int growTo(pt_ctx* c, DevBuf<T>& buf, size_t count)
 {
     if (buf.n >= std::max<size_t>(count, 1))
         return PT_OK;
-    *reallocated = true;
-    HIPCHK(c, buf.alloc(std::max<size_t>(count + count / 8, 1))); // some headroom: the baked copies vary from state to state
+    HIPCHK(c, buf.alloc(std::max<size_t>(count + count / 8, 1))); // some headroom: the number of world-space copies varies from state to state
     return PT_OK;
 }
 
@@ -1654,8 +1699,10 @@ int growTo(pt_ctx* c, DevBuf<T>& buf, size_t count, bool* reallocated)
 
 extern "C" {
 
-// Convert the next dynamic state on the host and start copying it into the INACTIVE set on the copy stream; returns without
-// waiting for the device.  Renders already enqueued (and any enqueued before the next pt_frame_tick) keep using the active set.
+// Convert the next dynamic state on the host -- the top level, the instance table, the lights: the trees below are static -- and
+// start putting it into the INACTIVE set on the copy stream (a few KB of copies and, where instances are copied to world space, two
+// kernels); returns without waiting for the device.  Renders already enqueued (and any enqueued before the next pt_frame_tick)
+// keep using the active set.
 int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot)
 {
     return guarded(c, "pt_upload_dynamic_async", [&]() -> int {
@@ -1669,53 +1716,91 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
     HIPCHK(c, hipSetDevice(c->device));
     DynamicHost h;
-    int rc = convertDynamic(c, lights, nL, topNodes, nTop, topRoot, h); // "Lot of CPU work" (raytracer.cpp:185): the GPU keeps rendering
-    if (rc)
+    int rc = convertDynamic(c, lights, nL, topNodes, nTop, topRoot, h);
+    if (rc || (rc = uploadStaticGeom(c)))
         return rc;
+    pt_ctx::StaticGeom& sg = c->sg;
     const int target = c->haveDynamic ? 1 - c->active : c->active; // nothing active yet: fill the active set itself
     pt_ctx::DynamicSet& d = c->dyn[target];
-    // the copy may not start before the renders that still read this set are done (it was the active set until the last tick),
+    // the copies may not start before the renders that still read this set are done (it was the active set until the last tick),
     // nor before an earlier, never-adopted upload into it has finished (same stream: ordered)
     if (d.used)
         HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
-    bool reallocated = false;
-    const size_t need[5] = { h.wide.size() * sizeof(WideNode), h.tris.size() * sizeof(TriIsect), h.instances.size() * sizeof(Instance),
-        h.lights.size() * sizeof(Light), h.fat.size() * sizeof(TriFat) };
-    const size_t total = need[0] + need[1] + need[2] + need[3] + need[4];
-    if (d.wide.n < h.wide.size() || d.tris.n < h.tris.size() || d.fat.n < h.fat.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1) || d.lights.n < std::max<size_t>(h.lights.size(), 1)
-        || d.stageBytes < total) {
+    const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->numTris + 1;
+    const size_t needWide = staticNodes + h.topSlots + h.bakedNodes, needTris = staticTris + h.bakedTris;
+    const size_t bytes[4] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
+        h.jobs.size() * sizeof(BakeJob) };
+    const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3];
+    if (d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1)
+        || d.lights.n < std::max<size_t>(h.lights.size(), 1) || d.jobs.n < std::max<size_t>(h.jobs.size(), 1) || d.stageBytes < std::max<size_t>(total, 1)) {
         // growing frees device memory, which the runtime only does once nothing uses it: wait for both streams (rare: the first
         // uploads, or a state with more world-space copies than any before)
         HIPCHK(c, hipStreamSynchronize(c->copyStream));
         if (d.used)
             HIPCHK(c, hipEventSynchronize(d.lastUse));
-        if ((rc = growTo(c, d.wide, h.wide.size(), &reallocated)) || (rc = growTo(c, d.tris, h.tris.size(), &reallocated)) || (rc = growTo(c, d.fat, h.fat.size(), &reallocated))
-            || (rc = growTo(c, d.instances, h.instances.size(), &reallocated)) || (rc = growTo(c, d.lights, h.lights.size(), &reallocated)))
+        const bool regrown = d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size();
+        if ((rc = growTo(c, d.wide, needWide)) || (rc = growTo(c, d.tris, needTris)) || (rc = growTo(c, d.fat, sg.fat.size()))
+            || (rc = growTo(c, d.instances, h.instances.size())) || (rc = growTo(c, d.lights, h.lights.size())) || (rc = growTo(c, d.jobs, h.jobs.size())))
             return rc;
-        if (d.stageBytes < total) {
+        if (regrown)
+            d.staticVersion = 0; // fresh buffers: the static arrays have to be put in again
+        if (d.stageBytes < std::max<size_t>(total, 1)) {
             if (d.stage)
                 (void)hipHostFree(d.stage);
             d.stage = nullptr;
-            d.stageBytes = total + total / 8;
+            d.stageBytes = total + total / 8 + 4096;
             HIPCHK(c, hipHostMalloc(&d.stage, d.stageBytes, hipHostMallocDefault));
+            d.stageBusy = false;
         }
-    } else {
-        HIPCHK(c, hipStreamSynchronize(c->copyStream)); // the staging memory of this set is about to be rewritten
+    }
+    if (d.stageBusy) { // the staging memory of this set is about to be rewritten: its last copies (two ticks ago) must have been read
+        HIPCHK(c, hipEventSynchronize(d.stageRead));
+        d.stageBusy = false;
+    }
+    if (d.staticVersion != sg.version) { // device to device, from the master copy
+        if (staticNodes)
+            HIPCHK(c, hipMemcpyAsync(d.wide.p, sg.dWide.p, staticNodes * sizeof(WideNode), hipMemcpyDeviceToDevice, c->copyStream));
+        HIPCHK(c, hipMemcpyAsync(d.tris.p, sg.dTris.p, staticTris * sizeof(TriIsect), hipMemcpyDeviceToDevice, c->copyStream));
+        if (!sg.fat.empty())
+            HIPCHK(c, hipMemcpyAsync(d.fat.p, sg.dFat.p, sg.fat.size() * sizeof(TriFat), hipMemcpyDeviceToDevice, c->copyStream));
+        d.staticVersion = sg.version;
     }
     unsigned char* st = (unsigned char*)d.stage;
-    const void* src[5] = { h.wide.data(), h.tris.data(), h.instances.data(), h.lights.data(), h.fat.data() };
-    void* dst[5] = { d.wide.p, d.tris.p, d.instances.p, d.lights.p, d.fat.p };
-    for (int k = 0; k < 5; k++) {
-        if (need[k] == 0)
+    const void* src[4] = { h.topWide.data(), h.instances.data(), h.lights.data(), h.jobs.data() };
+    void* dst[4] = { d.wide.p + staticNodes, d.instances.p, d.lights.p, d.jobs.p };
+    for (int k = 0; k < 4; k++) {
+        if (bytes[k] == 0)
             continue;
-        std::memcpy(st, src[k], need[k]);
-        HIPCHK(c, hipMemcpyAsync(dst[k], st, need[k], hipMemcpyHostToDevice, c->copyStream));
-        st += need[k];
+        std::memcpy(st, src[k], bytes[k]);
+        HIPCHK(c, hipMemcpyAsync(dst[k], st, bytes[k], hipMemcpyHostToDevice, c->copyStream));
+        st += bytes[k];
+    }
+    if (total) {
+        HIPCHK(c, hipEventRecord(d.stageRead, c->copyStream));
+        d.stageBusy = true;
+    }
+    if (!h.jobs.empty()) { // the world-space copies: one thread per (copy, node) and per (copy, triangle reference)
+        BakeArgs ba {};
+        ba.srcWide = sg.dWide.p, ba.srcBoxes = sg.dBoxes.p, ba.srcLeafOfs = sg.dLeafOfs.p, ba.refTri = sg.dRefTri.p, ba.srcTris = sg.dTris.p;
+        ba.dstWide = d.wide.p, ba.dstTris = d.tris.p, ba.emptyRef = sg.emptyRef;
+        for (size_t first = 0; first < h.jobs.size(); first += 32768) {
+            const uint32_t n = (uint32_t)std::min<size_t>(32768, h.jobs.size() - first);
+            uint32_t maxNodes = 0, maxRefs = 0;
+            for (uint32_t k = 0; k < n; k++)
+                maxNodes = std::max(maxNodes, h.jobs[first + k].numNodes), maxRefs = std::max(maxRefs, h.jobs[first + k].numRefs);
+            ba.jobs = d.jobs.p + first;
+            if (maxNodes)
+                hipLaunchKernelGGL(k_bake_nodes, dim3((maxNodes + 127) / 128, n), dim3(128), 0, c->copyStream, ba);
+            if (maxRefs)
+                hipLaunchKernelGGL(k_bake_tris, dim3((maxRefs + 255) / 256, n), dim3(256), 0, c->copyStream, ba);
+        }
+        HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(d.uploaded, c->copyStream));
     d.numLights = h.numLights;
     d.rootRef = h.rootRef;
     d.packetOk = h.packetOk;
+    d.hasInstances = h.hasInstances;
     d.instanceTopNode = std::move(h.instanceTopNode);
     c->pending = target;
     return PT_OK;
@@ -1843,6 +1928,8 @@ int pt_set_tiles(pt_ctx* c, const pt_rect* rects, uint32_t n)
         if (!ok)
             return fail(c, PT_ERR_INVALID, "pt_set_tiles: rect %u overlaps an earlier one", r);
     }
+    if (c->queuesReady && list == c->hostPixelList)
+        return PT_OK; // the same pixels in the same order: queues, planes and ordinals stay as they are
     c->identityPixels = rowMajor && n == 1 && rects[0].x0 == 0 && rects[0].y0 == 0 && rects[0].x1 == W && rects[0].y1 == H;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc = uploadVec(c, c->pixelList, list);
@@ -1853,6 +1940,7 @@ int pt_set_tiles(pt_ctx* c, const pt_rect* rects, uint32_t n)
     } else if ((rc = uploadVec(c, c->pixelOrdinal, ordinal)))
         return rc;
     c->numOwned = (uint32_t)list.size();
+    c->hostPixelList = std::move(list);
     c->queuesReady = false; // the ordinal of a pixel may have changed: queues and planes are re-made lazily (ensureQueues)
     return PT_OK;
     });
@@ -1874,6 +1962,9 @@ int pt_clear(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)c->cfg.width * c->cfg.height * sizeof(float4), c->stream));
+    if (c->foldPlanes > 1 && c->accumPlanes.p) // samples of a pt_render that failed half-way: not to be folded into the fresh accumulator
+        HIPCHK(c, hipMemsetAsync(c->accumPlanes.p, 0, c->accumPlanes.n * sizeof(float4), c->stream));
+    c->foldPlanes = 0;
     c->spp = 0;
     if (parityMode(c) && c->queuesReady) {
         int rc = resetStreams(c);
@@ -1901,8 +1992,10 @@ int pt_render(pt_ctx* c, uint32_t spp)
     for (uint32_t s = 0; s < spp;) {
         const uint32_t batch = fixedSchedule ? std::min(c->planes, spp - s) : 1u;
         rc = fixedSchedule ? renderSampleFixed(c, c->spp, batch, prof) : renderSampleRefill(c, c->spp);
-        if (rc)
+        if (rc) {
+            foldPlanesNow(c); // what the earlier batches of this call deposited belongs to the samples already counted
             return rc;
+        }
         c->spp += batch;
         s += batch;
     }
@@ -1951,13 +2044,14 @@ int pt_resolve(pt_ctx* c, float* rgba_out)
 
 int pt_resolve_device(pt_ctx* c, void* device_rgba)
 {
+    return guarded(c, "pt_resolve_device", [&]() -> int {
     if (!c)
         return PT_ERR_INVALID;
     if (!c->haveCamera || c->spp == 0)
         return fail(c, PT_ERR_STATE, "pt_resolve_device: nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n = c->cfg.width * c->cfg.height;
-    if (!device_rgba) {
+    if (!device_rgba) { // the context's own image (pt_resolve_device_ptr)
         if (c->resolveTmp.n != n)
             HIPCHK(c, c->resolveTmp.alloc(n));
         device_rgba = c->resolveTmp.p;
@@ -1966,7 +2060,12 @@ int pt_resolve_device(pt_ctx* c, void* device_rgba)
         c->camera.relativeAperture, c->camera.shutterTime, c->camera.ISO);
     HIPCHK(c, hipGetLastError());
     return PT_OK;
+    });
 }
+
+// the image pt_resolve_device(ctx, NULL) writes: width * height float4, valid once the render stream has passed that call; NULL before
+// the first one
+void* pt_resolve_device_ptr(pt_ctx* c) { return c ? (void*)c->resolveTmp.p : nullptr; }
 
 int pt_read_accum(pt_ctx* c, float* out)
 {

@@ -191,6 +191,8 @@ int pth_mesh_refit(pth_mesh* m, const float* positions, const float* normals)
 int pth_image_load_material_png_bgra8(const char* path, uint32_t width, uint32_t height, int isLinear, uint8_t* bgra_out)
 {
     return guarded([&] {
+        if (!path || !bgra_out)
+            throw std::invalid_argument("pth_image_load_material_png_bgra8: null argument");
         const ImageRGBA8 img = loadMaterialLayerBGRA8(path, width, height, isLinear != 0);
         std::memcpy(bgra_out, img.rgba.data(), img.rgba.size());
     });

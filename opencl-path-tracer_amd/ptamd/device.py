@@ -60,7 +60,7 @@ class ShadeBatchIO(C.Structure):
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_upload_static", "pt_upload_dynamic",
            "pt_upload_dynamic_async", "pt_frame_tick", "pt_update_geometry",
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
-           "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
+           "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
            "pt_intersect", "pt_gen_rays", "pt_shade_batch", "pt_version"]
 
@@ -101,6 +101,8 @@ def lib():
         l.pt_synchronize.argtypes = [C.c_void_p]
         l.pt_resolve.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_resolve_device.argtypes = [C.c_void_p, C.c_void_p]
+        l.pt_resolve_device_ptr.restype = C.c_void_p
+        l.pt_resolve_device_ptr.argtypes = [C.c_void_p]
         l.pt_read_accum.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_write_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         l.pt_accum_device_ptr.restype = C.c_void_p
@@ -245,6 +247,11 @@ class Context:
     def resolve_device(self, device_ptr=None):
         """accumulate kernel into device memory (None: a buffer owned by the context); asynchronous."""
         self._chk(lib().pt_resolve_device(self._h, C.c_void_p(device_ptr) if device_ptr else None), "pt_resolve_device")
+
+    @property
+    def resolve_device_ptr(self):
+        """Device address of the image resolve_device(None) writes (0 before the first such call)."""
+        return lib().pt_resolve_device_ptr(self._h) or 0
 
     @property
     def samples_per_pixel(self):

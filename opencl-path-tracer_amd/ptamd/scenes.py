@@ -219,7 +219,7 @@ def blob_room(width=1920, height=1080, material=None, builder=H.BVH_BINNED_SAH, 
 
 
 def instanced_grid(width=1920, height=1080, nx=4, nz=3, level=6, builder=H.BVH_SPATIAL_SPLIT, thin_lens=False,
-                   sky_size=(2048, 1024)):
+                   sky_size=(2048, 1024), rotate=False):
     """Configs 4/5: nx*nz instances (translate + uniform scale only) of two unique
     ~82k-triangle meshes (copper PBR metal, main.cpp:149-151, alternating with a PBR dielectric) on a
     ground quad, procedural HDR sky + one small emissive quad (quirk 4).  4x3 -> 983 040 instanced
@@ -244,10 +244,42 @@ def instanced_grid(width=1920, height=1080, nx=4, nz=3, level=6, builder=H.BVH_S
             s = float(1.0 + 0.35 * rng.random())
             x = (ix - (nx - 1) / 2) * 1.5
             z = (iz - (nz - 1) / 2) * 1.5
-            scene.add_node(meshes[k % 2], location=(x, 0.62 * s, z), scale=(s, s, s))
+            q = (1, 0, 0, 0)
+            if rotate:  # a random rotation per instance (tests: world-space boxes re-fitted, packets that change octant inside an instance)
+                axis = rng.normal(size=3)
+                axis /= np.linalg.norm(axis)
+                ang = rng.uniform(0, 2 * np.pi)
+                q = (float(np.cos(ang / 2)), *(float(c) for c in np.sin(ang / 2) * axis))
+            scene.add_node(meshes[k % 2], location=(x, 0.62 * s, z), orientation_wxyz=q, scale=(s, s, s))
             k += 1
     eye, target = (0.0, 2.6, -5.2), (0.0, 0.5, 0.0)
     cam = _camera(width, height, eye, target, 60.0, thin_lens=thin_lens, focal_length_mm=50.0,
                   aperture_fstops=2.0 if thin_lens else 8.0)
     sky = procedural_sky(*sky_size)
     return SceneBundle(scene, cam, width, height, sky=sky, name=f"instanced_grid_{nx}x{nz}")
+
+
+def instance_field(width=1920, height=1080, n=1000, level=3, seed=9, builder=H.BVH_BINNED_SAH, sky_size=(256, 128)):
+    """Many instances of a small mesh: n randomly placed, rotated and scaled copies of a 20 * 4^level-triangle blob
+    (level 3: 1 280 triangles, n = 1000 -> 1.28 M instanced triangles) over a ground quad -- the top-level tree is the deep one here."""
+    mesh = blob_mesh(L.material_pbr_dielectric((0.7, 0.3, 0.2), 0.6), level=level, seed=3, builder=builder)
+    scene = H.Scene()
+    mb = _MeshBuilder()
+    ext = 0.5 * n ** 0.5 + 2
+    mb.add_quad((-ext, 0, -ext), (-ext, 0, ext), (ext, 0, ext), (ext, 0, -ext), 0)
+    scene.add_node(mb.build([L.material_diffuse((0.6, 0.6, 0.6))], H.BVH_BINNED_SAH))
+    lb = _MeshBuilder()
+    lb.add_quad((-1.5, 0, -1.5), (1.5, 0, -1.5), (1.5, 0, 1.5), (-1.5, 0, 1.5), 0)
+    scene.add_node(lb.build([L.material_emissive((1.0, 0.9, 0.75), 40.0)], H.BVH_BINNED_SAH), location=(0.0, 6.0, 0.0))
+    rng = np.random.default_rng(seed)
+    side = 0.45 * n ** 0.5
+    for _ in range(n):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0, 2 * np.pi)
+        q = (float(np.cos(ang / 2)), *(float(c) for c in np.sin(ang / 2) * axis))
+        s = float(rng.uniform(0.5, 1.1))
+        scene.add_node(mesh, location=(float(rng.uniform(-side, side)), float(rng.uniform(0.4, 2.5)), float(rng.uniform(-side, side))),
+                       orientation_wxyz=q, scale=(s, s, s))
+    cam = _camera(width, height, (0.0, 4.0, -1.1 * side - 4.0), (0.0, 1.0, 0.0), 55.0)
+    return SceneBundle(scene, cam, width, height, sky=procedural_sky(*sky_size), name=f"instance_field_{n}")

@@ -38,13 +38,15 @@ def tri_vertex_ids(flat, prim):
     return np.sort(flat.triangles["indices"][prim], axis=1)
 
 
-def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0, t_outlier_frac=0.0):
+def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0, t_outlier_frac=0.0, uv_atol=5e-3):
     """hit/miss identical; t/u/v within tolerance; (prim, inst) identical except where two primitives are
     hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t.
     `t_outlier_frac` > 0 (deformed meshes: twisted triangles become slivers, and t of a hit that grazes a sliver is ill-conditioned)
     tolerates that fraction of rays beyond t_rtol, each within 1 %.
     `edge_flip_frac` > 0 (world-space copies of instances: triangle edges are rounded in another space than the
-    reference's) tolerates that fraction of hit/miss disagreements, each of which must graze a triangle edge."""
+    reference's) tolerates that fraction of hit/miss disagreements, each of which must graze a triangle edge.
+    `uv_atol`: barycentrics are compared through the hit point they encode; the direct bound on u and v is loose (they are
+    ill-conditioned for small or distant triangles: 5e-3 by default, more for scenes of tiny triangles seen from afar)."""
     gh, wh = got["prim"] >= 0, want["prim"] >= 0
     flips = gh != wh
     edge_flips = 0
@@ -60,16 +62,24 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac
     both = gh & wh
     dt = np.abs(got["t"][both] - want["t"][both]) / np.maximum(np.abs(want["t"][both]), 1e-6)
     bad = ~np.isclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=1e-6)
-    assert bad.mean() <= t_outlier_frac and (not bad.any() or dt[bad].max() < 1e-2), f"t differs for {bad.sum()} of {both.sum()} rays, worst {dt.max():.3e}"
+    assert bad.mean() <= t_outlier_frac, f"t differs for {bad.sum()} of {both.sum()} rays, worst {dt.max():.3e}"
+    for k in np.flatnonzero(bad):  # a tolerated outlier is within 1 %, or its NEARER hit grazes a triangle edge (the other side missed that
+        if dt[k] < 1e-2:           # triangle by round-off and reports what lies behind it)
+            continue
+        h = got if got["t"][both][k] < want["t"][both][k] else want
+        u, v = float(h["u"][both][k]), float(h["v"][both][k])
+        assert min(abs(u), abs(v), abs(1.0 - u - v)) < 2e-3, f"t differs by {dt[k]:.2e} away from any edge (u={u}, v={v})"
     same_geom = np.all(tri_vertex_ids(flat, got["prim"][both]) == tri_vertex_ids(flat, want["prim"][both]), axis=1)
     same = same_geom & (got["inst"][both] == want["inst"][both])
     assert (~same).mean() <= max_tie_frac, f"{(~same).sum()} of {both.sum()} rays hit a different primitive"
     # a different primitive is only legitimate as a tie: coincident / edge-sharing triangles hit at the same t
     # (which one is reported depends on the visit order, which is ours -- see pt_trace.h)
+    same = same | bad  # (the tolerated t outliers hit what lies behind a gap: another primitive at another distance)
     tie_dt = np.abs(got["t"][both][~same] - want["t"][both][~same]) / np.maximum(want["t"][both][~same], 1e-6)
     assert tie_dt.size == 0 or tie_dt.max() < 2e-5, f"different primitive at a different distance: {tie_dt.max():.2e}"
     # barycentrics: compared through the hit point they encode (object space), v0 + u*e1 + v*e2, because
     # u and v of a grazing hit are ill-conditioned (errors scale with 1/det) while the point is not
+    same = same & ~bad
     tri = flat.triangles["indices"][want["prim"][both][same]]
     p0, p1, p2 = (flat.vertices["vertex"][tri[:, k], :3].astype(np.float64) for k in range(3))
 
@@ -78,8 +88,8 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac
         return p0 + u * (p1 - p0) + v * (p2 - p0)
     extent = float(np.abs(flat.vertices["vertex"][:, :3]).max())
     assert np.abs(point(got) - point(want)).max() < 2e-4 * max(extent, 1.0)
-    assert np.allclose(got["u"][both][same], want["u"][both][same], atol=5e-3)
-    assert np.allclose(got["v"][both][same], want["v"][both][same], atol=5e-3)
+    assert np.allclose(got["u"][both][same], want["u"][both][same], atol=uv_atol)
+    assert np.allclose(got["v"][both][same], want["v"][both][same], atol=uv_atol)
     return dict(flips=int(flips.sum()), ties=int((~same).sum()), n=int(both.sum()), edge_flips=edge_flips)
 
 

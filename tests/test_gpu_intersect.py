@@ -12,17 +12,24 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["two_level", "baked", "packet"]
+MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet"]
 
 
 def _flags(gpu, mode):
-    """two_level: instances are entered like the reference does; baked: copied to world space (the default);
-    packet: baked, and pt_intersect runs the packet traversal kernel (one wave walks the tree once for 64 rays)."""
-    return {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "baked": 0, "packet": gpu.FLAG_PACKET_INTERSECT}[mode]
+    """two_level: instances are entered like the reference does (meshes that are a single leaf are still copied); unbaked: every
+    instance is entered; baked: copied to world space (the default); *packet: pt_intersect runs the packet traversal kernel
+    (one wave walks the tree once for 64 rays) -- on the world-space tree, or entering instances as a wave."""
+    return {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "baked": 0, "packet": gpu.FLAG_PACKET_INTERSECT,
+            "two_level_packet": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PACKET_INTERSECT, "unbaked": gpu.FLAG_NO_BAKED_INSTANCES,
+            "unbaked_packet": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PACKET_INTERSECT}[mode]
+
+
+def _entered(mode):
+    return mode.startswith(("two_level", "unbaked"))
 
 
 def _check_kernel_used(ctx, mode):
-    assert (ctx.stats()["packet_launches"] > 0) == (mode == "packet"), "wrong traversal kernel ran"
+    assert (ctx.stats()["packet_launches"] > 0) == mode.endswith("packet"), "wrong traversal kernel ran"
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -33,7 +40,7 @@ def test_golden_closest_and_any_hit(gpu, golden, name, mode):
     triangle edge is then rounded in world space, so a ray within round-off of an edge may change sides -- at most
     5e-4 of the rays, each verified to graze an edge.  The packet kernel tests, per ray, the same boxes and triangles
     with the same arithmetic as the per-ray kernel on the baked tree."""
-    two_level = mode == "two_level"
+    two_level = _entered(mode)
     flat, cam, sky, tex = golden_io.scene_inputs(golden, name)
     ctx = U.make_ctx(gpu, flat, 64, 36, camera=cam, sky=sky, tex=tex, flags=_flags(gpu, mode))
     o, d = golden[f"isect_{name}_o"], golden[f"isect_{name}_d"]
@@ -52,9 +59,12 @@ def test_golden_closest_and_any_hit(gpu, golden, name, mode):
 
 @pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
 @pytest.mark.parametrize("mode", MODES)
-def test_random_rays_two_level(gpu, builder, mode):
-    two_level = mode == "two_level"
-    b = scenes.instanced_grid(64, 36, level=4, builder=builder, sky_size=(16, 8))
+@pytest.mark.parametrize("rotate", [False, True])
+def test_random_rays_two_level(gpu, builder, mode, rotate):
+    if rotate and builder != H.BVH_SPATIAL_SPLIT:
+        pytest.skip("rotated instances: one builder is enough")
+    two_level = _entered(mode)
+    b = scenes.instanced_grid(64, 36, level=4, builder=builder, sky_size=(16, 8), rotate=rotate)
     ctx = U.make_ctx(gpu, b, 64, 36, flags=_flags(gpu, mode))
     sc = U.oracle_scene(b)
     o, d = U.random_rays(60000, 5, (-4, 0.05, -4), (4, 3, 4))
@@ -107,17 +117,21 @@ def test_edge_cases(gpu, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated"])
 @pytest.mark.parametrize("thin", [False, True])
-def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin):
+def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin, kind):
     """Closest-hit packets whose 64 rays point into one octant are walked with ONE conservative beam test per node
     (pt_packet.h) instead of 64 ray tests.  The beam may enter boxes no ray enters, never skip one a ray enters, and
     the triangle tests are the per-ray kernel's: hits must be identical (same triangle, same t / u / v bits) except
     at exact-t ties (duplicated SBVH references).  Three packet shapes: the samples of one pixel (a thin beam), 64 neighbouring pixels (a wide
     one), and packets that mix rays of distant pixels (many straddle an octant boundary: the per-lane fallback)."""
     W, Hh = 256, 144
-    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=thin, sky_size=(16, 8))
-    packet = U.make_ctx(gpu, b, W, Hh, flags=gpu.FLAG_PACKET_INTERSECT)
-    per_ray = U.make_ctx(gpu, b, W, Hh)
+    # two_level / unbaked_rotated: the packet enters instances as a wave (ray transformed per lane, beam rebuilt in the instance's
+    # space); with rotated instances some packets point into more than one octant after the transform and start over per lane
+    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=thin, sky_size=(16, 8), rotate=kind == "unbaked_rotated")
+    base = {"baked": 0, "two_level": gpu.FLAG_TWO_LEVEL_ONLY, "unbaked_rotated": gpu.FLAG_NO_BAKED_INSTANCES}[kind]
+    packet = U.make_ctx(gpu, b, W, Hh, flags=base | gpu.FLAG_PACKET_INTERSECT)
+    per_ray = U.make_ctx(gpu, b, W, Hh, flags=base)
     rows = []
     for sample in range(4):
         o, d, _ = per_ray.gen_rays(sample, W * Hh)
@@ -144,6 +158,35 @@ def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin):
     assert packet.stats()["packet_launches"] > 0 and per_ray.stats()["packet_launches"] == 0
     packet.close()
     per_ray.close()
+
+
+@pytest.mark.parametrize("mode", ["baked", "unbaked", "unbaked_packet"])
+def test_thousand_instances_of_a_small_mesh(gpu, mode):
+    """1 000 rotated, scaled instances of a 1 280-triangle mesh (1.28 M instanced triangles): here the TOP level is the deep tree
+    (a ray crosses many instance boxes).  Camera-like and random rays against the oracle, closest hit and any hit."""
+    W, Hh = 256, 144
+    b = scenes.instance_field(W, Hh, n=1000, level=3)
+    ctx = U.make_ctx(gpu, b, W, Hh, flags=_flags(gpu, mode))
+    sc = U.oracle_scene(b)
+    o1, d1, _ = ctx.gen_rays(0, W * Hh)
+    side = 0.45 * 1000 ** 0.5
+    o2, d2 = U.random_rays(40000, 11, (-side, 0.05, -side), (side, 4, side))
+    for o, d in ((o1, d1), (o2, d2)):
+        got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
+        # world-space copies of ROTATED instances: a ray through the gap round-off opens at a shared edge hits what lies behind
+        # (the copy's edges are rounded in another space than the reference's): a handful of rays, t within 1 %
+        # (2 cm triangles up to 40 units away: u and v themselves are only good to a few percent, the hit point they encode to 2e-4)
+        # and a ray that grazes one of them may miss it on one side (the ray is taken into the instance with FMAs here, without in the
+        # oracle) and report the triangle behind: a handful of rays, each checked to graze an edge
+        info = U.compare_hits(b.flat, got, want, edge_flip_frac=5e-4, t_outlier_frac=5e-4, uv_atol=5e-2)
+        assert info["n"] > 10000 and info["flips"] == 0
+        slack = int(5e-4 * len(o))
+        tmax = np.random.default_rng(2).uniform(0.05, 12, len(o)).astype(np.float32)
+        occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
+        ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
+        assert (occ != ref).sum() <= 3 + info["edge_flips"] + slack
+    _check_kernel_used(ctx, mode)
+    ctx.close()
 
 
 def test_invalid_scenes_are_rejected_not_traversed(gpu):
