@@ -615,6 +615,10 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
             "algorithmic_bytes_per_unit": dk["algorithmic_bytes_per_unit"], "units_per_launch": dk["units_per_launch"],
             "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
             "valu_issue_frac": dk.get("valu_issue_frac"), "issue_model": (tj or {}).get("issue_model"),
+            # counters, next to the modelled fraction: rocprof's VALUBusy (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles) and what the resident
+            # waves were doing (SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES), from the committed PMC passes
+            "valu_busy": dk.get("valu_busy"), "valu_active_lanes": dk.get("valu_active_lanes"),
+            "wave_cycles_issuing": dk.get("wave_cycles_issuing"), "wave_cycles_waiting": dk.get("wave_cycles_waiting"),
             "mrays_per_s_in_kernel": round(ps["rays_extension"] / ps["ms_intersect"] / 1e3, 1),
             "kernels": kernels,
             "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),

@@ -169,6 +169,7 @@ typedef struct {
     double ms_packet; /* the part of ms_intersect spent in the packet traversal kernel */
     uint64_t deposits_shadow; /* the part of `deposits` made by the any-hit traversal (unoccluded shadow rays,
                                  kernel.cl:132-135); the rest are emissive hits and sky misses in shade */
+    uint64_t gen_launches; /* launches of the primary-ray kernel (generatePrimaryRays); 0 where the packet traversal kernel generates the camera rays itself */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

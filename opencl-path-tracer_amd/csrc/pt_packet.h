@@ -166,7 +166,9 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
     // size come from the queue cursor: one atomic per span, well under what a device-scope word sustains (pt_trace.h).
     // Consecutive packets are neighbouring pixels, so a wave keeps finding its nodes in the scalar cache and L2, and
     // no wave is left with a long static tail while others idle.
-    constexpr uint32_t kSpan = PT_PACKET_DYNAMIC;
+    // (a launch with fewer packets than that per wave -- the 14 400 8x8-pixel packets of a 1-spp 1280 x 720 frame for 8 192 waves -- deals
+    // them one at a time, so that every wave works: with 16 per claim 900 waves walked 16 packets each while 7 300 watched)
+    const uint32_t kSpan = min((uint32_t)PT_PACKET_DYNAMIC, max(1u, packets / totalWaves));
     uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
     for (;;) {
         if (spanLeft == 0u) {

@@ -133,6 +133,10 @@ struct pt_ctx {
     int active = 0; // set the render kernels read
     int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
     hipStream_t copyStream = nullptr;
+    // small launches (a 1-spp interactive frame): the shadow rays of bounce b are traced on `sideStream` while the main stream traces
+    // the extension rays of bounce b + 1 (independent: both only need shade b; shade b + 1 waits for both)
+    hipStream_t sideStream = nullptr;
+    hipEvent_t evShaded[kMaxPasses] = {}, evShadowed[kMaxPasses] = {};
     std::vector<VertexShade> hostVerts;
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
@@ -158,9 +162,16 @@ struct pt_ctx {
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks[2] = { 0, 0 };
+    // live entries per pass of the most recent batch whose counters have come back (a HINT for the next batch's k_shade launches:
+    // copied to pinned memory by the stream at the end of every batch, never waited for)
+    uint32_t* passCountsPinned = nullptr; // kMaxPasses + 1 words
+    hipEvent_t passCountsCopied = nullptr;
+    uint32_t passCountsHint[kMaxPasses + 1] = {};
+    uint32_t passCountsEntries = 0; // entries of the batch the hint comes from (0: no hint yet)
+    uint32_t passCountsPending = 0; // entries of the batch whose copy is in flight
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
-    uint64_t packetLaunches = 0;
+    uint64_t packetLaunches = 0, genLaunches = 0;
     float4* accum = nullptr;
     uint32_t planes = 1; // samples in flight (fixed schedule)
     uint32_t spp = 0;
@@ -175,6 +186,7 @@ struct pt_ctx {
     DevBuf<Control> control;
     DevBuf<Totals> totals;
     DevBuf<uint32_t> spill;
+    size_t spillHalf = 0;
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
@@ -760,27 +772,30 @@ int ensureSpill(pt_ctx* c)
         c->packetBlocks[tl] = (uint32_t)(pb * c->numCUs);
     }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
-    HIPCHK(c, c->spill.alloc(threads * kSpillStack));
+    HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
+    c->spillHalf = threads * kSpillStack;
     return PT_OK;
 }
 
 inline int sceneKind(const pt_ctx* c) { return c->dyn[c->active].hasInstances ? 1 : 0; }
 
-void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a)
+void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a, hipStream_t stream = nullptr)
 {
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
     const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
+    if (!stream)
+        stream = c->stream;
     if (anyHit) {
         if (twoLevel)
-            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, a);
+            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, a);
+            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, a);
     } else {
         if (twoLevel)
-            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, a);
+            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, a);
+            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, a);
     }
 }
 
@@ -847,6 +862,7 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
     // several samples in flight: one grid row per group of `interleave` samples (k_gen)
     const uint32_t span = fp.planes > 1u ? fp.numOwned * fp.interleave : std::max(n, 1u);
     const uint32_t blocks = (span + 255u) / 256u, rows = fp.planes > 1u ? fp.planes / fp.interleave : 1u;
+    c->genLaunches++;
     hipLaunchKernelGGL(k_gen, dim3(blocks, rows), dim3(256), 0, c->stream, fp, c->rays[q].view(), c->identityPixels ? nullptr : c->pixelList.p,
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
@@ -856,6 +872,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #endif
 #ifndef PT_SHADE_SPLIT
 #define PT_SHADE_SPLIT 1
+#endif
+#ifndef PT_OVERLAP_SMALL
+#define PT_OVERLAP_SMALL 1 // small launches: shadow rays of bounce b beside the extension rays of bounce b + 1 (side stream)
 #endif
 #ifndef PT_PACKET_USE
 #define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
@@ -902,10 +921,12 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
         launchTrace(c, false, a);
 }
 
-void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false)
+void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
+    if (side) // runs beside the closest-hit traversal of the next bounce: a spill region of its own
+        a.spill = c->spill.p + c->spillHalf;
     a.rayO = c->shadow.o.p;
     a.rayD = c->shadow.d.p;
     a.rayC = c->shadow.c.p;
@@ -915,7 +936,7 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false)
     if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 2u))
         launchPacket(c, true, a);
     else
-        launchTrace(c, true, a);
+        launchTrace(c, true, a, side);
 }
 
 // shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
@@ -957,13 +978,22 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     } else {
         a.out = c->rays[out].view();
         a.shadow = c->shadow.view();
-        // The queue of pass b holds what survived b bounces -- 23 / 6 / 1.3 % of the capacity on the benchmark scene -- but how much is a
-        // device word, and a million workgroups that leave at once cost 0.6 ms per launch to dispatch.  So pass b >= 1 launches the
-        // one-tile kernel over the first capacity / 2^b tiles only and, behind it, a 512-workgroup grid of the tile-walking kernel for
-        // whatever lies beyond (nothing, unless paths survive better than one in two per bounce: then that part runs ~10 % slower).
+        // The queue of pass b holds what survived b bounces -- 23 / 6 / 1.3 % of the capacity on the benchmark scene, more than half per
+        // bounce behind glass -- but how much is a device word, and a million workgroups that leave at once cost 0.6 ms per launch to
+        // dispatch.  So pass b >= 1 launches the one-tile kernel over as many tiles as the same pass of the previous batch filled (its
+        // counters come back through pinned memory, unwaited-for; the first batch of a context assumes a half per bounce) and, behind
+        // it, a 512-workgroup grid of the tile-walking kernel for whatever lies beyond -- a safety net that normally finds nothing.
         uint32_t head = blocks;
-        if (PT_SHADE_SPLIT && pass > 0)
-            head = std::max(1u, blocks >> std::min(pass + c->shadeHeadShift, 24u));
+        if (PT_SHADE_SPLIT && pass > 0) {
+            if (c->passCountsEntries && !c->shadeHeadShift) {
+                // what the same pass of the last finished batch held, scaled to this batch's size, + 3 % + 8 tiles
+                const double scale = (double)launchEntries / (double)c->passCountsEntries;
+                const double guess = (double)c->passCountsHint[pass] * scale * 1.03;
+                head = std::min(blocks, (uint32_t)(guess / kShadeBlock) + 8u);
+            } else {
+                head = std::max(1u, blocks >> std::min(pass + c->shadeHeadShift, 24u)); // no history yet: half per bounce
+            }
+        }
         if (generalShading(c))
             hipLaunchKernelGGL((k_shade<false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
         else
@@ -985,6 +1015,11 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
 int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 {
     FrameParams fp = frameParams(c, sample);
+    if (c->passCountsPending && hipEventQuery(c->passCountsCopied) == hipSuccess) { // the latest copy has landed: adopt it
+        std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
+        c->passCountsEntries = c->passCountsPending;
+        c->passCountsPending = 0;
+    }
     fp.planes = batch;
     fp.interleave = 1;
     while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
@@ -999,6 +1034,8 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // The packet kernel serves the first pass when consecutive queue entries are >= 16 samples of one pixel.  (Packets of 8x8 pixel
     // blocks -- what the default pixel order would give a 1-spp frame -- were measured too: the beam test handles them, but a
     // 1280x720 frame is 14 k packets for 8 k persistent waves claiming 16 at a time: 2.2-2.4 ms per frame instead of 1.4-1.6.)
+    // (8x8-pixel packets for a 1-spp frame were measured again in round 3 with one packet per claim: 271 us for the 14 400 packets of
+    // a 1280 x 720 frame against 251 us through the per-ray kernel -- 1.8 rounds of latency-bound packet walks on 8 192 waves)
     const bool coherentFirst = fp.interleave >= 16u;
     const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
@@ -1008,6 +1045,11 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     else
         launchGen(c, fp, 0, 0, entries, 0, 0);
     prof.end();
+    // Small launches are latency-bound (every traversal launch of a 1-spp 1280 x 720 frame takes 0.1-0.25 ms whatever it holds): the
+    // shadow rays of bounce b then run on a side stream BESIDE the extension rays of bounce b + 1.  Both need only shade b; shade
+    // b + 1 waits for both, so the accumulator sees its deposits in the same order as in the serial schedule (bit-identical images).
+    // Large batches fill the machine with one kernel; two traversal kernels side by side only evict each other's nodes (measured: slower).
+    const bool overlap = PT_OVERLAP_SMALL && entries <= (4u << 20) && !c->profile && !(c->packetUse & 2u);
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
@@ -1016,13 +1058,29 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
         launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr);
         prof.end();
+        if (overlap && b > 0)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries);
         prof.end();
         prof.begin(3);
-        launchShadow(c, b, coherent);
+        if (overlap) {
+            HIPCHK(c, hipEventRecord(c->evShaded[b], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->sideStream, c->evShaded[b], 0));
+            launchShadow(c, b, coherent, c->sideStream);
+            HIPCHK(c, hipEventRecord(c->evShadowed[b], c->sideStream));
+        } else {
+            launchShadow(c, b, coherent);
+        }
         prof.end();
         std::swap(in, out);
+    }
+    if (overlap)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 1], 0));
+    if (c->passCountsPinned && !c->passCountsPending) { // (a copy still in flight keeps its slot: the host reads it only once its event has fired)
+        HIPCHK(c, hipMemcpyAsync(c->passCountsPinned, &c->control.p->extCount[0], sizeof(c->passCountsHint), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->passCountsCopied, c->stream));
+        c->passCountsPending = entries;
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
@@ -1156,11 +1214,21 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         return bail(e, "hipStreamCreate (copy stream)");
     if ((e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess)
         return bail(e, "hipEventCreate");
+    if ((e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate (side stream)");
+    for (int k = 0; k < kMaxPasses; k++)
+        if ((e = hipEventCreateWithFlags(&c->evShaded[k], hipEventDisableTiming)) != hipSuccess
+            || (e = hipEventCreateWithFlags(&c->evShadowed[k], hipEventDisableTiming)) != hipSuccess)
+            return bail(e, "hipEventCreate");
     for (auto& d : c->dyn)
         if ((e = hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming)) != hipSuccess
             || (e = hipEventCreateWithFlags(&d.lastUse, hipEventDisableTiming)) != hipSuccess
             || (e = hipEventCreateWithFlags(&d.stageRead, hipEventDisableTiming)) != hipSuccess)
             return bail(e, "hipEventCreate");
+    if ((e = hipHostMalloc((void**)&c->passCountsPinned, sizeof(c->passCountsHint), hipHostMallocDefault)) != hipSuccess
+        || (e = hipEventCreateWithFlags(&c->passCountsCopied, hipEventDisableTiming)) != hipSuccess)
+        return bail(e, "pinned counters");
+    std::memset(c->passCountsPinned, 0, sizeof(c->passCountsHint));
     if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream)) != hipSuccess)
         return bail(e, "alloc totals");
     if ((e = c->accumOwn.alloc((size_t)cfg->width * cfg->height)) != hipSuccess
@@ -1190,6 +1258,8 @@ void pt_destroy(pt_ctx* c)
         (void)hipStreamSynchronize(c->stream);
     if (c->copyStream) // a never-adopted upload may still be copying into the sets released below
         (void)hipStreamSynchronize(c->copyStream);
+    if (c->sideStream)
+        (void)hipStreamSynchronize(c->sideStream);
     DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
         &c->rays[1].d, &c->rays[1].thr, &c->stagedRays.o, &c->stagedRays.d, &c->stagedRays.thr, &c->shadow.o, &c->shadow.d, &c->shadow.c,
         &c->stagedShadow.o, &c->stagedShadow.d, &c->stagedShadow.c };
@@ -1210,6 +1280,13 @@ void pt_destroy(pt_ctx* c)
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
+    if (c->sideStream) (void)hipStreamDestroy(c->sideStream);
+    for (int k = 0; k < kMaxPasses; k++) {
+        if (c->evShaded[k]) (void)hipEventDestroy(c->evShaded[k]);
+        if (c->evShadowed[k]) (void)hipEventDestroy(c->evShadowed[k]);
+    }
+    if (c->passCountsPinned) (void)hipHostFree(c->passCountsPinned);
+    if (c->passCountsCopied) (void)hipEventDestroy(c->passCountsCopied);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->ownStream && c->stream)
@@ -2119,6 +2196,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->ms_shadow = c->msShadow;
     out->ms_gen = c->msGen;
     out->packet_launches = c->packetLaunches;
+    out->gen_launches = c->genLaunches;
     out->ms_packet = c->msPacket;
     return PT_OK;
 }
@@ -2129,7 +2207,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
-    c->packetLaunches = 0;
+    c->packetLaunches = c->genLaunches = 0;
     return PT_OK;
 }
 

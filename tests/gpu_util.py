@@ -38,13 +38,15 @@ def tri_vertex_ids(flat, prim):
     return np.sort(flat.triangles["indices"][prim], axis=1)
 
 
-def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0, t_outlier_frac=0.0, uv_atol=5e-3):
+def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac=0.0, t_outlier_frac=0.0, uv_atol=5e-3, t_atol=1e-6):
     """hit/miss identical; t/u/v within tolerance; (prim, inst) identical except where two primitives are
     hit at the same t within tolerance (shared edges, SBVH-duplicated references): those must agree on t.
     `t_outlier_frac` > 0 (deformed meshes: twisted triangles become slivers, and t of a hit that grazes a sliver is ill-conditioned)
     tolerates that fraction of rays beyond t_rtol, each within 1 %.
     `edge_flip_frac` > 0 (world-space copies of instances: triangle edges are rounded in another space than the
     reference's) tolerates that fraction of hit/miss disagreements, each of which must graze a triangle edge.
+    `t_atol`: the absolute error of t scales with the magnitude of the coordinates, not with t (a ray that starts 5e-4 in front of a
+    surface 15 units from the origin has t good to a few 1e-6): scenes far larger than the unit cube pass a few ulps of their extent.
     `uv_atol`: barycentrics are compared through the hit point they encode; the direct bound on u and v is loose (they are
     ill-conditioned for small or distant triangles: 5e-3 by default, more for scenes of tiny triangles seen from afar)."""
     gh, wh = got["prim"] >= 0, want["prim"] >= 0
@@ -61,7 +63,7 @@ def compare_hits(flat, got, want, t_rtol=2e-4, max_tie_frac=1e-2, edge_flip_frac
     assert flips.mean() <= 1e-4, f"hit/miss differs for {flips.sum()} rays"
     both = gh & wh
     dt = np.abs(got["t"][both] - want["t"][both]) / np.maximum(np.abs(want["t"][both]), 1e-6)
-    bad = ~np.isclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=1e-6)
+    bad = ~np.isclose(got["t"][both], want["t"][both], rtol=t_rtol, atol=t_atol)
     assert bad.mean() <= t_outlier_frac, f"t differs for {bad.sum()} of {both.sum()} rays, worst {dt.max():.3e}"
     for k in np.flatnonzero(bad):  # a tolerated outlier is within 1 %, or its NEARER hit grazes a triangle edge (the other side missed that
         if dt[k] < 1e-2:           # triangle by round-off and reports what lies behind it)

@@ -46,6 +46,32 @@ def test_full_size_properties(gpu, bundle):
     assert close.mean() > 0.97, close.mean()
 
 
+@pytest.mark.parametrize("flags_name", ["copied", "entered"])
+def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_name):
+    """What bench.py times -- config 4 with 256 samples in flight: ONE 256-sample batch whose primary rays are generated and traced by
+    the packet kernel (beam test, no k_gen launch), 531 M queue entries -- held against the oracle directly: 4 096 sampled pixels at the
+    full 256 spp, at the gates of the room configurations (mean bias < 2e-3, tone-mapped RMSE < 2e-3).  `entered`: the same with every
+    instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line."""
+    flags = 0 if flags_name == "copied" else gpu.FLAG_NO_BAKED_INSTANCES
+    ctx = U.make_ctx(gpu, bundle, W, H, seed=1, samples_in_flight=256, flags=flags)
+    ctx.render(256)
+    st = ctx.stats()
+    assert st["packet_launches"] == 1 and st["gen_launches"] == 0, "the batch must take the path the benchmark times"
+    assert st["rays_generated"] == W * H * 256 and ctx.samples_per_pixel == 256
+    a = ctx.read_accum()[:, :3]
+    ctx.close()
+    px = np.random.default_rng(4).choice(W * H, 4096, replace=False).astype(np.uint32)
+    ref, _ = O.render(U.oracle_scene(bundle), bundle.camera, W, H, 256, seed=1, pixels=px, threads=16)
+    got, want = a[px], ref[px, :3]
+    bias = abs(got.mean() - want.mean()) / want.mean()
+    assert bias < 2e-3, bias
+    e = U.rmse(U.tonemap(got, 256, bundle.camera), U.tonemap(want, 256, bundle.camera))
+    assert e < 2e-3, e
+    # path by path most pixels agree to round-off (a pixel holds 256 paths here; one fp32 decision flip per pixel is common)
+    close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * want.max()).all(axis=1)
+    assert close.mean() > 0.9, close.mean()
+
+
 def test_config5_4k_thin_lens_properties(gpu):
     """BASELINE.json config 5 (same scene at 3840x2160, thin lens f/2 focused on the grid centre): ray-count
     conservation, tile sharding over 8 ranks' worth of tile lists == the whole frame, sampled pixels against the

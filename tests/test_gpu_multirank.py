@@ -42,6 +42,23 @@ def test_two_rank_job_on_one_gpu_equals_the_single_rank_job(gpu, tmp_path):
     assert j2["value"] > 0 and j2["image_mean_radiance"] == j1["image_mean_radiance"]
 
 
+def test_bench_starts_its_own_ranks_and_strong_scaling_keeps_the_job_fixed(gpu, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (fresh child processes) and relays rank
+    0's line.  With --scaling strong the JOB is fixed -- in_flight x rounds samples per pixel of the whole image per step -- so two ranks
+    trace exactly the paths one rank traces, half of the pixels each: same ray counts, same image bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    j2 = _run([sys.executable, "bench.py", "--gpus", "2", "--share-gpu", "--backend", "gloo", "--scaling", "strong", "--in-flight", "8",
+               "--dump-accum", two] + COMMON, env)  # rounds 2: 16 samples per pixel per step, 16 in flight per rank
+    j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--in-flight", "16", "--dump-accum", one]
+              + [a if a != "2" or COMMON[i - 1] != "--rounds" else "1" for i, a in enumerate(COMMON)], env)
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j1["scaling"] == "strong"
+    assert j2["config"]["spp_per_step"] == 16 == j1["config"]["spp_per_step"] and j2["config"]["samples_in_flight"] == 16
+    assert j2["rays"] == j1["rays"] and j2["rays"]["primary"] == 192 * 128 * 16
+    assert np.array_equal(np.load(one), np.load(two))
+
+
 def test_oversized_jobs_and_overlapping_tiles_fail_with_a_message(gpu):
     """BASELINE config 5 sized naively -- 4K, a rank's eighth of the pixels, 2 048 samples in flight = 2.1 G queue entries,
     ~350 GB -- must be refused when the queues are set up, with a message that says what to change, not die in a later

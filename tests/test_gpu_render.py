@@ -200,6 +200,32 @@ def test_determinism_batching_refill_and_tiles(gpu):
     assert np.allclose(p0 + p1, ap, rtol=1e-5, atol=1e-5 * ap.max())
 
 
+@pytest.mark.parametrize("scene", ["room", "grid_two_level"])
+def test_interactive_frames_packets_and_overlapped_passes_are_bit_identical(gpu, scene):
+    """RayTracer::rayTrace's operating point: one sample per pixel per call (src/main.cpp:106-119).  The schedule of such small
+    launches -- the shadow rays of bounce b traced on a side stream beside the extension rays of bounce b + 1, static packets sized to
+    the launch -- must produce the image of the plain schedule (every launch in order on one stream: what a context with kernel
+    profiling on runs) bit for bit, frame after frame."""
+    W, Hh = 320, 184  # not a multiple of 64 pixels per row of blocks: ragged packets at the right edge
+    if scene == "room":
+        b, flags = scenes.blob_room(W, Hh, level=4, material=L.material_refractive(0.9, 1.5, (1.0, 0.6, 0.6), 5.0)), 0
+    else:
+        b, flags = scenes.instanced_grid(W, Hh, level=4, sky_size=(64, 32), rotate=True), gpu.FLAG_TWO_LEVEL_ONLY
+    fast = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1, flags=flags)
+    plain = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1, flags=flags)
+    plain.profile_kernels(True)  # serial schedule
+    for frame in range(6):
+        fast.render(1)
+        plain.render(1)
+        a, p = fast.read_accum(), plain.read_accum()
+        assert np.array_equal(a, p), f"frame {frame}: {int((a != p).any(axis=1).sum())} pixels differ"
+    sf, sp = fast.stats(), plain.stats()
+    for k in ("rays_extension", "rays_shadow", "shade_hits", "deposits"):
+        assert sf[k] == sp[k], k
+    fast.close()
+    plain.close()
+
+
 def test_clear_accumulate_and_spp_bookkeeping(gpu):
     b = scenes.cornell_box(48, 27)
     ctx = U.make_ctx(gpu, b, 48, 27, seed=2)

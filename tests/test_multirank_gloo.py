@@ -76,3 +76,19 @@ def test_two_rank_render_and_reduce(tmp_path):
     assert np.array_equal(z["accum"], full), "reduced tile renders != single-rank render"
     assert z["rays"][0] == cnt["raysExtension"] + cnt["raysShadow"]
     assert z["tmax"][0] == 2.0 and 0 < z["owned"] < W * H
+
+
+def test_bench_without_a_launcher_starts_its_ranks_as_child_processes():
+    """`python bench.py --gpus 2` outside torchrun must not bail out on WORLD_SIZE: it starts the ranks itself (torch.distributed.run
+    as a CHILD, before the parent has touched a GPU) and exits with the children's status.  Here (no GPU) the children get as far as
+    bench.py's own 'needs a GPU' message -- which proves they were started as ranks of a 2-rank job -- and the parent reports failure."""
+    import subprocess
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: tests/test_gpu_multirank.py runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stderr and "launch with torch.distributed.run" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,6 +1,6 @@
 """Static VALU instruction mix of every kernel of libptamd.so by issue class (here, no GPU needed):
 
-    python tools/isa_mix.py profiles/round2/isa_mix.json
+    python tools/isa_mix.py profiles/round3/isa_mix.json
 
 Classes and cycles per wave64 instruction are the ones tools/micro/valu_issue.hip measured on the MI355X (profiles/round2/
 r2c_valu_issue.md, W = 8 waves per SIMD): full rate ~2 cycles (v_fma/mul/add/sub/fmac_f32, and/or/xor, shifts, add/sub_u32, mov),
@@ -20,8 +20,11 @@ FULL = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_f
         "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_add_co_u32", "v_addc_co_u32",
         "v_sub_co_u32", "v_subb_co_u32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"}
 QUARTER = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
-KERNELS = {"k_traceILb1": "k_trace<true>", "k_traceILb0": "k_trace<false>", "k_trace_packetILb0": "k_trace_packet<false>", "k_shadeILb0ELb0": "k_shade<false>",
-           "k_shadeILb0ELb1": "k_shade<false, general>", "5k_genE": "k_gen", "k_fold_planes": "k_fold_planes", "k_resolve": "k_resolve"}
+# <any hit, two level>: the names without a second argument are the instantiations for scenes that are one world-space tree (the headline)
+KERNELS = {"k_traceILb1ELb0": "k_trace<true>", "k_traceILb0ELb0": "k_trace<false>", "k_traceILb1ELb1": "k_trace<true, two-level>",
+           "k_traceILb0ELb1": "k_trace<false, two-level>", "k_trace_packetILb0ELb0": "k_trace_packet<false>",
+           "k_trace_packetILb0ELb1": "k_trace_packet<false, two-level>", "k_shadeILb0ELb0ELb0": "k_shade<false>",
+           "k_shadeILb0ELb1ELb0": "k_shade<false, general>", "5k_genE": "k_gen", "k_fold_planes": "k_fold_planes", "k_resolve": "k_resolve"}
 
 
 def main():

@@ -20,8 +20,8 @@ def report(tag, s, nrays):
           f" served/iter inner {li/max(ki,1):5.1f} leaf {ll/max(kl,1):5.1f} special {ls/max(ks,1):5.1f}  overall {(li+ll+ls)/it:5.1f}  handouts {ho} ({hr/max(ho,1):.1f} rays each)")
     if s[18]:
         print(f"             inner lane-steps at a node one of whose children contains the ray origin: {s[18] / max(li, 1):.3f} of all inner lane-steps")
-    if s[16]:
-        print(f"             triangles tested per ray {s[16]/max(nrays,1):5.2f} (lane-level count / 64 lanes: {s[16]} per-wave loops)")
+    # (counter 16 is the hand-out's LDS-read CYCLES, pt_trace.h PT_TOC(16, tShfl) -- printed with the cycle shares below; round 2
+    #  printed it here as "triangles tested per ray", which it is not: profiles/round2/r2v_trace_stats_*.txt carry that wrong line)
     tot, tin, tle, tsp, tha = s[10], s[11], s[12], s[13], s[14]
     if tot:
         print(f"             wave cycles: inner {100*tin/tot:4.1f}% ({tin/max(ki,1):6.0f}/step)  leaf {100*tle/tot:4.1f}% ({tle/max(kl,1):6.0f}/step)  special {100*tsp/tot:4.1f}% ({tsp/max(ks,1):6.0f}/pass)"

@@ -13,7 +13,7 @@ import sys
 
 import os
 src, dst = sys.argv[1], sys.argv[2]
-tag = sys.argv[3] if len(sys.argv) > 3 else "r2"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r3"
 rnd = os.path.basename(os.path.dirname(os.path.abspath(dst)))
 mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mix.json")))["kernels"]
 
@@ -21,7 +21,13 @@ mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mi
 def table(name):
     out = {}
     for line in open(f"{src}/pmc_{name}.txt"):
-        line = line.replace("k_shade<false, false, false>", "k_shade<false>").replace("k_shade<false, false>", "k_shade<false>")  # the production instantiation (one tile per workgroup); k_shade<false, false, true> is the tile-walking safety net  # the production instantiation (not the general integrator kernel)
+        # the production instantiations: k_shade one tile per workgroup (k_shade<false, false, true> is the tile-walking safety net), the
+        # traversal kernels for scenes that are one world-space tree (<., true>: the ones that enter instances)
+        for long, short in (("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
+                            ("k_trace<true, false>", "k_trace<true>"), ("k_trace<false, false>", "k_trace<false>"),
+                            ("k_trace_packet<false, false>", "k_trace_packet<false>"), ("k_trace<true, true>", "k_trace<true,two-level>"),
+                            ("k_trace<false, true>", "k_trace<false,two-level>"), ("k_trace_packet<false, true>", "k_trace_packet<false,two-level>")):
+            line = line.replace(long, short)
         m = re.match(r"(?:void )?ptd::(\S+)\s+(\S+)\s+(\d+)\s+per-dispatch\s+(\d+)\s+\((\d+) dispatches\)", line)
         if m:
             out.setdefault(m.group(1), {})[m.group(2)] = (float(m.group(3)), int(m.group(5)))
@@ -32,6 +38,10 @@ bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
 kern = bench["roofline"]["kernels"]
 fetch, write = table("FETCH_SIZE"), table("WRITE_SIZE")
 insts, act = table("SQ_INSTS_VALU"), table("GRBM_GUI_ACTIVE")
+try:
+    waves = table("SQ_WAVES")
+except OSError:
+    waves = {}
 STEPS = 2  # the PMC passes run --rounds 1 --warmup 1 --steps 1: two batches
 # bytes per unit that FETCH_SIZE misses: the 16-B-per-lane reads of consecutive queue entries, counted at 1/2
 HALF_COUNTED = {
@@ -48,11 +58,11 @@ out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["
                       "at x0.50 in the same passes), everything else 1:1; WRITE_SIZE exact (primary rays x 32 B).",
        "kernels": {}, "issue": {},
        "issue_model": ("cycles a wave64 vector instruction occupies its SIMD's issue port, measured (tools/micro/valu_issue.hip, "
-                       f"profiles/{rnd}/r2c_valu_issue.md): full rate 2 (fma/mul/add, logic, shifts, moves), half rate 4 (min/max, compares, selects, "
+                       f"profiles/round2/r2c_valu_issue.md): full rate 2 (fma/mul/add, logic, shifts, moves), half rate 4 (min/max, compares, selects, "
                        "conversions, VOP3 integer, packed f32), quarter rate 8 (rcp/rsq/sqrt/exp/log); valu_issue_frac = SQ_INSTS_VALU x the mean "
                        f"cost of the kernel's inner-loop mix (profiles/{rnd}/isa_mix.json) / (1024 SIMDs x kernel cycles)"),
        "source": [f"profiles/{rnd}/{tag}_{p}" for p in ("pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "pmc_SQ_INSTS_VALU.txt",
-                                                          "pmc_GRBM_GUI_ACTIVE.txt", "bench.json")]}
+                                                          "pmc_GRBM_GUI_ACTIVE.txt", "pmc_SQ_WAVES.txt", "bench.json")]}
 for name, k in kern.items():
     if name not in fetch and name not in write:
         continue
@@ -74,6 +84,12 @@ for name, k in kern.items():
              "valu_instructions_per_unit": round(i["SQ_INSTS_VALU"][0] / STEPS / units, 2)}
         if "SQ_THREAD_CYCLES_VALU" in act[name] and "SQ_ACTIVE_INST_VALU" in act[name]:
             e["valu_active_lanes"] = round(act[name]["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * act[name]["SQ_ACTIVE_INST_VALU"][0]), 3)
+            # rocprof's own VALUBusy: SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles (a COUNTER, next to the modelled valu_issue_frac)
+            e["valu_busy"] = round(act[name]["SQ_ACTIVE_INST_VALU"][0] * 4.0 / simd_cycles, 3)
+        w = waves.get(name, {})
+        if "SQ_WAVE_CYCLES" in w and w["SQ_WAVE_CYCLES"][0] > 0:  # what the resident waves were doing, as fractions of wave-cycles
+            e["wave_cycles_issuing"] = round(w.get("SQ_ACTIVE_INST_ANY", (0, 0))[0] / w["SQ_WAVE_CYCLES"][0], 3)
+            e["wave_cycles_waiting"] = round(w.get("SQ_WAIT_INST_ANY", (0, 0))[0] / w["SQ_WAVE_CYCLES"][0], 3)
         out["issue"][name] = e
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
