@@ -336,6 +336,17 @@ def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
         c["config5_one_gpu"] = measure_scene(D, big, W4, H4, device, n4, steps=2, what=f"configs[4] on ONE GPU: the headline scene at {W4}x{H4}, thin lens f/2")
         return c
     guarded("configs", configs)
+
+    def material_order():
+        m = {"what": "k_shade on scenes with five material types on one mesh (diffuse, PBR metal, PBR dielectric, rough glass, basic glass) in "
+                     "the room of configs 2/3: tiles shaded in queue order (the default) against material order (PT_FLAG_MATERIAL_BINS)"}
+        for pattern in ("patches", "confetti"):
+            sc = scenes.mixed_material_room(W, Hh, level=args.level, pattern=pattern)
+            for name, fl in (("queue_order", 0), ("material_order", D.FLAG_MATERIAL_BINS)):
+                r = measure_scene(D, sc, W, Hh, device, in_flight, flags=fl, steps=2)
+                m[f"{pattern}_{name}"] = {k: r[k] for k in ("mrays_per_s", "shade_ns_per_entry", "kernel_ms_per_step")}
+        return m
+    guarded("material_order", material_order)
     return out
 
 

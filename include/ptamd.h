@@ -142,6 +142,9 @@ typedef struct {
 /* shade runs neeMisShading (assets/cl/shading.cl:35-349: NEE + BSDF sampling combined by the balance heuristic) instead of
  * neeIsShading (:356-623), the integrator the reference compiles in.  The reference reaches its MIS code only under
  * #define COMPARE_SHADING (kernel.cl:6); one uninitialised read in it is fixed here. */
+#define PT_FLAG_MATERIAL_BINS 512u /* scenes whose surfaces are of several material types: k_shade walks every 512-entry tile in material
+                                     order instead of queue order (measured SLOWER on MI355X -- the kernel is bound by its gathers, not by
+                                     divergent BSDF code: DESIGN.md section 6 -- hence opt-in) */
 #define PT_FLAG_QUEUE_PRIMARY_RAYS 256u /* always write the primary rays to the queue (k_gen), also where the packet kernel could
                                           regenerate them from the entry index (diagnostics; the image is the same) */
 #define PT_FLAG_INTEGRATOR_MIS 32u

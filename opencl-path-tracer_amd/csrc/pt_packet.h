@@ -105,7 +105,7 @@ __device__ inline float rowShr1(float v) // v[lane - 1]
 // (14 dwords per lane).  A transform that turns the packet's directions into more than one octant (a rotation can, for the few packets that
 // look along one of the instance's axes) ends the beam walk: the packet starts over on the per-lane path with the hits it has found.
 #ifndef PT_PACKET_MIN_WAVES_TL
-#define PT_PACKET_MIN_WAVES_TL 8
+#define PT_PACKET_MIN_WAVES_TL 7 // 67 VGPRs: at 8 waves (64) the lane-role address offsets of the beam test spill to scratch -- two extra memory round trips per node
 #endif
 constexpr int kPacketSave = 14; // world-space state of a lane while its packet is inside an instance
 // The beam of 64 rays whose directions point into one octant: per axis the interval of the origins and of |1 / direction|, and from
@@ -166,9 +166,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
     // size come from the queue cursor: one atomic per span, well under what a device-scope word sustains (pt_trace.h).
     // Consecutive packets are neighbouring pixels, so a wave keeps finding its nodes in the scalar cache and L2, and
     // no wave is left with a long static tail while others idle.
-    // (a launch with fewer packets than that per wave -- the 14 400 8x8-pixel packets of a 1-spp 1280 x 720 frame for 8 192 waves -- deals
-    // them one at a time, so that every wave works: with 16 per claim 900 waves walked 16 packets each while 7 300 watched)
-    const uint32_t kSpan = min((uint32_t)PT_PACKET_DYNAMIC, max(1u, packets / totalWaves));
+    constexpr uint32_t kSpan = PT_PACKET_DYNAMIC;
     uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
     for (;;) {
         if (spanLeft == 0u) {
@@ -231,7 +229,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
         float hu = 0.f, hv = 0.f;
         int hprim = -1, hinst = -1;
         int curInst = -1; // wave-uniform
-        if (TWO_LEVEL) { // the world-space ray, for the way back out of an instance
+        if constexpr (TWO_LEVEL) { // the world-space ray, for the way back out of an instance
             ldsSave[pwave][0][lane] = asU(co.x), ldsSave[pwave][1][lane] = asU(co.y), ldsSave[pwave][2][lane] = asU(co.z);
             ldsSave[pwave][3][lane] = asU(cd.x), ldsSave[pwave][4][lane] = asU(cd.y), ldsSave[pwave][5][lane] = asU(cd.z);
             ldsSave[pwave][6][lane] = asU(cid.x), ldsSave[pwave][7][lane] = asU(cid.y), ldsSave[pwave][8][lane] = asU(cid.z);
@@ -265,7 +263,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
             uint32_t ofsQ;
             // the beam of the rays as they are now (co, cid; signs uniform): per axis the interval of the origins and of |1 / direction|
             beamSetup(co, cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
-            if (TWO_LEVEL) { // the world-space beam, next to the world-space ray
+            if constexpr (TWO_LEVEL) { // the world-space beam, next to the world-space ray
                 ldsSave[pwave][9][lane] = asU(S), ldsSave[pwave][10][lane] = asU(negSO), ldsSave[pwave][11][lane] = asU(mulPos);
                 ldsSave[pwave][12][lane] = asU(mulNeg), ldsSave[pwave][13][lane] = ofsQ;
             }
@@ -273,9 +271,18 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
             uint32_t stRef = 0u; // the stack: entry e is lane e
             uint32_t sp = 0u;
             uint32_t cur = rootRef;
+#ifdef PT_TRACE_STATS
+            uint32_t stBeamNodes = 0u, stBeamLeaves = 0u, stEnters = 0u, stEmptyVisits = 0u, stNodesAtEnter = 0u, stLeavesAtEnter = 0u;
+            unsigned long long stEnterCycles = 0ull;
+#endif
             while (true) {
                 if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
                     if (cur != kRefLeaveInstance) {
+#ifdef PT_TRACE_STATS
+                        stEnters++;
+                        stNodesAtEnter = stBeamNodes, stLeavesAtEnter = stBeamLeaves;
+                        const unsigned long long tEnter = __builtin_readcyclecounter();
+#endif
                         // -------- enter instance refIndex(cur): instances are only ever entered from world space ---------------
                         V3 to, td;
                         uint32_t root;
@@ -287,24 +294,31 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                             viaBeam = false; // the packet no longer points into one octant: start over, per lane (the rays are still the world-space ones)
                             break;
                         }
-                        co = to, cd = td, cid = tid;
-                        nx = sx != 0ull, ny = sy != 0ull, nz = sz != 0ull;
-                        beamSetup(co, cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                        co = to, cd = td; // (1 / direction is only needed for the beam: it does not stay in registers here)
+                        beamSetup(co, tid, sx != 0ull, sy != 0ull, sz != 0ull, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
                         curInst = (int)refIndex(cur);
                         stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
                         sp++;
                         cur = uni(root);
+#ifdef PT_TRACE_STATS
+                        stEnterCycles += __builtin_readcyclecounter() - tEnter;
+#endif
                         continue;
                     }
+#ifdef PT_TRACE_STATS
+                    if (stBeamLeaves == stLeavesAtEnter && stBeamNodes <= stNodesAtEnter + 1u)
+                        stEmptyVisits++; // the instance's root node was tested and nothing below it
+#endif
                     // -------- the sentinel: back to the world-space ray and beam ----------------------------------------------
                     co = mk(asF(ldsSave[pwave][0][lane]), asF(ldsSave[pwave][1][lane]), asF(ldsSave[pwave][2][lane]));
                     cd = mk(asF(ldsSave[pwave][3][lane]), asF(ldsSave[pwave][4][lane]), asF(ldsSave[pwave][5][lane]));
-                    cid = mk(asF(ldsSave[pwave][6][lane]), asF(ldsSave[pwave][7][lane]), asF(ldsSave[pwave][8][lane]));
-                    nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
                     S = asF(ldsSave[pwave][9][lane]), negSO = asF(ldsSave[pwave][10][lane]), mulPos = asF(ldsSave[pwave][11][lane]);
                     mulNeg = asF(ldsSave[pwave][12][lane]), ofsQ = ldsSave[pwave][13][lane];
                     curInst = -1;
                 } else if (refCount(cur) == 0u) {
+#ifdef PT_TRACE_STATS
+                    stBeamNodes++;
+#endif
                     const uint32_t ni = refIndex(cur);
                     const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
                     const char* nb = (const char*)&sc.wide[ni];
@@ -344,6 +358,9 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                 } else {
                     const uint32_t first = refIndex(cur), n = refCount(cur);
                     bool any = false;
+#ifdef PT_TRACE_STATS
+                    stBeamLeaves++;
+#endif
                     // (fetching triangle k + 1 while triangle k is tested was measured: +0.4 ms per batch -- scalar registers are short here)
                     for (uint32_t k = 0; k < n; k++) {
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
@@ -376,9 +393,21 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                 sp--;
                 cur = __builtin_amdgcn_readlane(stRef, sp);
             }
+#ifdef PT_TRACE_STATS
+            if (lane == 0) { // closest-hit beam packets: [48] packets [49] nodes [50] leaves [51] instance entries [52] of which found nothing [53] cycles in entries [54] bails
+                atomicAdd(&g_traceStats[48], 1ull), atomicAdd(&g_traceStats[49], (unsigned long long)stBeamNodes), atomicAdd(&g_traceStats[50], (unsigned long long)stBeamLeaves);
+                atomicAdd(&g_traceStats[51], (unsigned long long)stEnters), atomicAdd(&g_traceStats[52], (unsigned long long)stEmptyVisits), atomicAdd(&g_traceStats[53], stEnterCycles);
+                if (!viaBeam)
+                    atomicAdd(&g_traceStats[54], 1ull);
+            }
+#endif
         }
 #endif
         if (ANY_HIT || !viaBeam) {
+        if constexpr (TWO_LEVEL && !ANY_HIT) { // (a packet that left the beam walk: its rays are the world-space ones; 1 / direction was not kept)
+            cid = mk(rcpSlab(cd.x), rcpSlab(cd.y), rcpSlab(cd.z));
+            nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+        }
         uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
         uint32_t sp = 0u; // wave-uniform
         uint32_t cur = rootRef;

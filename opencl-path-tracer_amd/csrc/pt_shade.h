@@ -765,10 +765,17 @@ __device__ inline void stQ(float4* p, float4 v)
 // LOOP = true: a small grid whose workgroups walk tiles from a.firstTile on (tile += gridDim.x) -- the safety net behind a launch that
 // covers only the head of the queue (ptamd.hip, launchShade).  Slower per entry than the one-tile kernel (128 VGPRs and spills: the
 // loop keeps the scene pointers live), so it is never the main path.
-template <bool PARITY, bool GENERAL = false, bool LOOP = false>
+// BINNED = true (scenes whose surfaces are of more than one material type): the 512 entries of a tile are shaded in MATERIAL ORDER.  The
+// reference dispatches on the material inside one kernel (shading.cl:387-601) and so does shadeHit: a wave whose 64 hits are of three
+// types runs three BSDFs one after the other.  Here every thread first looks up the type of its entry's hit (4 bytes of the triangle's
+// shading record), the workgroup counting-sorts its tile by (type, miss) through LDS -- ballot ranks inside a wave, one 64-lane scan over
+// the (type, wave) counters -- and thread t then shades the t-th entry of that order: waves see one type except at the seams.  Nothing
+// moves in memory; the compaction below writes the outputs wherever its counters say, as always.
+template <bool PARITY, bool GENERAL = false, bool LOOP = false, bool BINNED = false>
 __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 : PT_SHADE_MIN_WAVES) k_shade(ShadeArgs a)
 {
     static_assert(!(PARITY && LOOP), "the parity kernel stages at the input slot: one tile per workgroup");
+    static_assert(!BINNED || (!PARITY && !LOOP), "material order: production queue semantics, one tile per workgroup");
     const uint32_t count = *a.inCount;
     uint32_t tile = a.firstTile + blockIdx.x;
     if (tile * kShadeBlock >= count) // uniform for the workgroup
@@ -776,8 +783,45 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
     __shared__ uint32_t sCount[kShadeBlock / 64][4];
     __shared__ uint32_t sBase[4];
   do {
-    const uint32_t i = tile * kShadeBlock + threadIdx.x;
+    uint32_t i = tile * kShadeBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+    if (BINNED) {
+        constexpr uint32_t kKeys = 8u, kWaves = kShadeBlock / 64u;
+        static_assert(kKeys * kWaves == 64u, "one lane per (key, wave) counter");
+        __shared__ uint32_t sBin[kKeys * kWaves]; // [key][wave]
+        __shared__ uint16_t sPerm[kShadeBlock];
+        const uint32_t w = threadIdx.x >> 6;
+        uint32_t key = kKeys - 1u; // beyond the live entries: sorts last
+        if (i < count) {
+            const int prim = (int)((const uint32_t*)&a.hits.h[i])[3];
+            key = prim < 0 ? 5u : min(asU(a.sc.triFat[prim].mat.w), 4u); // material type (MAT_*), 5: the ray left the scene
+        }
+        uint32_t rank = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kKeys; k++) {
+            const unsigned long long m = __ballot(key == k);
+            if (key == k)
+                rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                sBin[k * kWaves + w] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64u) { // exclusive scan of the 64 counters, key-major
+            const uint32_t v = sBin[threadIdx.x];
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if ((int)lane >= o)
+                    incl += up;
+            }
+            sBin[threadIdx.x] = incl - v;
+        }
+        __syncthreads();
+        sPerm[sBin[key * kWaves + w] + rank] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = tile * kShadeBlock + sPerm[threadIdx.x];
+    }
 #if PT_SHADE_PARK
     __shared__ float sPark[PARITY ? 1 : 10][PARITY ? 1 : kShadeBlock];
 #endif

@@ -103,7 +103,7 @@ struct TraceArgs {
 #ifdef PT_TRACE_STATS
 // diagnostic build only (tools/variants.sh ... -DPT_TRACE_STATS): where do the lanes of a wave go?
 // [0] iterations, [1] sum of active lanes, [2..4] iterations per kind, [5..7] lanes served per kind, [8] hand-outs, [9] rays
-__device__ unsigned long long g_traceStats[48]; // [0..23] closest-hit launches, [24..47] any-hit launches
+__device__ unsigned long long g_traceStats[64]; // [0..23] closest-hit launches, [24..47] any-hit launches, [48..63] packet kernel
 #define PT_STAT(i, v) statAcc[i] += (unsigned long long)(v)
 #define PT_TIC(t) const unsigned long long t = __builtin_readcyclecounter()
 #define PT_TOC(i, t) statAcc[i] += __builtin_readcyclecounter() - t

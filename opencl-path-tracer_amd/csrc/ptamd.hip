@@ -170,6 +170,7 @@ struct pt_ctx {
     uint32_t passCountsEntries = 0; // entries of the batch the hint comes from (0: no hint yet)
     uint32_t passCountsPending = 0; // entries of the batch whose copy is in flight
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
+    bool materialBins = false; // the surfaces are of more than one material type: k_shade shades its tiles in material order
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
     uint64_t packetLaunches = 0, genLaunches = 0;
     float4* accum = nullptr;
@@ -777,7 +778,11 @@ int ensureSpill(pt_ctx* c)
     return PT_OK;
 }
 
-inline int sceneKind(const pt_ctx* c) { return c->dyn[c->active].hasInstances ? 1 : 0; }
+inline int sceneKind(const pt_ctx* c)
+{
+    static const bool forceTwoLevel = getenv("PTAMD_FORCE_TWO_LEVEL_KERNELS") != nullptr; // diagnostics: what do the instantiations that CAN enter instances cost on a scene without any?
+    return (c->dyn[c->active].hasInstances || forceTwoLevel) ? 1 : 0;
+}
 
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a, hipStream_t stream = nullptr)
 {
@@ -996,6 +1001,8 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
         }
         if (generalShading(c))
             hipLaunchKernelGGL((k_shade<false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
+        else if (c->materialBins)
+            hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
         else
             hipLaunchKernelGGL((k_shade<false, false>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
         if (head < blocks) {
@@ -1160,11 +1167,12 @@ const char* pt_version(void) { return "ptamd 0.1 (gfx950)"; }
 
 #ifdef PT_TRACE_STATS
 // diagnostic builds only: read and clear the traversal-loop counters
-int pt_debug_trace_stats(unsigned long long* out48)
+int pt_debug_trace_stats(unsigned long long* out, unsigned int n) // n <= 64 counters (pt_trace.h, g_traceStats)
 {
-    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_traceStats), sizeof(unsigned long long) * 48) != hipSuccess)
+    n = std::min(n, 64u);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceStats), sizeof(unsigned long long) * n) != hipSuccess)
         return -1;
-    unsigned long long zero[48] = {};
+    unsigned long long zero[64] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_traceStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -1472,6 +1480,16 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->haveStatic = true;
     c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
     c->pending = -1;
+    {   // material types in use (emissive surfaces end a path in a few instructions: they do not count)
+        uint32_t types = 0;
+        for (uint32_t t = 0; t < nT; t++) {
+            uint32_t ty;
+            std::memcpy(&ty, (const char*)&mats[tris[t].materialIndex] + 32, 4); // the type word of the 48-byte record (Material::typeAndPad.x)
+            types |= 1u << std::min(ty, 31u);
+        }
+        types &= ~(1u << MAT_EMISSIVE);
+        c->materialBins = (types & (types - 1u)) != 0u && (c->cfg.flags & PT_FLAG_MATERIAL_BINS) != 0u; // opt-in: measured slower (pt_shade.h)
+    }
     c->sg.extraRoots.clear();
     if ((rc = buildStaticGeom(c)))
         return rc;

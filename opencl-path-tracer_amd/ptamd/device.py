@@ -18,6 +18,7 @@ FLAG_PACKET_INTERSECT = 16  # the pt_intersect hook uses the packet kernel where
 FLAG_INTEGRATOR_MIS = 32  # neeMisShading instead of neeIsShading
 FLAG_COMPARE_SHADING = 64  # the reference's COMPARE_SHADING build: MIS on the left half of the image, IS on the right, same view
 FLAG_SOLID_ANGLE_LIGHTS = 128  # NEE picks lights by weightedRandomPointOnLight
+FLAG_MATERIAL_BINS = 512  # k_shade walks its tiles in material order (scenes with several material types; measured slower: opt-in)
 FLAG_QUEUE_PRIMARY_RAYS = 256  # k_gen writes the primary rays even where the packet kernel could regenerate them
 
 

@@ -218,6 +218,38 @@ def blob_room(width=1920, height=1080, material=None, builder=H.BVH_BINNED_SAH, 
     return SceneBundle(scene, cam, width, height, material_textures=textures, name="blob_room")
 
 
+def mixed_material_room(width=1920, height=1080, level=6, pattern="patches", builder=H.BVH_SPATIAL_SPLIT, seed=13):
+    """The room of configs 2/3 with a mesh whose triangles carry FIVE materials -- diffuse, PBR metal, PBR dielectric, rough glass,
+    basic glass -- `patches`: by region (a low-frequency field over the surface: what a painted or assembled object looks like, the
+    hits of a wave are mostly one type), `confetti`: per triangle at random (every wave sees every type: the worst case for a shading
+    kernel that dispatches on the material)."""
+    mats5 = [L.material_diffuse((0.7, 0.7, 0.2)), L.material_pbr_metal((0.955, 0.638, 0.538), 0.8), L.material_pbr_dielectric((0.2, 0.3, 0.75), 0.7),
+             L.material_refractive(0.9, 1.5, (1.0, 0.6, 0.6), 5.0), L.material_basic_refractive(1.5, (0.5, 1.0, 0.5), 3.0)]
+    v, f = icosphere(level)
+    rng = np.random.default_rng(seed)
+    d = np.zeros(len(v))
+    for k in range(6):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        d += (0.22 / (1 + k)) * np.sin((1.5 + 1.7 * k) * (v @ axis) * np.pi + rng.uniform(0, 2 * np.pi))
+    p = (v * (0.5 * (1.0 + 0.55 * d))[:, None]).astype(np.float32)
+    if pattern == "confetti":
+        mi = rng.integers(0, 5, len(f))
+    else:
+        c = v[f].mean(axis=1)
+        field = sum(np.sin(3.1 * (c @ a) + ph) for a, ph in ((rng.normal(size=3), rng.uniform(0, 6.28)) for _ in range(4)))
+        mi = np.clip(((field - field.min()) / (np.ptp(field) + 1e-9) * 5).astype(int), 0, 4)
+    blob = H.Mesh(p, f.astype(np.uint32), mats5, material_index=mi.astype(np.uint32), builder=builder)
+    mats = _room_materials()
+    mb = _MeshBuilder()
+    _room(mb, mats)
+    scene = H.Scene()
+    scene.add_node(mb.build(mats, H.BVH_BINNED_SAH))
+    scene.add_node(blob, location=(0.0, 0.75, 0.1), scale=(1.3, 1.3, 1.3))
+    cam = _camera(width, height, (0.0, 1.0, -3.9), (0.0, 1.0, 0.0), min(40.0 * (width / height) ** 0.5, 75.0))
+    return SceneBundle(scene, cam, width, height, name=f"mixed_room_{pattern}")
+
+
 def instanced_grid(width=1920, height=1080, nx=4, nz=3, level=6, builder=H.BVH_SPATIAL_SPLIT, thin_lens=False,
                    sky_size=(2048, 1024), rotate=False):
     """Configs 4/5: nx*nz instances (translate + uniform scale only) of two unique

@@ -10,6 +10,6 @@ python3 - <<PY
 import json
 d=json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
 print(d["value"], d["roofline"]["family_ms"])
-for k in ("two_level","dynamic","configs","frame"):
+for k in ("two_level","dynamic","configs","material_order","frame"):
     print(k, json.dumps(d.get(k))[:1500])
 PY

@@ -3,13 +3,13 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; flagsets=$2; shift 2
 out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py -m gpu -q > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
+timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py -m gpu -q -k "packet or beam" > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
 [ $rc -ne 0 ] && echo "TESTS FAILED (continuing with the bench)"
 for v in "$@"; do
   lib=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_$v.so
   [ "$v" = base ] && lib=$PWD/opencl-path-tracer_amd/csrc/libptamd.so
   for fl in $flagsets; do
-  PTAMD_LIB=$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 1 --flags $fl > $out/${v}_$fl.json 2> $out/${v}_$fl.err || exit 1
+  PTAMD_LIB=$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --no-secondary --steps 3 --warmup 1 --rounds 1 --flags $fl > $out/${v}_$fl.json 2> $out/${v}_$fl.err || exit 1
   python3 - <<PY
 import json
 d=json.load(open("$out/${v}_$fl.json")); r=d["roofline"]

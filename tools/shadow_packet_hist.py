@@ -11,10 +11,10 @@ W, Hh = 1920, 1080
 b = scenes.instanced_grid(W, Hh, level=6)
 ctx = D.Context(W, Hh, seed=1, samples_in_flight=64, max_bounces=1)
 ctx.upload_scene(b.flat, sky=b.sky); ctx.set_camera(b.camera)
-out = (C.c_ulonglong * 48)()
-D.lib().pt_debug_trace_stats(out)
+out = (C.c_ulonglong * 64)()
+D.lib().pt_debug_trace_stats(out, 64)
 ctx.render(64)
-D.lib().pt_debug_trace_stats(out)
+D.lib().pt_debug_trace_stats(out, 64)
 h = np.array(list(out), np.float64)
 leaves, nodes = h[:24], h[24:]
 print("packets", int(leaves.sum()), "stats", ctx.stats()["rays_shadow"], "shadow rays")

@@ -7,8 +7,8 @@ import numpy as np
 from ptamd import scenes, device as D
 
 def read():
-    out = (C.c_ulonglong * 48)()
-    assert D.lib().pt_debug_trace_stats(out) == 0
+    out = (C.c_ulonglong * 64)()
+    assert D.lib().pt_debug_trace_stats(out, 64) == 0
     return list(out)
 
 def report(tag, s, nrays):
@@ -28,8 +28,10 @@ def report(tag, s, nrays):
               f"  hand-out {100*tha/tot:4.1f}% ({tha/max(ho,1):6.0f}/hand-out)  (request {100*s[15]/tot:4.1f}% shuffles {100*s[16]/tot:4.1f}% assign {100*s[17]/tot:4.1f}%)  vote+rest {100*(tot-tin-tle-tsp-tha)/tot:4.1f}% ({(tot-tin-tle-tsp-tha)/it:6.0f}/iter)  total/iter {tot/it:6.0f}")
 
 W, Hh = 1920, 1080
+FLAGS = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # 2: every instance entered (PT_FLAG_NO_BAKED_INSTANCES)
+print(f"context flags {FLAGS}")
 b = scenes.instanced_grid(W, Hh, level=6)
-ctx = D.Context(W, Hh, seed=1)
+ctx = D.Context(W, Hh, seed=1, flags=FLAGS)
 ctx.upload_scene(b.flat, sky=b.sky); ctx.set_camera(b.camera)
 o, d, _ = ctx.gen_rays(0, W * Hh)
 REP = 8  # launch size comparable to one bench launch
@@ -49,7 +51,7 @@ report("shadow-like", read()[24:], len(p))
 
 # the real pipeline: one 32-sample batch, per bounce depth limit (difference between rows = that bounce)
 for mb in (1, 2, 4):
-    c2 = D.Context(W, Hh, seed=1, samples_in_flight=64, max_bounces=mb)
+    c2 = D.Context(W, Hh, seed=1, samples_in_flight=64, max_bounces=mb, flags=FLAGS)
     c2.upload_scene(b.flat, sky=b.sky); c2.set_camera(b.camera)
     c2.render(64); read(); c2.reset_stats()
     c2.render(64); st = c2.stats(); s = read()
