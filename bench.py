@@ -539,14 +539,15 @@ def main():
         dist.destroy_process_group()
 
 
-def newest_traffic_json(W, Hh, level, in_flight, world):
-    """HBM traffic per unit from the committed PMC passes (profiles/roundN/traffic.json) of exactly this configuration."""
+def newest_traffic_json(W, Hh, level, in_flight, world, flags=0):
+    """HBM traffic per unit from the committed PMC passes (profiles/roundN/traffic*.json) of exactly this configuration (scene flags
+    included: instances copied / entered)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic*.json")), reverse=True):
         try:
             tj = json.load(open(path))
             c = tj["config"]
-            if (c["width"], c["height"], c["level"], c["samples_in_flight"], c["n_gpus"]) == (W, Hh, level, in_flight, world):
+            if (c["width"], c["height"], c["level"], c["samples_in_flight"], c["n_gpus"], tj.get("scene_flags", 0) & 6) == (W, Hh, level, in_flight, world, flags & 6):
                 tj["_path"] = os.path.relpath(path, ROOT)
                 return tj
         except (OSError, KeyError, ValueError):
@@ -565,7 +566,7 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
     ctx.profile_kernels(False)
     batches = spp_step // in_flight
     packets = ps["packet_launches"] > 0  # primary rays went through k_trace_packet
-    tj = newest_traffic_json(W, Hh, args.level, in_flight, world)
+    tj = newest_traffic_json(W, Hh, args.level, in_flight, world, args.flags)
     kernels = {}
 
     def add(name, what, ms, launches, units, bytes_per_unit, extra_bytes=0.0):

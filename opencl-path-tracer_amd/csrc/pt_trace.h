@@ -136,9 +136,18 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 }
 
 // TWO_LEVEL: the tree holds instance references (instances that were not copied to world space at upload); scenes that are one
-// world-space tree run the instantiation without the instance code.
+// world-space tree run the instantiation without the instance code.  Entering and leaving an instance are PARKED steps (served in
+// batches outside the hot loop, see the kernel).  Measured alternatives (round 3, benchmark scene with every instance entered, ms per
+// 256-sample batch of closest-hit bounce rays / shadow rays; parked: 30.4 / 53.1): both inside the hot loop at no extra iteration --
+// the ray transformed at the head of the inner step on the instance's root, the world-space ray re-read from the queue at the pop
+// of the sentinel -- 81 / 61 (nearly every iteration has SOME lane entering or leaving, so every iteration pays for both, and the
+// kernel spills at 72 VGPRs); only the leave inside, the world-space ray of every lane parked in LDS in place of the staged
+// packet: 36.1 / 54.4 at 7 waves per SIMD, 32.9 / 56.1 at 6.
+#ifndef PT_TRACE_MIN_WAVES_TL
+#define PT_TRACE_MIN_WAVES_TL 7
+#endif
 template <bool ANY_HIT, bool TWO_LEVEL>
-__global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
+__global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
     __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
@@ -207,10 +216,9 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
     const uint32_t totalWaves = total >> 6, gwave = gtid >> 6;
     const uint32_t spanSize = 64u * min(8u, max(1u, count / (totalWaves * 64u * 8u)));
     // (Shrinking the static packets of small launches -- the passes of a 1-spp 1280 x 720 frame hold 0.1-0.9 M rays for 0.46 M lanes --
-    // so that every wave gets a share of >= 8 rays was measured: 1.34 instead of 1.37 ms per frame alone, 1.18 instead of 1.03 ms
-    // together with the overlapped passes of ptamd.hip: more resident waves slow every wave's iteration down.)
-    constexpr uint32_t firstSize = 64u;
-    uint32_t spanNext = gwave * firstSize, spanEnd = spanNext + firstSize; // wave-uniform: claimed, not yet loaded
+    // so that every wave gets a share of >= 8 rays was measured in round 3: 1.34 instead of 1.37 ms per frame alone, 1.18 instead of
+    // 1.03 ms together with the overlapped passes of ptamd.hip: more resident waves slow every wave's iteration down.)
+    uint32_t spanNext = gwave * 64u, spanEnd = spanNext + 64u; // wave-uniform: claimed, not yet loaded
     auto requestPacket = [&]() {
         if (spanNext >= spanEnd) {
             uint32_t base = 0xFFFFFFC0u; // "nothing left"
@@ -222,19 +230,21 @@ __global__ void __launch_bounds__(kTraceBlock, PT_TRACE_MIN_WAVES) k_trace(Trace
             const uint32_t left = count > spanEnd ? count - spanEnd : 0u;
             claim = min(spanSize, max(64u, (left / (totalWaves * PT_GUIDED_SPANS)) & ~63u));
 #endif
-            if (totalWaves * firstSize < count) { // otherwise the static packets cover the queue: no dynamic part
+            // (small launches -- the passes of a 1-spp frame -- are covered by the static packets: no dynamic part, and no wave asks the
+            // cursor just to learn that: 7 168 such atomics were ~80 us of a 100-250 us launch)
+            if (gwave * 64u < count && (count + 63u) / 64u > totalWaves) {
                 if (lane == 0)
                     base = atomicAdd(ANY_HIT ? &a.ctl->shadowCursor[a.pass] : &a.ctl->extCursor[a.pass], claim);
-                base = totalWaves * firstSize + __shfl(base, 0);
+                base = totalWaves * 64u + __shfl(base, 0);
             }
             spanNext = base;
             spanEnd = base + claim;
         }
         const uint32_t base = spanNext;
+        spanNext += 64u;
         poolBase = base;
         poolNext = 0;
-        poolEnd = base < count ? min(min(64u, spanEnd - base), count - base) : 0u;
-        spanNext += 64u;
+        poolEnd = base < count ? min(64u, count - base) : 0u;
         if (poolEnd) { // wave-uniform.  Lane l copies entry l (clamped: the tail of the last packet is never handed out)
             const uint32_t e = base + min(lane, poolEnd - 1u);
             // every lane has read its ray of the previous packet (the reads were waited for before the rays were used)

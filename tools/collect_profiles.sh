@@ -6,7 +6,7 @@ tag=$1; dst=profiles/round3; mkdir -p $dst
 for pair in "final:$tag" "final_tl:${tag}_two_level"; do
   src=gpurun_out/${pair%%:*}; t=${pair##*:}
   [ -d $src ] || continue
-  cp $(ls $src/stats/*/*kernel_stats.csv | head -1) $dst/${t}_kernel_stats_bench_steps2.csv
+  cp $(ls -t $src/stats/*/*kernel_stats.csv | head -1) $dst/${t}_kernel_stats_bench_steps2.csv
   for f in $src/pmc_*.txt; do cp $f $dst/${t}_$(basename $f); done
   python3 -c "
 import json,sys
@@ -16,4 +16,5 @@ done
 [ -f gpurun_out/final/rank_emul.txt ] && grep -v amdgpu.ids gpurun_out/final/rank_emul.txt > $dst/${tag}_rank_emul.txt
 python3 tools/isa_mix.py $dst/isa_mix.json > $dst/isa_mix.txt
 python3 tools/traffic_json.py gpurun_out/final $dst/traffic.json $tag > /dev/null
+[ -d gpurun_out/final_tl ] && python3 tools/traffic_json.py gpurun_out/final_tl $dst/traffic_two_level.json ${tag}_two_level > /dev/null
 ls $dst

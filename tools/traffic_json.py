@@ -15,7 +15,10 @@ import os
 src, dst = sys.argv[1], sys.argv[2]
 tag = sys.argv[3] if len(sys.argv) > 3 else "r3"
 rnd = os.path.basename(os.path.dirname(os.path.abspath(dst)))
+TWO_LEVEL_RUN = "final_tl" in src
 mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(dst)), "isa_mix.json")))["kernels"]
+if TWO_LEVEL_RUN:
+    mix = {k.replace(", two-level>", ">"): v for k, v in mix.items() if "two-level" in k or k.startswith("k_shade")}
 
 
 def table(name):
@@ -23,10 +26,14 @@ def table(name):
     for line in open(f"{src}/pmc_{name}.txt"):
         # the production instantiations: k_shade one tile per workgroup (k_shade<false, false, true> is the tile-walking safety net), the
         # traversal kernels for scenes that are one world-space tree (<., true>: the ones that enter instances)
-        for long, short in (("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
+        for long, short in (("k_shade<false, false, false, false>", "k_shade<false>"), ("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
                             ("k_trace<true, false>", "k_trace<true>"), ("k_trace<false, false>", "k_trace<false>"),
-                            ("k_trace_packet<false, false>", "k_trace_packet<false>"), ("k_trace<true, true>", "k_trace<true,two-level>"),
-                            ("k_trace<false, true>", "k_trace<false,two-level>"), ("k_trace_packet<false, true>", "k_trace_packet<false,two-level>")):
+                            ("k_trace_packet<false, false>", "k_trace_packet<false>"),
+                            # passes taken with every instance entered (gpurun_out/final_tl): the <., true> instantiations ran; bench.py names
+                            # the kernels of its line by what they compute either way
+                            ("k_trace<true, true>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,two-level>"),
+                            ("k_trace<false, true>", "k_trace<false>" if TWO_LEVEL_RUN else "k_trace<false,two-level>"),
+                            ("k_trace_packet<false, true>", "k_trace_packet<false>" if TWO_LEVEL_RUN else "k_trace_packet<false,two-level>")):
             line = line.replace(long, short)
         m = re.match(r"(?:void )?ptd::(\S+)\s+(\S+)\s+(\d+)\s+per-dispatch\s+(\d+)\s+\((\d+) dispatches\)", line)
         if m:
@@ -51,7 +58,8 @@ HALF_COUNTED = {
     "k_shade<false>": (24.0, "ray origin, direction and hit record, 3 x 16 B per entry (a bounce ray's throughput adds 8 B)"),
     "k_gen": (0.0, "writes only"),
 }
-out = {"config": {"width": bench["config"]["width"], "height": bench["config"]["height"], "level": bench["config"]["level"],
+out = {"scene_flags": bench["config"].get("scene_flags", 0),
+       "config": {"width": bench["config"]["width"], "height": bench["config"]["height"], "level": bench["config"]["level"],
                   "samples_in_flight": bench["config"]["samples_in_flight"], "n_gpus": bench["n_gpus"]},
        "calibration": "FETCH_SIZE / WRITE_SIZE in KB, summed over the dispatches of one bench step; FETCH_SIZE counts 16 B/lane coalesced "
                       "reads at 1/2 (MI355X_MICROARCH.md; k_fold_planes -- (samples in flight - 1) planes x owned pixels x 16 B per launch -- reads back "
