@@ -1617,10 +1617,10 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         uint32_t nextNode = staticNodes + numTopInner, nextTri = staticTris;
         auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
             const pt_ctx::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
-            const bool single = root.numNodes == 0;
+            const bool single = refCount(root.ref) != 0u; // the mesh is one leaf
             if (single != !wholeTrees)
                 return;
-            if (!single && (!root.bakeable || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))) // parity mode follows the reference to the letter
+            if (!single && (!root.bakeable || root.numNodes == 0u || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))) // parity mode follows the reference to the letter
                 return;
             double w[4][8]; // [r][4..7] = row r of the world transform
             if (!invertTransform(topNodes[hInst[instIndex].topNode].invTransform, w))

@@ -142,3 +142,79 @@ def test_deforming_mesh_through_refit(gpu, builder):
         with pytest.raises(gpu.PtError, match="topology"):
             ctx.update_geometry(flat2)
     ctx.close()
+
+
+def _grid_scene(meshes, placements, seed):
+    """ground + light + one instance per placement (mesh index, x, z, scale, yaw)"""
+    scene = H.Scene()
+    mb = scenes._MeshBuilder()
+    mb.add_quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), 0)
+    scene.add_node(mb.build([L.material_pbr_dielectric((0.5, 0.5, 0.5), 0.3)], H.BVH_BINNED_SAH))
+    lb = scenes._MeshBuilder()
+    lb.add_quad((-0.6, 0, -0.6), (0.6, 0, -0.6), (0.6, 0, 0.6), (-0.6, 0, 0.6), 0)
+    scene.add_node(lb.build([L.material_emissive((1.0, 0.9, 0.75), 30.0)], H.BVH_BINNED_SAH), location=(0.0, 4.0, 0.0))
+    for m, x, z, s, yaw in placements:
+        scene.add_node(meshes[m], location=(x, 0.62 * s, z), scale=(s, s, s), orientation_wxyz=(float(np.cos(yaw / 2)), 0.0, float(np.sin(yaw / 2)), 0.0))
+    return scene
+
+
+@pytest.mark.parametrize("flags_name", ["copied", "entered"])
+def test_states_with_more_and_fewer_instances(gpu, flags_name):
+    """The static arrays (two meshes) are uploaded ONCE; the states that follow hold 2, 9 and 3 instances of them.  The dynamic sets grow
+    (more world-space copies than any state before: fresh buffers, the static part put in again from the master copy) and are reused when
+    a state needs less; every state renders like a fresh context that only ever saw it."""
+    flags = 0 if flags_name == "copied" else gpu.FLAG_NO_BAKED_INSTANCES
+    meshes = [scenes.blob_mesh(L.material_pbr_metal((0.955, 0.638, 0.538), 0.8), level=3, seed=7),
+              scenes.blob_mesh(L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7), level=3, seed=11)]
+    rng = np.random.default_rng(3)
+
+    def placements(n):
+        return [(k % 2, float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.7, 1.3)), float(rng.uniform(0, 6.28))) for k in range(n)]
+    flats = [_grid_scene(meshes, placements(n), 0).flatten() for n in (2, 9, 3, 9)]
+    for f in flats[1:]:  # same meshes in the same order: the static arrays do not change
+        assert np.array_equal(f.triangles, flats[0].triangles) and np.array_equal(f.sub_nodes, flats[0].sub_nodes)
+    cam = scenes.instanced_grid(W, Hh, nx=2, nz=2, level=2, sky_size=(16, 8)).camera
+    ctx = U.make_ctx(gpu, flats[0], W, Hh, camera=cam, seed=3, flags=flags)
+    for k, flat in enumerate(flats):
+        if k:
+            ctx.upload_dynamic_async(flat)
+            ctx.frame_tick()
+        ctx.clear()
+        ctx.render(8)
+        a = ctx.read_accum().copy()
+        fresh = U.make_ctx(gpu, flat, W, Hh, camera=cam, seed=3, flags=flags)
+        fresh.render(8)
+        assert np.array_equal(a, fresh.read_accum()), f"state {k} ({len(flat.top_nodes)} top-level nodes)"
+        fresh.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags_name", ["copied", "entered"])
+def test_top_level_leaf_that_names_an_interior_node(gpu, flags_name):
+    """A top-level leaf may name ANY node of the caller's sub-BVH array as its root (the reference just starts traversing there,
+    scene.cl:141-160).  The meshes' trees are packed root by root at pt_upload_static; a leaf that names an interior node makes that
+    node a root of its own at the next upload (the static part is converted again, every dynamic set refreshes its copy).  Hits against
+    the oracle on the same arrays: the instance now shows only the part of the mesh below that node."""
+    flags = 0 if flags_name == "copied" else gpu.FLAG_NO_BAKED_INSTANCES
+    b = scenes.instanced_grid(W, Hh, nx=2, nz=1, level=3, sky_size=(16, 8))
+    flat = b.flat
+    ctx = U.make_ctx(gpu, b, W, Hh, seed=1, flags=flags)
+    o, d = U.random_rays(30000, 8, (-3, 0.05, -3), (3, 3, 3))
+    U.compare_hits(flat, ctx.intersect(o, d), O.intersect_batch(U.oracle_scene(b), o, d, threads=8), edge_flip_frac=5e-4)
+    import copy
+    part = copy.copy(flat)
+    part.top_nodes = flat.top_nodes.copy()
+    leaves = np.flatnonzero(part.top_nodes["isLeaf"] != 0)
+    big = [int(l) for l in leaves if flat.sub_nodes["count"][int(part.top_nodes["a"][l])] == 0]  # instances whose root is an inner node
+    assert big
+    leaf = big[-1]
+    root = int(part.top_nodes["a"][leaf])
+    child = int(flat.sub_nodes["left"][root]) + 1  # the right child of the mesh root: an interior node (or a leaf) of the mesh tree
+    part.top_nodes["a"][leaf] = child
+    ctx.upload_dynamic(part)
+    got, want = ctx.intersect(o, d), O.intersect_batch(O.BoundScene(part, sky=b.sky), o, d, threads=8)
+    info = U.compare_hits(part, got, want, edge_flip_frac=5e-4)
+    assert info["n"] > 5000
+    whole = O.intersect_batch(U.oracle_scene(b), o, d, threads=8)
+    assert (want["prim"] != whole["prim"]).mean() > 0.005, "the modified instance must show less of its mesh"
+    ctx.close()
