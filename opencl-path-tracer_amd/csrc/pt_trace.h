@@ -66,13 +66,17 @@ constexpr int kTraceBlock = 256;
 #endif
 constexpr int kParkedBreakAny = PT_PARKED_BREAK_ANY; // same, any-hit traversal (only unoccluded rays park: they have a deposit to make)
 constexpr int kParkedBreak = PT_PARKED_BREAK; // leave the hot loop once this many lanes are parked on a special step or idle
-// the instantiations that enter instances park far more often (every instance entry and exit): they are served a little earlier.
-// Benchmark scene, every instance entered, (closest, any hit) = (16, 32) / (24, 40) / (32, 48): 7 663 / 7 682 / 7 563 Mrays/s
+// the instantiations that enter instances park far more often (every instance entry and exit): they are served earlier.
+// Benchmark scene, every instance entered, (closest, any hit) = (12, 16) / (16, 24) / (16, 32) / (24, 40) / (32, 48):
+// 8 191 / 8 234 / 8 233 / 8 221 / 8 032 Mrays/s (with the one-pass special section; 7 663 / 7 682 / 7 563 for the last three before it)
 #ifndef PT_PARKED_BREAK_TL
-#define PT_PARKED_BREAK_TL 24
-#define PT_PARKED_BREAK_ANY_TL 40
+#define PT_PARKED_BREAK_TL 16
+#define PT_PARKED_BREAK_ANY_TL 24
 #endif
 constexpr int kRefillIdleLanes = PT_REFILL_IDLE; // hand out new rays once this many lanes are idle
+#ifndef PT_REFILL_IDLE_TL
+#define PT_REFILL_IDLE_TL 8 // the same in the instantiations that enter instances
+#endif
 
 struct TraceArgs {
     SceneDev sc;
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nIdle = __popcll(idle);
-            if (nIdle >= kRefillIdleLanes) {
+            if (nIdle >= (TWO_LEVEL ? PT_REFILL_IDLE_TL : kRefillIdleLanes)) {
                 const uint32_t avail = poolEnd - poolNext;
                 if (avail == 0u) {
                     exhausted = true; // the request issued after the last hand-out came back empty
@@ -328,25 +332,29 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
         }
         PT_TOC(14, tHand);
         PT_TIC(tSpec);
-        // ---- resolve special references (instance entry / leave, end of traversal) -------------------
-        // They are kept OUT of the hot loop below: lanes that reach one park until the loop breaks, then all
-        // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
-        // the ray-space registers stay loop-invariant in it.
-        while (true) {
+        if constexpr (TWO_LEVEL) {
+            // ---- parked lanes of a tree with instances: ONE pass serves them all -------------------------------------------
+            // A parked lane has popped its leave-instance sentinel, stands before an instance, or is done.  What it needs follows from
+            // what comes NEXT: after the sentinel the next stack entry -- an instance (world-space ray from the queue, then the
+            // transform: exit and entry in one step), a top-level node or leaf (the world-space ray), nothing (the result).  Round 2
+            // looped here, one kind of step per round: an exit followed by an entry was two rounds.
             const bool wantSpecial = active && refCount(cur) == kRefSpecial;
             const unsigned long long m = __ballot(wantSpecial);
-            if (m == 0ull)
-                break;
-            PT_STAT(4, 1);
-            PT_STAT(7, __popcll(m));
-            if (ANY_HIT) { // a shadow ray only gets here unoccluded (an occluded one retires in its leaf step)
-                const uint32_t nFin = (uint32_t)__popcll(__ballot(wantSpecial && refIndex(cur) == kSpecialFinish));
-                if (lane == 0)
-                    ldsDeposits[wave] += nFin;
-            }
-            if (wantSpecial) {
-                const uint32_t what = refIndex(cur);
-                if (what == kSpecialFinish) {
+            if (m != 0ull) {
+                PT_STAT(4, 1);
+                PT_STAT(7, __popcll(m));
+                const bool leaving = wantSpecial && cur == kRefLeaveInstance;
+                if (leaving) {
+                    curInst = -1;
+                    cur = sp > 0 ? pop(--sp) : kRefFinish;
+                }
+                const bool finishing = wantSpecial && cur == kRefFinish;
+                if (ANY_HIT) { // a shadow ray only gets here unoccluded (an occluded one retires in its leaf step)
+                    const uint32_t nFin = (uint32_t)__popcll(__ballot(finishing));
+                    if (lane == 0)
+                        ldsDeposits[wave] += nFin;
+                }
+                if (finishing) {
                     // -------- ray finished: closestT != maxT decides hit/miss (scene.cl:257) ------------
                     if (ANY_HIT) {
                         if (a.occluded)
@@ -367,31 +375,100 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         a.inst[rayIdx] = hinst;
                     }
                     active = false;
-                } else if (TWO_LEVEL) {
-                    if (what == kSpecialLeaveInstance) {
-                        // -------- back to world space ---------------------------------------------------------
-                        {   // the world-space ray again, from the queue (instances are rarely entered: ptamd.hip copies them to world space)
-                            float4 wo = a.rayO[rayIdx], wd = a.rayD[rayIdx];
-                            if (wd.x == 0.0f) wd.x = FLT_MIN;
-                            if (wd.y == 0.0f) wd.y = FLT_MIN;
-                            if (wd.z == 0.0f) wd.z = FLT_MIN;
-                            if (wo.x == 0.0f) wo.x = -FLT_MIN;
-                            if (wo.y == 0.0f) wo.y = -FLT_MIN;
-                            if (wo.z == 0.0f) wo.z = -FLT_MIN;
-                            setRay(xyz(wo), xyz(wd));
-                        }
-                        curInst = -1;
-                        cur = sp > 0 ? pop(--sp) : kRefFinish;
-                    } else {
-                        // -------- enter instance `what` (scene.cl:116-139); instances are only ever entered from world space
+                } else if (wantSpecial) {
+                    V3 wo = co, wd = cd; // the world-space ray: still in the registers, unless the lane comes out of an instance
+                    if (leaving) {
+                        const float4 qo = a.rayO[rayIdx], qd = a.rayD[rayIdx];
+                        wo = xyz(qo), wd = xyz(qd);
+                        if (wd.x == 0.0f) wd.x = FLT_MIN;
+                        if (wd.y == 0.0f) wd.y = FLT_MIN;
+                        if (wd.z == 0.0f) wd.z = FLT_MIN;
+                        if (wo.x == 0.0f) wo.x = -FLT_MIN;
+                        if (wo.y == 0.0f) wo.y = -FLT_MIN;
+                        if (wo.z == 0.0f) wo.z = -FLT_MIN;
+                    }
+                    if (refCount(cur) == kRefSpecial) {
+                        // -------- enter instance refIndex(cur) (scene.cl:116-139); instances are only ever entered from world space
+                        const uint32_t what = refIndex(cur);
                         const Instance in = sc.instances[what];
                         V3 to, td;
-                        rayIntoInstance(in.r0, in.r1, in.r2, co, cd, &to, &td);
+                        rayIntoInstance(in.r0, in.r1, in.r2, wo, wd, &to, &td);
                         setRay(to, td);
                         curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
                         push(sp, kRefLeaveInstance);
                         sp++;
                         cur = in.rootRef;
+                    } else {
+                        setRay(wo, wd); // back in world space, at a top-level node or leaf
+                    }
+                }
+            }
+        } else {
+            // ---- resolve special references (instance entry / leave, end of traversal) -------------------
+            // They are kept OUT of the hot loop below: lanes that reach one park until the loop breaks, then all
+            // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
+            // the ray-space registers stay loop-invariant in it.
+            while (true) {
+                const bool wantSpecial = active && refCount(cur) == kRefSpecial;
+                const unsigned long long m = __ballot(wantSpecial);
+                if (m == 0ull)
+                    break;
+                PT_STAT(4, 1);
+                PT_STAT(7, __popcll(m));
+                if (ANY_HIT) { // a shadow ray only gets here unoccluded (an occluded one retires in its leaf step)
+                    const uint32_t nFin = (uint32_t)__popcll(__ballot(wantSpecial && refIndex(cur) == kSpecialFinish));
+                    if (lane == 0)
+                        ldsDeposits[wave] += nFin;
+                }
+                if (wantSpecial) {
+                    const uint32_t what = refIndex(cur);
+                    if (what == kSpecialFinish) {
+                        // -------- ray finished: closestT != maxT decides hit/miss (scene.cl:257) ------------
+                        if (ANY_HIT) {
+                            if (a.occluded)
+                                a.occluded[rayIdx] = 0u;
+                            const float4 contrib = a.rayC[rayIdx];
+                            const uint32_t pixel = asU(a.rayD[rayIdx].w);
+                            float4* ap = a.accum.at(asU(contrib.w) >> 16, pixel); // one live path per entry: plain RMW
+                            float4 px = *ap;
+                            px.x += contrib.x, px.y += contrib.y, px.z += contrib.z;
+                            *ap = px;
+                        } else {
+                            if (hprim >= 0 && hinst < 0) { // hit on a world-space copy of an instance: back to (original triangle, instance)
+                                const float4 tc = sc.tris[hprim].c;
+                                hprim = (int)asU(tc.y);
+                                hinst = (int)asU(tc.z);
+                            }
+                            a.hit[rayIdx] = make_float4(hprim >= 0 ? tClosest : INFINITY, hu, hv, asF((uint32_t)hprim));
+                            a.inst[rayIdx] = hinst;
+                        }
+                        active = false;
+                    } else if (TWO_LEVEL) {
+                        if (what == kSpecialLeaveInstance) {
+                            // -------- back to world space ---------------------------------------------------------
+                            {   // the world-space ray again, from the queue (instances are rarely entered: ptamd.hip copies them to world space)
+                                float4 wo = a.rayO[rayIdx], wd = a.rayD[rayIdx];
+                                if (wd.x == 0.0f) wd.x = FLT_MIN;
+                                if (wd.y == 0.0f) wd.y = FLT_MIN;
+                                if (wd.z == 0.0f) wd.z = FLT_MIN;
+                                if (wo.x == 0.0f) wo.x = -FLT_MIN;
+                                if (wo.y == 0.0f) wo.y = -FLT_MIN;
+                                if (wo.z == 0.0f) wo.z = -FLT_MIN;
+                                setRay(xyz(wo), xyz(wd));
+                            }
+                            curInst = -1;
+                            cur = sp > 0 ? pop(--sp) : kRefFinish;
+                        } else {
+                            // -------- enter instance `what` (scene.cl:116-139); instances are only ever entered from world space
+                            const Instance in = sc.instances[what];
+                            V3 to, td;
+                            rayIntoInstance(in.r0, in.r1, in.r2, co, cd, &to, &td);
+                            setRay(to, td);
+                            curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
+                            push(sp, kRefLeaveInstance);
+                            sp++;
+                            cur = in.rootRef;
+                        }
                     }
                 }
             }
@@ -420,7 +497,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
             const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
             const int nWork = nInner + nLeaf;
             constexpr int parkedBreak = TWO_LEVEL ? (ANY_HIT ? PT_PARKED_BREAK_ANY_TL : PT_PARKED_BREAK_TL) : (ANY_HIT ? kParkedBreakAny : kParkedBreak);
-            if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= kRefillIdleLanes))
+            if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= (TWO_LEVEL ? PT_REFILL_IDLE_TL : kRefillIdleLanes)))
                 break;
             if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
                 PT_STAT(2, 1);

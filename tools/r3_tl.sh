@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; flagsets=$2; shift 2
 out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py -m gpu -q -k "packet or beam" > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
-[ $rc -ne 0 ] && echo "TESTS FAILED (continuing with the bench)"
+#timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py -m gpu -q -k "two_level or unbaked or thousand or beam" > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
+#[ $rc -ne 0 ] && echo "TESTS FAILED (continuing with the bench)"
 for v in "$@"; do
   lib=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_$v.so
   [ "$v" = base ] && lib=$PWD/opencl-path-tracer_amd/csrc/libptamd.so
