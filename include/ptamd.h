@@ -284,6 +284,9 @@ typedef struct {
 } pt_shade_batch_io;
 int pt_shade_batch(pt_ctx* ctx, pt_shade_batch_io* io);
 
+/* test hook, no device needed: the host side of the routine that quantises up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
+ * unused slot) into the 64-byte 4-wide node the traversal kernels read (out64).  Every child box must lie inside its quantised box. */
+int pt_debug_quantise_node(const float* lo12, const float* hi12, const uint32_t* refs4, const uint8_t* empty4, uint32_t empty_ref, void* out64);
 const char* pt_version(void);
 
 #ifdef __cplusplus

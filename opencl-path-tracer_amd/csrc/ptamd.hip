@@ -1179,6 +1179,26 @@ int pt_debug_trace_stats(unsigned long long* out, unsigned int n) // n <= 64 cou
 
 const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
+// Test hook, no device needed: the host side of quantiseWideNode (pt_bake.h) -- up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
+// unused slot) into the 64-byte node the traversal kernels read.  tests/test_abi_and_layout.py checks the planes it makes against the
+// expression the kernels evaluate (origin + 2^exp * q): every child box must lie inside its quantised box.
+int pt_debug_quantise_node(const float* lo12, const float* hi12, const uint32_t* refs4, const uint8_t* empty4, uint32_t emptyRef, void* out64)
+{
+    if (!lo12 || !hi12 || !refs4 || !empty4 || !out64)
+        return PT_ERR_INVALID;
+    float lo[4][3], hi[4][3];
+    bool empty[4];
+    for (int k = 0; k < 4; k++) {
+        empty[k] = empty4[k] != 0;
+        for (int a = 0; a < 3; a++)
+            lo[k][a] = lo12[k * 3 + a], hi[k][a] = hi12[k * 3 + a];
+    }
+    WideNode w;
+    quantiseWideNode(lo, hi, refs4, empty, emptyRef, &w);
+    std::memcpy(out64, &w, sizeof(w));
+    return PT_OK;
+}
+
 int pt_create(const pt_config* cfg, pt_ctx** out)
 {
     return guarded(nullptr, "pt_create", [&]() -> int {

@@ -63,7 +63,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_uplo
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
            "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
-           "pt_intersect", "pt_gen_rays", "pt_shade_batch", "pt_version"]
+           "pt_intersect", "pt_gen_rays", "pt_shade_batch", "pt_debug_quantise_node", "pt_version"]
 
 _lib = None
 

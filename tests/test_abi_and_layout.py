@@ -62,3 +62,45 @@ def test_material_factories_fill_the_union_like_the_reference():
     assert list(e["colour"][:3]) == [500.0, 250.0, 125.0]
     d = L.material_diffuse((0.1, 0.2, 0.3))
     assert d["textureId"] == -1
+
+
+def test_quantised_child_boxes_contain_the_exact_ones():
+    """The 4-wide nodes hold their children's boxes as 8-bit planes relative to the node's origin and per-axis power-of-two scale
+    (pt_bake.h, quantiseWideNode: shared by the host's collapse and the device's world-space copies).  The planes must be CONSERVATIVE
+    when evaluated the way the traversal kernels do (origin + 2^exp * q in fp32): lower planes at or below the box, upper planes at or
+    above -- for boxes of any size and position, flat ones, far-away ones, one child or four.  Runs without a GPU."""
+    lib = ctypes.CDLL(D.DEVICE_LIB_PATH)
+    lib.pt_debug_quantise_node.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_void_p]
+    rng = np.random.default_rng(12)
+    empty_ref = (1 << 27) | 12345
+    for trial in range(3000):
+        n = int(rng.integers(1, 5))
+        centre = rng.normal(size=3) * 10.0 ** rng.uniform(-3, 4)
+        size = 10.0 ** rng.uniform(-6, 3)
+        lo = np.ones((4, 3), np.float32)
+        hi = -np.ones((4, 3), np.float32)
+        empty = np.ones(4, np.uint8)
+        for k in range(n):
+            a = centre + rng.uniform(-1, 1, 3) * size
+            ext = rng.uniform(0, 1, 3) * size * (rng.random(3) > 0.15)  # some axes flat
+            lo[k], hi[k], empty[k] = a.astype(np.float32), (a + ext).astype(np.float32), 0
+            hi[k] = np.maximum(hi[k], lo[k])
+        refs = np.arange(4, dtype=np.uint32) + 7
+        out = np.zeros(16, np.uint32)
+        assert lib.pt_debug_quantise_node(lo.ctypes.data, hi.ctypes.data, refs.ctypes.data, empty.ctypes.data, empty_ref, out.ctypes.data) == 0
+        origin = out[:3].view(np.float32)
+        exps = [(int(out[3]) >> (8 * a)) & 0xFF for a in range(3)]
+        scale = [np.float32(np.ldexp(1.0, e - 127)) for e in exps]
+        q = out[4:10]  # qlox, qhix, qloy, qhiy, qloz, qhiz: byte k = child k
+        for k in range(4):
+            assert out[12 + k] == (empty_ref if empty[k] else refs[k])
+            for a in range(3):
+                ql, qh = (int(q[2 * a]) >> (8 * k)) & 0xFF, (int(q[2 * a + 1]) >> (8 * k)) & 0xFF
+                if empty[k]:
+                    assert ql > qh, "an unused slot is an inverted box"
+                    continue
+                plane_lo = np.float32(origin[a] + scale[a] * np.float32(ql))
+                plane_hi = np.float32(origin[a] + scale[a] * np.float32(qh))
+                assert plane_lo <= lo[k, a] and plane_hi >= hi[k, a], (trial, k, a, plane_lo, lo[k, a], plane_hi, hi[k, a])
+                # and tight to within one quantisation step
+                assert lo[k, a] - plane_lo <= 1.001 * scale[a] and plane_hi - hi[k, a] <= 1.001 * scale[a]
