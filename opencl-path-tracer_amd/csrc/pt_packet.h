@@ -116,6 +116,9 @@ __device__ inline void beamSetup(const V3 co, const V3 cid, bool nx, bool ny, bo
     V3 oLo = co, oHi = co;
     if (__builtin_amdgcn_ballot_w64(co.x != asF(uni(asU(co.x))) || co.y != asF(uni(asU(co.y))) || co.z != asF(uni(asU(co.z)))) != 0ull) { // not a pinhole
         waveMin3Max3(oLo.x, oLo.y, oLo.z, oHi.x, oHi.y, oHi.z);
+        // the reference points of a converging bundle (below) are computed, not given: a few ulps of slack around their interval
+        oLo = mk(oLo.x - fabsf(oLo.x) * 0x1p-20f, oLo.y - fabsf(oLo.y) * 0x1p-20f, oLo.z - fabsf(oLo.z) * 0x1p-20f);
+        oHi = mk(oHi.x + fabsf(oHi.x) * 0x1p-20f, oHi.y + fabsf(oHi.y) * 0x1p-20f, oHi.z + fabsf(oHi.z) * 0x1p-20f);
     }
     V3 mLo = mk(fabsf(cid.x), fabsf(cid.y), fabsf(cid.z)), mHi = mLo;
     waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z);
@@ -262,12 +265,19 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
             float S, negSO, mulPos, mulNeg;
             uint32_t ofsQ;
             // the beam of the rays as they are now (co, cid; signs uniform): per axis the interval of the origins and of |1 / direction|
-            beamSetup(co, cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+            // A thin-lens packet is a CONVERGING bundle: the samples of a pixel leave from all over the lens and meet (up to the pixel's
+            // footprint) on the focal plane, which their un-normalised directions (camera.cl:71-75) put at t = 1.  Bounding such a bundle
+            // by its origins -- the lens -- and its directions is as wide as the lens everywhere, also where the picture is in focus.  The
+            // beam is therefore built around the rays' points at t = tShift = 1: a double cone whose waist is the pixel's footprint on the
+            // focal plane, and every distance in the node test below is measured from there (t' = t - tShift; boxes in front of the waist
+            // have negative t', which the sign-aware bounds were built for).  Pinhole packets: tShift = 0, the origins themselves.
+            const float tShift = (a.fused && a.fp.cam.thinLens) ? 1.0f : 0.0f; // wave-uniform
+            beamSetup(mk(fmaf(tShift, cd.x, co.x), fmaf(tShift, cd.y, co.y), fmaf(tShift, cd.z, co.z)), cid, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
             if constexpr (TWO_LEVEL) { // the world-space beam, next to the world-space ray
                 ldsSave[pwave][9][lane] = asU(S), ldsSave[pwave][10][lane] = asU(negSO), ldsSave[pwave][11][lane] = asU(mulPos);
                 ldsSave[pwave][12][lane] = asU(mulNeg), ldsSave[pwave][13][lane] = ofsQ;
             }
-            float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the packet
+            float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the packet, minus tShift (the node test's distances are t' = t - tShift)
             uint32_t stRef = 0u; // the stack: entry e is lane e
             uint32_t sp = 0u;
             uint32_t cur = rootRef;
@@ -295,7 +305,8 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                             break;
                         }
                         co = to, cd = td; // (1 / direction is only needed for the beam: it does not stay in registers here)
-                        beamSetup(co, tid, sx != 0ull, sy != 0ull, sz != 0ull, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                        beamSetup(mk(fmaf(tShift, cd.x, co.x), fmaf(tShift, cd.y, co.y), fmaf(tShift, cd.z, co.z)), tid, sx != 0ull, sy != 0ull, sz != 0ull, axis, isFar, S, negSO,
+                            mulPos, mulNeg, ofsQ);
                         curInst = (int)refIndex(cur);
                         stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
                         sp++;
@@ -332,8 +343,9 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                     v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
                     const float tn = rowShr1(v); // lane 5: the entry bound from lane 4
                     // entry <= exit, exit >= 0, entry < the packet's culling distance: three lane masks and-ed in scalar registers
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= 0.f) & __builtin_amdgcn_ballot_w64(tn < tcMax);
-                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn), 0); // bits of max(tn, 0): negative floats are negative integers
+                    // (exit >= 0 and entry < culling distance in t, i.e. exit' >= -tShift and entry' < tcMax - tShift)
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= tShift) & __builtin_amdgcn_ballot_w64(tn < tcMax);
+                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn + tShift), 0); // bits of max(entry, 0): negative floats are negative integers
                     uint32_t key[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
@@ -386,7 +398,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                     }
                     // the packet's culling distance shrinks once every ray has a hit
                     if (__builtin_amdgcn_ballot_w64(any) != 0ull && __builtin_amdgcn_ballot_w64(tClosest == INFINITY) == 0ull)
-                        tcMax = asF(uni(asU(waveMax(tClosest))));
+                        tcMax = asF(uni(asU(waveMax(tClosest)))) * (1.0f + 0x1p-20f) - tShift;
                 }
                 if (sp == 0u)
                     break;

@@ -389,29 +389,36 @@ def test_later_shade_passes_beyond_the_head_launch(gpu, monkeypatch):
     assert ref_st["rays_extension"] > 2 * 96 * 64 * 128
 
 
-def test_beam_packets_render_like_the_per_ray_kernel_from_random_viewpoints(gpu):
+@pytest.mark.parametrize("instances", ["copied", "entered_rotated"])
+def test_beam_packets_render_like_the_per_ray_kernel_from_random_viewpoints(gpu, instances):
     """End to end, from eight random viewpoints (inside the grid of meshes, grazing the ground, looking straight down an axis --
     where a direction component changes sign across the image and packets fall back to per-lane tests --, with and without a
     thin lens): the packet kernel's beam test may not lose a hit, so the image is the per-ray kernel's.  A pixel may differ
     only through an exact-t tie (a ray through the shared edge of two triangles, a split SBVH triangle listed in two leaves:
-    the traversal order picks the winner) -- a handful per image, never a systematic difference."""
+    the traversal order picks the winner) -- a handful per image, never a systematic difference.
+    Thin-lens packets are CONVERGING bundles: their beam is built around the rays' points on the focal plane (t = 1 of the un-normalised
+    directions), boxes in front of it have negative distances (pt_packet.h, tShift); near, in-focus and far geometry are all in these views.
+    `entered_rotated`: every instance (randomly rotated) is entered -- the packet takes ray and reference point into the instance's space."""
     from ptamd import host as H
     W, Hh = 160, 96
-    b = scenes.instanced_grid(W, Hh, level=4, sky_size=(16, 8))
+    b = scenes.instanced_grid(W, Hh, level=4, sky_size=(16, 8), rotate=instances == "entered_rotated")
+    base = gpu.FLAG_NO_BAKED_INSTANCES if instances == "entered_rotated" else 0
     rng = np.random.default_rng(11)
     views = [((0.0, 1.0, -6.0), (0.0, 0.5, 0.0)), ((0.1, 6.0, 0.1), (0.0, 0.0, 0.0)), ((-5.0, 0.3, 0.0), (5.0, 0.3, 0.0)), ((0.0, 0.8, 0.0), (3.0, 0.6, 2.0))]
     views += [(tuple(rng.uniform((-5, 0.2, -5), (5, 3, 5))), tuple(rng.uniform((-2, 0, -2), (2, 1, 2)))) for _ in range(4)]
     total_diff = 0
     for k, (eye, target) in enumerate(views):
         thin = k % 2 == 1
-        cam = H.camera_data(eye, H.look_at_quat(eye, target), 60.0, W / Hh, focal_distance=float(np.linalg.norm(np.subtract(target, eye))),
+        # (focus on the target, half-way to it, or far behind it: geometry on either side of the bundle's waist)
+        focus = float(np.linalg.norm(np.subtract(target, eye))) * (1.0, 0.5, 3.0)[k % 3]
+        cam = H.camera_data(eye, H.look_at_quat(eye, target), 60.0, W / Hh, focal_distance=focus,
                             thin_lens=thin, focal_length_mm=50.0 if thin else 0.0, aperture_fstops=2.0 if thin else 0.0)
         imgs = []
-        for flags in (0, gpu.FLAG_NO_PACKETS):
+        for flags in (base, base | gpu.FLAG_NO_PACKETS):
             ctx = U.make_ctx(gpu, b, W, Hh, camera=cam, seed=3, samples_in_flight=64, flags=flags)
             ctx.render(64)
             st = ctx.stats()
-            assert (st["packet_launches"] > 0) == (flags == 0)
+            assert (st["packet_launches"] > 0) == (flags == base)
             imgs.append((ctx.read_accum()[:, :3], st))
             ctx.close()
         (a, sa), (n, sn) = imgs
