@@ -373,6 +373,7 @@ def main():
                     help="weak: in_flight x N samples in flight per rank on 1/N of the pixels (per-rank load fixed); strong: in_flight x rounds "
                          "samples per pixel of the whole image per step whatever N is (job fixed)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the two_level / dynamic / configs objects of the N = 1 line")
+    ap.add_argument("--thin-lens", action="store_true", help="configs[4]'s camera: thin lens f/2 focused on the grid centre (with --width 3840 --height 2160: config 5)")
     ap.add_argument("--flags", type=int, default=0, help="pt_config.flags of the render context (2 = PT_FLAG_NO_BAKED_INSTANCES: two-level traversal)")
     ap.add_argument("--dump-accum", default=None, help="rank 0 saves the (reduced) HDR accumulator as .npy (tests)")
     args = ap.parse_args()
@@ -423,7 +424,7 @@ def main():
             dist.init_process_group(args.backend)
 
     W, Hh = args.width, args.height
-    bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT)
+    bundle = scenes.instanced_grid(W, Hh, nx=4, nz=3, level=args.level, builder=H.BVH_SPATIAL_SPLIT, thin_lens=args.thin_lens)
     flat = bundle.flat
     rects = tile_rects(W, Hh, rank, world) if world > 1 else []
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
@@ -510,9 +511,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[3]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
+                "workload": f"configs[{4 if args.thin_lens else 3}]: instanced ~1M-triangle grid (4x3 instances of two {flat.instanced_triangles // 12}-triangle "
                             f"SBVH meshes = {flat.instanced_triangles} instanced triangles, PBR metal/dielectric, procedural HDR sky + "
-                            f"emissive quad), scene handed over as the reference's two-level BVH, {W}x{Hh}, 4 bounces, NEE + Russian roulette, counter PRNG; "
+                            f"emissive quad), scene handed over as the reference's two-level BVH, {W}x{Hh}, {'thin lens f/2, ' if args.thin_lens else ''}4 bounces, NEE + Russian roulette, counter PRNG; "
                             + ("every instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES)" if args.flags & 2 else
                                "mesh instances entered at traversal, single-leaf meshes copied (PT_FLAG_TWO_LEVEL_ONLY)" if args.flags & 4 else
                                "instances copied to world space at upload (the library's default while they fit a 2 GB budget; the `two_level` "
