@@ -1022,10 +1022,14 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
 int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 {
     FrameParams fp = frameParams(c, sample);
-    if (c->passCountsPending && hipEventQuery(c->passCountsCopied) == hipSuccess) { // the latest copy has landed: adopt it
-        std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
-        c->passCountsEntries = c->passCountsPending;
-        c->passCountsPending = 0;
+    if (c->passCountsPending) {
+        if (hipEventQuery(c->passCountsCopied) == hipSuccess) { // the latest copy has landed: adopt it
+            std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
+            c->passCountsEntries = c->passCountsPending;
+            c->passCountsPending = 0;
+        } else {
+            (void)hipGetLastError(); // "not ready" is an answer, not an error: it must not be what the check at the end of the batch finds
+        }
     }
     fp.planes = batch;
     fp.interleave = 1;
