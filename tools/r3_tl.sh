@@ -1,10 +1,14 @@
 #!/bin/bash
-# GPU box: two-level variants: tools/r3_tl.sh tag "flags..." variant...
+# GPU box: the bench scene with the instances copied / entered for every named library variant:
+#   tools/r3_tl.sh tag "flags.." variant...      flags: 0 copied, 2 every instance entered, 4 only the meshes entered
+#   (base = the in-tree library; others from tools/mkvariants.sh).  TESTS=1 runs the traversal tests on the in-tree library first.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; flagsets=$2; shift 2
 out=gpurun_out/$tag; mkdir -p $out
-#timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py -m gpu -q -k "two_level or unbaked or thousand or beam" > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
-#[ $rc -ne 0 ] && echo "TESTS FAILED (continuing with the bench)"
+if [ -n "$TESTS" ]; then
+  timeout -k 10 900 python -m pytest tests/test_gpu_intersect.py -m gpu -q -k "two_level or unbaked or thousand or beam" > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
+  [ $rc -ne 0 ] && echo "TESTS FAILED" && exit $rc
+fi
 for v in "$@"; do
   lib=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_$v.so
   [ "$v" = base ] && lib=$PWD/opencl-path-tracer_amd/csrc/libptamd.so
