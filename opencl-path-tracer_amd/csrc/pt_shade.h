@@ -765,7 +765,9 @@ __device__ inline void stQ(float4* p, float4 v)
 // LOOP = true: a small grid whose workgroups walk tiles from a.firstTile on (tile += gridDim.x) -- the safety net behind a launch that
 // covers only the head of the queue (ptamd.hip, launchShade).  Slower per entry than the one-tile kernel (128 VGPRs and spills: the
 // loop keeps the scene pointers live), so it is never the main path.
-// BINNED = true (scenes whose surfaces are of more than one material type): the 512 entries of a tile are shaded in MATERIAL ORDER.  The
+// BINNED = true (opt-in, PT_FLAG_MATERIAL_BINS, for scenes whose surfaces are of more than one material type; MEASURED SLOWER than queue
+// order even with five types per triangle at random -- 34.9 vs 31.1 ms per batch: the kernel is bound by its gathers and barriers, not by
+// divergent BSDF code): the 512 entries of a tile are shaded in MATERIAL ORDER.  The
 // reference dispatches on the material inside one kernel (shading.cl:387-601) and so does shadeHit: a wave whose 64 hits are of three
 // types runs three BSDFs one after the other.  Here every thread first looks up the type of its entry's hit (4 bytes of the triangle's
 // shading record), the workgroup counting-sorts its tile by (type, miss) through LDS -- ballot ranks inside a wave, one 64-lane scan over
