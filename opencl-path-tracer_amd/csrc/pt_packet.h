@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
             const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
             float S, negSO, mulPos, mulNeg;
             uint32_t ofsQ;
-            // the beam of the rays as they are now (co, cid; signs uniform): per axis the interval of the origins and of |1 / direction|
-            // A thin-lens packet is a CONVERGING bundle: the samples of a pixel leave from all over the lens and meet (up to the pixel's
+            // The beam of the rays as they are now (signs uniform): per axis the interval of a REFERENCE POINT of every ray and of |1 / direction|.
+            // The reference point of a pinhole ray is its origin.  A thin-lens packet is a CONVERGING bundle: the samples of a pixel leave from all over the lens and meet (up to the pixel's
             // footprint) on the focal plane, which their un-normalised directions (camera.cl:71-75) put at t = 1.  Bounding such a bundle
             // by its origins -- the lens -- and its directions is as wide as the lens everywhere, also where the picture is in focus.  The
             // beam is therefore built around the rays' points at t = tShift = 1: a double cone whose waist is the pixel's footprint on the

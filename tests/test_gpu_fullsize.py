@@ -46,13 +46,17 @@ def test_full_size_properties(gpu, bundle):
     assert close.mean() > 0.97, close.mean()
 
 
-@pytest.mark.parametrize("flags_name", ["copied", "entered"])
+@pytest.mark.parametrize("flags_name", ["copied", "entered", "thin_lens"])
 def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_name):
     """What bench.py times -- config 4 with 256 samples in flight: ONE 256-sample batch whose primary rays are generated and traced by
     the packet kernel (beam test, no k_gen launch), 531 M queue entries -- held against the oracle directly: 4 096 sampled pixels at the
     full 256 spp, at the gates of the room configurations (mean bias < 2e-3, tone-mapped RMSE < 2e-3).  `entered`: the same with every
-    instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line."""
-    flags = 0 if flags_name == "copied" else gpu.FLAG_NO_BAKED_INSTANCES
+    instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line; `thin_lens`: config 5's camera
+    (f/2 focused on the grid centre) -- the packets are converging bundles walked around their waist on the focal plane."""
+    flags = gpu.FLAG_NO_BAKED_INSTANCES if flags_name == "entered" else 0
+    if flags_name == "thin_lens":
+        bundle = scenes.instanced_grid(W, H, level=6, thin_lens=True)
+        assert bundle.camera["thinLensEnabled"]
     ctx = U.make_ctx(gpu, bundle, W, H, seed=1, samples_in_flight=256, flags=flags)
     ctx.render(256)
     st = ctx.stats()
