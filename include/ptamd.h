@@ -261,6 +261,11 @@ typedef struct {
 int pt_intersect(pt_ctx* ctx, const pt_rays_soa* rays, uint32_t n, int any_hit, pt_hits_soa* hits, uint32_t repeat, float* ms_out);
 /* generatePrimaryRays (kernel.cl:24-84) for sample index `sample`: first n owned pixels, SoA out. */
 int pt_gen_rays(pt_ctx* ctx, uint32_t sample, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel);
+/* generatePrimaryRays + the first intersectWalk of one batch (src/raytracer.cpp:323-357) exactly as pt_render issues them for `batch`
+ * samples per owned pixel starting at sample index `sample` -- camera rays generated inside the traversal kernel and walked as bundles
+ * where pt_render does that.  n = owned pixels * batch; rays (optional) and hit records come back in queue order.  Fixed schedule only. */
+int pt_primary_pass(pt_ctx* ctx, uint32_t sample, uint32_t batch, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz,
+    uint32_t* pixel, pt_hits_soa* hits);
 
 /* One shade invocation per entry (kernel.cl:190-301, neeIsShading shading.cl:356-623), PT_RNG_COUNTER keying. */
 typedef struct {

@@ -1,0 +1,365 @@
+// Super-packets: one wave walks the tree ONCE for R x 64 consecutive primary rays -- every lane carries R of them.
+//
+// With 256 samples of a pixel adjacent in the queue (ptamd.hip), the packets of k_trace_packet (pt_packet.h) that follow each other are
+// packets of the SAME pixel: their beams are the same beam (the pixel's footprint) and they visit the same nodes -- the node tests, the
+// scalar tournament and the beam set-up were done once per 64 rays for what is one bundle of 256.  Here they are done once per R x 64:
+// the camera rays of a pinhole share their origin, so a lane keeps ONE origin and R directions / closest hits, the node loop is
+// k_trace_packet's beam walk unchanged (it is wave-uniform: it does not care how many rays stand behind the beam), and a leaf tests its
+// triangles against the lane's R rays -- with the origin-dependent half of Moeller-Trumbore (T = o - v0, Q = T x e1, e2 . Q) computed once
+// per triangle.  Per 64 rays: 14 node tests -> 14 / R, one beam set-up -> 1 / R; the triangle tests, the ray generation and the
+// results stay per ray.
+//
+// Serves the first closest-hit pass of the fixed schedule where the packet kernel generates the camera rays itself (`fused`), the camera
+// is a pinhole and the scene is one world-space tree; super-packets that do not qualify as a whole -- the ragged tail of the queue, rays
+// that point into more than one octant -- are walked sub-packet by sub-packet on the per-lane path (every lane its own box tests and
+// lane mask, as in k_trace_packet).  Same hits as k_trace_packet and k_trace up to exact-t ties (pt_packet.h).
+//
+// Reference semantics: traceRay, scene.cl:61-271; slab accept test bvh.cl:72,114; Moeller-Trumbore shapes.cl:20-72.
+#pragma once
+#include "pt_packet.h"
+
+#ifndef PT_MULTI_RAYS
+#define PT_MULTI_RAYS 4
+#endif
+#ifndef PT_MULTI_MIN_WAVES // per SIMD: a lane's R rays and their hit records live in registers (R = 4: 96 VGPRs)
+#define PT_MULTI_MIN_WAVES (PT_MULTI_RAYS >= 8 ? 3 : PT_MULTI_RAYS >= 4 ? 5 : 6)
+#endif
+
+namespace ptd {
+
+// Moeller-Trumbore in two halves, operation by operation.  The per-ray and packet kernels write the test as cross / dot expressions and
+// leave the choice of fused multiply-adds to the compiler; with the origin half hoisted out of the loop over a lane's rays it chooses
+// differently, and the barycentrics move in their fifth digit (cancellation in T x e1) -- harmless to a picture, but "the same hits as
+// k_trace, to the bit" is what the tests of these kernels assert.  So the sequence the compiler emits for those kernels is spelled out here:
+//   cross(a, b).x = fma(a.y, b.z, -(a.z * b.y))              dot(a, b) = fma(a.z, b.z, fma(a.x, b.x, a.y * b.y))
+//   det           = e1.z * P.z + fma(e1.x, P.x, e1.y * P.y)  (the last product rounded on its own)
+// tests/test_gpu_intersect.py (first pass of a batch) fails if the two ever drift apart.
+__device__ inline V3 crossExact(const V3 a, const V3 b)
+{
+#pragma clang fp contract(off)
+    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ inline float dotExact(const V3 a, const V3 b)
+{
+#pragma clang fp contract(off)
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
+}
+// the half that only knows the origin
+__device__ inline void triOriginHalf(const V3 o, const V3 v0, const V3 e1, const V3 e2, V3* T, V3* Q, float* e2Q)
+{
+#pragma clang fp contract(off)
+    *T = mk(o.x - v0.x, o.y - v0.y, o.z - v0.z);
+    *Q = crossExact(*T, e1);
+    *e2Q = dotExact(e2, *Q);
+}
+// the half per ray: det (the caller rejects |det| < FLT_MIN), u, v, t
+__device__ inline void triRayHalf(const V3 d, const V3 e1, const V3 e2, const V3 T, const V3 Q, const float e2Q, float* det, float* u, float* v, float* t)
+{
+#pragma clang fp contract(off)
+    const V3 P = crossExact(d, e2);
+    const float pz = e1.z * P.z;
+    *det = pz + __builtin_fmaf(e1.x, P.x, e1.y * P.y);
+    const float inv = rcpFast(*det);
+    *u = dotExact(T, P) * inv;
+    *v = dotExact(d, Q) * inv;
+    *t = e2Q * inv;
+}
+
+template <int R>
+__global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
+{
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef const u4v __attribute__((address_space(4)))* ScalarU4; // uniform address + constant space = scalar loads
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gwave = (blockIdx.x * kPacketBlock + threadIdx.x) >> 6;
+    const uint32_t totalWaves = (gridDim.x * kPacketBlock) >> 6;
+    const uint32_t count = a.ctl->extCount[a.pass];
+    const SceneDev& sc = a.sc;
+    constexpr uint32_t kPer = 64u * R;
+    const uint32_t supers = (count + kPer - 1u) / kPer;
+    const uint32_t rootRef = uni(sc.rootRef);
+    const ScalarU4 wideS = (ScalarU4)(unsigned long long)sc.wide;
+    const ScalarU4 trisS = (ScalarU4)(unsigned long long)sc.tris;
+
+    // claims as in k_trace_packet: the first span of a wave is static, later ones come from the queue cursor (one atomic per span)
+    constexpr uint32_t kSpan = PT_PACKET_DYNAMIC / R > 0 ? PT_PACKET_DYNAMIC / R : 1;
+    uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
+    for (;;) {
+        if (spanLeft == 0u) {
+            const uint32_t left = supers > spanBase ? supers - spanBase : 0u; // spanBase lags the cursor: an upper bound
+            const uint32_t claim = min(kSpan, max(1u, left / totalWaves));
+            uint32_t b = 0;
+            if (lane == 0)
+                b = atomicAdd(&a.ctl->extCursor[a.pass], claim);
+            spanBase = totalWaves * kSpan + uni(b);
+            spanLeft = claim;
+        }
+        if (spanBase >= supers)
+            break;
+        const uint32_t base = spanBase * kPer;
+        spanBase++;
+        spanLeft--;
+
+        // ---- the lane's R camera rays (entries base + 64 r + lane: consecutive lanes write consecutive queue entries) -------------
+        V3 co = mk(0.f), cd[R];
+        float tClosest[R], hu[R], hv[R];
+        int hprim[R];
+        bool whole = true; // wave-uniform: every ray exists, one origin, one octant
+        V3 mLo = mk(INFINITY), mHi = mk(0.f);
+        unsigned long long sx = 0ull, sy = 0ull, sz = 0ull, ax = ~0ull, ay = ~0ull, az = ~0ull;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + 64u * (uint32_t)r + lane;
+            const bool active = idx < count;
+            V3 o = mk(0.f), d = mk(0.f, 0.f, 1.f);
+            if (active) {
+                uint32_t px, pl;
+                primaryEntry(a.fp, a.pixelList, idx, &px, &pl);
+                primaryRay(a.fp, px, pl, &o, &d);
+                ((float4*)a.rayO)[idx] = make_float4(o.x, o.y, o.z, asF(px)); // queued for k_shade (the throughput of a primary ray is 1 and is not stored)
+                ((float4*)a.rayD)[idx] = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, pl)));
+            }
+            // zero components are nudged as at k_trace's hand-out (NO_PARALLEL_RAYS, scene.cl:123-137)
+            if (d.x == 0.0f) d.x = FLT_MIN;
+            if (d.y == 0.0f) d.y = FLT_MIN;
+            if (d.z == 0.0f) d.z = FLT_MIN;
+            if (o.x == 0.0f) o.x = -FLT_MIN;
+            if (o.y == 0.0f) o.y = -FLT_MIN;
+            if (o.z == 0.0f) o.z = -FLT_MIN;
+            if (r == 0)
+                co = o;
+            cd[r] = d;
+            tClosest[r] = INFINITY, hu[r] = hv[r] = 0.f, hprim[r] = -1;
+            const V3 id = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
+            mLo = mk(fminf(mLo.x, fabsf(id.x)), fminf(mLo.y, fabsf(id.y)), fminf(mLo.z, fabsf(id.z)));
+            mHi = mk(fmaxf(mHi.x, fabsf(id.x)), fmaxf(mHi.y, fabsf(id.y)), fmaxf(mHi.z, fabsf(id.z)));
+            const unsigned long long bx = __builtin_amdgcn_ballot_w64(id.x < 0.f), by = __builtin_amdgcn_ballot_w64(id.y < 0.f), bz = __builtin_amdgcn_ballot_w64(id.z < 0.f);
+            sx |= bx, sy |= by, sz |= bz, ax &= bx, ay &= by, az &= bz;
+            whole = whole && __builtin_amdgcn_ballot_w64(active) == ~0ull
+                && __builtin_amdgcn_ballot_w64(o.x != asF(uni(asU(co.x))) || o.y != asF(uni(asU(co.y))) || o.z != asF(uni(asU(co.z)))) == 0ull;
+        }
+        // every direction component has one sign across the R x 64 rays: no ray negative (the OR of the ballots is empty) or all of them (the AND is full)
+        whole = whole && (sx == 0ull || ax == ~0ull) && (sy == 0ull || ay == ~0ull) && (sz == 0ull || az == ~0ull);
+
+        if (whole) {
+            // ---- beam walk (pt_packet.h) for the bundle of R x 64 rays ---------------------------------------------------------------
+            const bool nx = sx != 0ull, ny = sy != 0ull, nz = sz != 0ull;
+            const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
+            const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
+            waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z); // the lanes' own intervals (over their R rays) folded over the wave
+            const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+            const float oA = axis == 0u ? co.x : (axis == 1u ? co.y : co.z); // one origin: the interval of the origins is a point
+            const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
+            const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
+            const float S = neg ? -1.f : 1.f;
+            const float negSO = -(S * oA);
+            const float mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
+            const uint32_t ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
+            float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the bundle
+            uint32_t stRef = 0u; // the stack: entry e is lane e
+            uint32_t sp = 0u;
+            uint32_t cur = rootRef;
+            while (true) {
+                if (refCount(cur) == 0u) {
+                    const uint32_t ni = refIndex(cur);
+                    const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
+                    const char* nb = (const char*)&sc.wide[ni];
+                    const float originA = *(const float*)(nb + ofsO);
+                    const uint32_t ebits = *(const uint8_t*)(nb + ofsE);
+                    const uint32_t qd = *(const uint32_t*)(nb + ofsQ);
+                    const float q = (float)((qd >> shift) & 0xFFu);
+                    const float g = fmaf(q, S * asF(ebits << 23), fmaf(S, originA, negSO));
+                    float v = g * (g >= 0.f ? mulPos : mulNeg);
+                    v = maxRowShr2(v);
+                    v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
+                    const float tn = rowShr1(v); // lane 5: the entry bound from lane 4
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= 0.f) & __builtin_amdgcn_ballot_w64(tn < tcMax);
+                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn), 0); // bits of max(tn, 0): negative floats are negative integers
+                    uint32_t key[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        key[k] = ((m >> (8 * k + 5)) & 1ull) ? ((__builtin_amdgcn_readlane(tloBits, 8 * k + 5) & ~3u) | (uint32_t)k) : (kKeyNone | (uint32_t)k);
+                    const bool s01 = key[0] < key[1], s23 = key[2] < key[3];
+                    const uint32_t k01 = s01 ? key[0] : key[1], k23 = s23 ? key[2] : key[3];
+                    const uint32_t r01 = s01 ? D.x : D.y, r23 = s23 ? D.z : D.w;
+                    const bool sl = k01 < k23;
+                    const uint32_t best = sl ? k01 : k23;
+                    if (best < kKeyNone) {
+                        const uint32_t refs[4] = { D.x, D.y, D.z, D.w };
+                        const uint32_t limit = kKeyNone - best - 1u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (key[k] - best - 1u < limit) {
+                                stRef = laneWrite(stRef, uni(refs[k]), uni(sp));
+                                sp++;
+                            }
+                        cur = sl ? r01 : r23;
+                        continue;
+                    }
+                } else {
+                    const uint32_t first = refIndex(cur), n = refCount(cur);
+                    bool any = false;
+                    for (uint32_t k = 0; k < n; k++) {
+                        const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
+                        const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
+                        const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
+                        // the half of Moeller-Trumbore that only knows the origin: once per triangle
+                        V3 T, Q;
+                        float e2Q;
+                        triOriginHalf(co, v0, e1, e2, &T, &Q, &e2Q);
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            float det, u, v, t;
+                            triRayHalf(cd[r], e1, e2, T, Q, e2Q, &det, &u, &v, &t);
+                            const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tClosest[r];
+                            if (hit) {
+                                tClosest[r] = t;
+                                hu[r] = u;
+                                hv[r] = v;
+                                hprim[r] = (int)(first + k);
+                                any = true;
+                            }
+                        }
+                    }
+                    // the bundle's culling distance shrinks once every ray has a hit
+                    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                        float far = tClosest[0];
+#pragma unroll
+                        for (int r = 1; r < R; r++)
+                            far = fmaxf(far, tClosest[r]);
+                        if (__builtin_amdgcn_ballot_w64(far == INFINITY) == 0ull)
+                            tcMax = asF(uni(asU(waveMax(far))));
+                    }
+                }
+                if (sp == 0u)
+                    break;
+                sp--;
+                cur = __builtin_amdgcn_readlane(stRef, sp);
+            }
+        } else {
+            // ---- not one bundle (ragged tail, several origins or octants): sub-packet by sub-packet, every lane for itself ------------
+            // (k_trace_packet's per-lane path: a lane tests the four child boxes for its own ray and takes part only in nodes and
+            // leaves whose box it passed -- 64-bit lane masks ride on the stack entries)
+#pragma unroll 1
+            for (int r = 0; r < R; r++) {
+                const uint32_t idx = base + 64u * (uint32_t)r + lane;
+                const bool active = idx < count;
+                V3 o = mk(0.f), d = mk(0.f, 0.f, 1.f);
+                if (active) { // the ray again (its origin was not kept): generated, not re-read -- the same bits either way
+                    uint32_t px, pl;
+                    primaryEntry(a.fp, a.pixelList, idx, &px, &pl);
+                    primaryRay(a.fp, px, pl, &o, &d);
+                }
+                if (d.x == 0.0f) d.x = FLT_MIN;
+                if (d.y == 0.0f) d.y = FLT_MIN;
+                if (d.z == 0.0f) d.z = FLT_MIN;
+                if (o.x == 0.0f) o.x = -FLT_MIN;
+                if (o.y == 0.0f) o.y = -FLT_MIN;
+                if (o.z == 0.0f) o.z = -FLT_MIN;
+                const V3 cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
+                const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                float tC = INFINITY, u_ = 0.f, v_ = 0.f;
+                int hp = -1;
+                uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
+                uint32_t sp = 0u;
+                uint32_t cur = rootRef;
+                unsigned long long curMask = __builtin_amdgcn_ballot_w64(active);
+                if (curMask != 0ull)
+                    while (true) {
+                        const bool here = __builtin_amdgcn_inverse_ballot_w64(curMask);
+                        if (refCount(cur) == 0u) {
+                            const uint32_t ni = refIndex(cur);
+                            const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u];
+                            const uint4* wp = (const uint4*)&sc.wide[ni];
+                            const uint4 B = wp[1];
+                            const uint2 C = *(const uint2*)&wp[2];
+                            const float kx = asF((A.w & 0xFFu) << 23) * cid.x, ky = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y, kz = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                            const float bx = (asF(A.x) - o.x) * cid.x, by = (asF(A.y) - o.y) * cid.y, bz = (asF(A.z) - o.z) * cid.z;
+                            const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
+                            const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
+                            const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
+                            const f2 kx2 = { kx, kx }, ky2 = { ky, ky }, kz2 = { kz, kz }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
+                            const float tLimit = here ? tC : -INFINITY; // a lane that is not in this node sees no child
+                            unsigned long long m[4];
+                            uint32_t key[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
+                                const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
+                                const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
+                                const f2 tx = __builtin_elementwise_fma(qx, kx2, bx2), ty = __builtin_elementwise_fma(qy, ky2, by2), tz = __builtin_elementwise_fma(qz, kz2, bz2);
+                                const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                                const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
+                                const float tlo = fmaxf(tmin, 0.f);
+                                const bool vis = tmax >= tlo && tmin < tLimit; // bvh.cl:72,114
+                                m[k] = __builtin_amdgcn_ballot_w64(vis);
+                                const uint32_t pick = (uint32_t)(__builtin_ffsll((long long)m[k]) - 1) & 63u;
+                                key[k] = (__builtin_amdgcn_readlane(asU(vis ? tlo : INFINITY), pick) & ~3u) | (uint32_t)k;
+                            }
+                            const bool s01 = key[0] < key[1], s23 = key[2] < key[3];
+                            const uint32_t k01 = s01 ? key[0] : key[1], k23 = s23 ? key[2] : key[3];
+                            const uint32_t r01 = s01 ? D.x : D.y, r23 = s23 ? D.z : D.w;
+                            const unsigned long long m01 = s01 ? m[0] : m[1], m23 = s23 ? m[2] : m[3];
+                            const bool sl = k01 < k23;
+                            const uint32_t best = sl ? k01 : k23;
+                            if (best < kKeyNone) {
+                                const uint32_t refs[4] = { D.x, D.y, D.z, D.w };
+                                const uint32_t limit = kKeyNone - best - 1u;
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (key[k] - best - 1u < limit) {
+                                        lanePush(stRef, stLo, stHi, uni(refs[k]), uni((uint32_t)m[k]), uni((uint32_t)(m[k] >> 32)), uni(sp));
+                                        sp++;
+                                    }
+                                cur = sl ? r01 : r23;
+                                curMask = sl ? m01 : m23;
+                                continue;
+                            }
+                        } else {
+                            const uint32_t first = refIndex(cur), n = refCount(cur);
+                            for (uint32_t k = 0; k < n; k++) {
+                                const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
+                                const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
+                                const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
+                                V3 T, Q;
+                                float e2Q, det, u, v, t;
+                                triOriginHalf(o, v0, e1, e2, &T, &Q, &e2Q);
+                                triRayHalf(d, e1, e2, T, Q, e2Q, &det, &u, &v, &t);
+                                const bool hit = here && !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tC;
+                                if (hit)
+                                    tC = t, u_ = u, v_ = v, hp = (int)(first + k);
+                            }
+                        }
+                        if (sp == 0u)
+                            break;
+                        sp--;
+                        cur = __builtin_amdgcn_readlane(stRef, sp);
+                        curMask = (unsigned long long)__builtin_amdgcn_readlane(stLo, sp) | ((unsigned long long)__builtin_amdgcn_readlane(stHi, sp) << 32);
+                    }
+                // into the lane's result slots (static indices: the arrays stay in registers)
+#pragma unroll
+                for (int q = 0; q < R; q++)
+                    if (q == r)
+                        tClosest[q] = tC, hu[q] = u_, hv[q] = v_, hprim[q] = hp;
+            }
+        }
+        // ---- results: consecutive lanes write consecutive records (scene.cl:257) -------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = base + 64u * (uint32_t)r + lane;
+            if (idx < count) {
+                int hp = hprim[r], hinst = -1;
+                if (hp >= 0) { // a world-space copy of an instance: back to (original triangle, instance)
+                    const float4 tc = sc.tris[hp].c;
+                    hp = (int)asU(tc.y);
+                    hinst = (int)asU(tc.z);
+                }
+                a.hit[idx] = make_float4(hp >= 0 ? tClosest[r] : INFINITY, hu[r], hv[r], asF((uint32_t)hp));
+                a.inst[idx] = hinst;
+            }
+        }
+    }
+}
+
+} // namespace ptd

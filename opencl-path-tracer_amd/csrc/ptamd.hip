@@ -5,6 +5,7 @@
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_packet.h"
+#include "pt_packet_multi.h"
 #include "pt_bake.h"
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
@@ -162,6 +163,7 @@ struct pt_ctx {
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks[2] = { 0, 0 };
+    uint32_t multiBlocks = 0; // persistent grid of k_trace_multi
     // live entries per pass of the most recent batch whose counters have come back (a HINT for the next batch's k_shade launches:
     // copied to pinned memory by the stream at the end of every batch, never waited for)
     uint32_t* passCountsPinned = nullptr; // kMaxPasses + 1 words
@@ -772,6 +774,11 @@ int ensureSpill(pt_ctx* c)
             pb = std::max(1, std::min(pb, atoi(e)));
         c->packetBlocks[tl] = (uint32_t)(pb * c->numCUs);
     }
+    {
+        int b = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS>, kPacketBlock, 0));
+        c->multiBlocks = (uint32_t)(std::max(1, b) * c->numCUs);
+    }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
     c->spillHalf = threads * kSpillStack;
@@ -920,10 +927,18 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
     a.inst = c->hitInst.p;
     a.ctl = ctl;
     a.pass = pass;
-    if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
-        launchPacket(c, false, a);
-    else
+    if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u)) {
+        // camera rays of a pinhole generated in the kernel, one world-space tree: PT_MULTI_RAYS x 64 consecutive entries -- the samples of
+        // one pixel, or of neighbouring pixels -- are ONE bundle and are walked as one (pt_packet_multi.h)
+        if (PT_MULTI_RAYS > 1 && fused && !c->camera.thinLens && sceneKind(c) == 0 && !(c->packetUse & 8u)) {
+            c->packetLaunches++;
+            hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS>), dim3(c->multiBlocks), dim3(kPacketBlock), 0, c->stream, a);
+        } else {
+            launchPacket(c, false, a);
+        }
+    } else {
         launchTrace(c, false, a);
+    }
 }
 
 void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr)
@@ -1016,12 +1031,24 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     }
 }
 
+// frame parameters of a batch of `batch` samples per owned pixel: how many of a pixel's samples sit next to each other in the queue
+FrameParams batchFrameParams(pt_ctx* c, uint32_t sample, uint32_t batch)
+{
+    FrameParams fp = frameParams(c, sample);
+    fp.planes = batch;
+    fp.interleave = 1;
+    while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
+        fp.interleave *= 2u, fp.interleaveShift++;
+    fp.invSpan = 1.0f / (float)((uint64_t)c->numOwned << fp.interleaveShift);
+    return fp;
+}
+
 // Fixed launch schedule for one sample when every owned pixel has its own queue slot: gen, then
 // maxBounces x (intersect, shade, shadow intersect), then the bookkeeping kernel.  No host
 // read-back anywhere (the reference blocks on a 176-byte read every pass, raytracer.cpp:381-389).
 int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 {
-    FrameParams fp = frameParams(c, sample);
+    FrameParams fp = batchFrameParams(c, sample, batch);
     if (c->passCountsPending) {
         if (hipEventQuery(c->passCountsCopied) == hipSuccess) { // the latest copy has landed: adopt it
             std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
@@ -1031,11 +1058,6 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             (void)hipGetLastError(); // "not ready" is an answer, not an error: it must not be what the check at the end of the batch finds
         }
     }
-    fp.planes = batch;
-    fp.interleave = 1;
-    while (fp.interleave < kGenInterleave && batch % (fp.interleave * 2u) == 0u)
-        fp.interleave *= 2u, fp.interleaveShift++;
-    fp.invSpan = 1.0f / (float)((uint64_t)c->numOwned << fp.interleaveShift);
     const uint32_t bounces = maxBounces(c);
     const uint32_t entries = c->numOwned * batch;
     // Where the packet kernel serves the primary rays it generates them itself, from the entry index, and queues them for
@@ -2416,6 +2438,62 @@ int pt_gen_rays(pt_ctx* c, uint32_t sample, uint32_t n, float* ox, float* oy, fl
         if (dz) dz[i] = d[i].z;
         if (pixel)
             std::memcpy(&pixel[i], &o[i].w, 4);
+    }
+    return PT_OK;
+    });
+}
+
+// The first pass of one batch exactly as pt_render issues it -- camera rays generated inside the traversal kernel where pt_render does
+// that, walked as bundles where it does that -- with the rays and the hit records read back in queue order.
+int pt_primary_pass(pt_ctx* c, uint32_t sample, uint32_t batch, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel,
+    pt_hits_soa* hits)
+{
+    return guarded(c, "pt_primary_pass", [&]() -> int {
+    if (!c || !hits || batch == 0 || n == 0)
+        return PT_ERR_INVALID;
+    if (!c->haveStatic || !c->haveDynamic || !c->haveCamera)
+        return fail(c, PT_ERR_STATE, "pt_primary_pass: scene (static + dynamic) and camera must be set first");
+    if (parityMode(c) || c->cfg.max_active_rays != 0)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_primary_pass: the fixed schedule only");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensureQueues(c)) || (rc = ensureSpill(c)))
+        return rc;
+    if (batch > c->planes || n != c->numOwned * batch)
+        return fail(c, PT_ERR_INVALID, "pt_primary_pass: batch exceeds samples_in_flight, or n != owned pixels * batch");
+    FrameParams fp = batchFrameParams(c, sample, batch);
+    const bool coherentFirst = fp.interleave >= 16u;
+    const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
+    const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
+    if (fused)
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, &c->control.p->extCount[0], &c->control.p->generated, n);
+    else
+        launchGen(c, fp, 0, 0, n, 0, 0);
+    launchIntersect(c, 0, 0, coherentFirst, fused ? &fp : nullptr);
+    std::vector<float4> o(n), d(n), h(n);
+    std::vector<int32_t> in(n);
+    HIPCHK(c, hipMemcpyAsync(o.data(), c->rays[0].o.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.data(), c->rays[0].d.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->hitH.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(in.data(), c->hitInst.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    const std::vector<uint32_t>& top = c->dyn[c->active].instanceTopNode;
+    for (uint32_t i = 0; i < n; i++) {
+        if (ox) ox[i] = o[i].x;
+        if (oy) oy[i] = o[i].y;
+        if (oz) oz[i] = o[i].z;
+        if (dx) dx[i] = d[i].x;
+        if (dy) dy[i] = d[i].y;
+        if (dz) dz[i] = d[i].z;
+        if (pixel)
+            std::memcpy(&pixel[i], &o[i].w, 4);
+        hits->t[i] = h[i].x, hits->u[i] = h[i].y, hits->v[i] = h[i].z;
+        int32_t prim;
+        std::memcpy(&prim, &h[i].w, 4);
+        hits->prim[i] = prim;
+        hits->inst[i] = (in[i] >= 0 && (size_t)in[i] < top.size()) ? (int32_t)top[in[i]] : -1;
     }
     return PT_OK;
     });

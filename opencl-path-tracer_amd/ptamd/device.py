@@ -63,7 +63,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_uplo
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
            "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
-           "pt_intersect", "pt_gen_rays", "pt_shade_batch", "pt_debug_quantise_node", "pt_version"]
+           "pt_intersect", "pt_gen_rays", "pt_primary_pass", "pt_shade_batch", "pt_debug_quantise_node", "pt_version"]
 
 _lib = None
 
@@ -117,6 +117,7 @@ def lib():
         l.pt_intersect.argtypes = [C.c_void_p, C.POINTER(RaysSoA), C.c_uint32, C.c_int, C.POINTER(HitsSoA), C.c_uint32,
                                    C.POINTER(C.c_float)]
         l.pt_gen_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 7
+        l.pt_primary_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8
         l.pt_shade_batch.argtypes = [C.c_void_p, C.POINTER(ShadeBatchIO)]
         _lib = l
     return _lib
@@ -294,6 +295,16 @@ class Context:
         pixel = np.zeros(n, np.uint32)
         self._chk(lib().pt_gen_rays(self._h, sample, n, *[_p(a) for a in arrs], _p(pixel)), "pt_gen_rays")
         return np.stack(arrs[:3], 1), np.stack(arrs[3:], 1), pixel
+
+    def primary_pass(self, sample, batch, n):
+        """first pass of one batch as pt_render issues it: (o, d, pixel, hits) in queue order"""
+        arrs = [np.zeros(n, np.float32) for _ in range(6)]
+        pixel = np.zeros(n, np.uint32)
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        prim, inst = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        hits = HitsSoA(_p(t).value, _p(u).value, _p(v).value, _p(prim).value, _p(inst).value)
+        self._chk(lib().pt_primary_pass(self._h, sample, batch, n, *[_p(a) for a in arrs], _p(pixel), C.byref(hits)), "pt_primary_pass")
+        return np.stack(arrs[:3], 1), np.stack(arrs[3:], 1), pixel, dict(t=t, u=u, v=v, prim=prim, inst=inst)
 
     def shade_batch(self, o, d, thr, pixel, flags, bounce, t, u, v, prim, inst, sample=0):
         n = len(o)

@@ -160,6 +160,39 @@ def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin, kind):
     per_ray.close()
 
 
+@pytest.mark.parametrize("kind", ["baked", "two_level", "baked_thin_lens"])
+@pytest.mark.parametrize("spp", [64, 16])
+def test_first_pass_of_a_batch_finds_the_hits_of_the_per_ray_kernel(gpu, kind, spp):
+    """pt_primary_pass runs the first pass of a batch the way pt_render does: the camera rays are generated inside the traversal kernel
+    and -- pinhole camera, one world-space tree -- bundles of several packets (the samples of one pixel, or of a few neighbouring ones)
+    walk the tree as ONE bundle (pt_packet_multi.h).  The rays it queues for the shading kernel must be the bits k_gen writes, and every
+    hit record the per-ray kernel's for that ray: same triangle and same t / u / v bits, except at exact-t ties."""
+    W, Hh = 96, 54
+    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=kind == "baked_thin_lens", sky_size=(16, 8))
+    base = gpu.FLAG_TWO_LEVEL_ONLY if kind == "two_level" else 0
+    first = U.make_ctx(gpu, b, W, Hh, flags=base, samples_in_flight=spp)
+    queued = U.make_ctx(gpu, b, W, Hh, flags=base | gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=spp)
+    n = W * Hh * spp
+    for sample in (0, spp):
+        o, d, pixel, got = first.primary_pass(sample, spp, n)
+        o2, d2, pixel2, want = queued.primary_pass(sample, spp, n)  # k_gen + the per-ray kernel
+        assert np.array_equal(pixel, pixel2)
+        assert np.array_equal(o.view(np.uint32), o2.view(np.uint32)) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+        again = queued.intersect(o, d)  # the hook, rays handed in
+        for k in ("t", "u", "v", "prim", "inst"):
+            assert np.array_equal(again[k], want[k]), k
+        same = (got["prim"] == want["prim"]) & (got["inst"] == want["inst"])
+        diff = ~same
+        assert diff.mean() < 1e-3, diff.sum()
+        assert np.allclose(got["t"][diff], want["t"][diff], rtol=1e-6)
+        for k in ("t", "u", "v"):
+            assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+        assert 0.3 < (got["prim"] >= 0).mean() < 1.0
+    assert first.stats()["packet_launches"] == 2 and queued.stats()["packet_launches"] == 0
+    first.close()
+    queued.close()
+
+
 @pytest.mark.parametrize("mode", ["baked", "unbaked", "unbaked_packet"])
 def test_thousand_instances_of_a_small_mesh(gpu, mode):
     """1 000 rotated, scaled instances of a 1 280-triangle mesh (1.28 M instanced triangles): here the TOP level is the deep tree
