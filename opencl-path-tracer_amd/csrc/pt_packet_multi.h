@@ -65,9 +65,51 @@ __device__ inline void triRayHalf(const V3 d, const V3 e1, const V3 e2, const V3
     *t = e2Q * inv;
 }
 
+// Do the R x 64 directions point into one octant?  Per axis: the interval of |1 / direction| over the lane's rays (folded over the wave by
+// bundleBeam) and the common sign.
 template <int R>
+__device__ inline bool bundleOctant(const V3 (&d)[R], V3& mLo, V3& mHi, bool& nx, bool& ny, bool& nz)
+{
+    mLo = mk(INFINITY), mHi = mk(0.f);
+    unsigned long long sx = 0ull, sy = 0ull, sz = 0ull, ax = ~0ull, ay = ~0ull, az = ~0ull;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const V3 id = mk(rcpSlab(d[r].x), rcpSlab(d[r].y), rcpSlab(d[r].z));
+        mLo = mk(fminf(mLo.x, fabsf(id.x)), fminf(mLo.y, fabsf(id.y)), fminf(mLo.z, fabsf(id.z)));
+        mHi = mk(fmaxf(mHi.x, fabsf(id.x)), fmaxf(mHi.y, fabsf(id.y)), fmaxf(mHi.z, fabsf(id.z)));
+        const unsigned long long bx = __builtin_amdgcn_ballot_w64(id.x < 0.f), by = __builtin_amdgcn_ballot_w64(id.y < 0.f), bz = __builtin_amdgcn_ballot_w64(id.z < 0.f);
+        sx |= bx, sy |= by, sz |= bz, ax &= bx, ay &= by, az &= bz;
+    }
+    nx = sx != 0ull, ny = sy != 0ull, nz = sz != 0ull;
+    // every direction component has one sign across the R x 64 rays: no ray negative (the OR of the ballots is empty) or all of them (the AND is full)
+    return (sx == 0ull || ax == ~0ull) && (sy == 0ull || ay == ~0ull) && (sz == 0ull || az == ~0ull);
+}
+// the constants of the lane's role (axis, entry | exit plane) in the node test, for a bundle with ONE origin (beamSetup, pt_packet.h)
+__device__ inline void bundleBeam(const V3 co, V3 mLo, V3 mHi, bool nx, bool ny, bool nz, uint32_t axis, uint32_t isFar, float& S, float& negSO, float& mulPos,
+    float& mulNeg, uint32_t& ofsQ)
+{
+    waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z); // the lanes' own intervals (over their R rays) folded over the wave
+    const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+    const float oA = axis == 0u ? co.x : (axis == 1u ? co.y : co.z); // one origin: the interval of the origins is a point
+    const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
+    const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
+    S = neg ? -1.f : 1.f;
+    negSO = -(S * oA);
+    mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
+    ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
+}
+
+// TWO_LEVEL: the tree holds instance references (k_trace_packet's scheme, pt_packet.h).  Entering an instance is a wave-uniform event: every
+// lane takes its origin and its R directions into the instance's space, the beam is rebuilt from them, a sentinel goes onto the stack;
+// popping it brings the world-space rays and beam back from LDS (8 + 3 R dwords per lane).  Which instance a ray's closest hit lies in
+// is kept in LDS too (written when a hit is accepted -- a few times per ray -- instead of R more registers).  A transform that turns the
+// bundle into more than one octant ends the beam walk: the bundle starts over, sub-packet by sub-packet.
+template <int R, bool TWO_LEVEL>
 __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
 {
+    constexpr int kSaveRay = 0, kSaveBeam = 3 + 3 * R, kSaveInst = kSaveBeam + 5, kSave = kSaveInst + R;
+    __shared__ uint32_t ldsSave[TWO_LEVEL ? kPacketBlock / 64 : 1][TWO_LEVEL ? kSave : 1][64];
+    const uint32_t pwave = threadIdx.x >> 6;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef const u4v __attribute__((address_space(4)))* ScalarU4; // uniform address + constant space = scalar loads
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -106,8 +148,6 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
         float tClosest[R], hu[R], hv[R];
         int hprim[R];
         bool whole = true; // wave-uniform: every ray exists, one origin, one octant
-        V3 mLo = mk(INFINITY), mHi = mk(0.f);
-        unsigned long long sx = 0ull, sy = 0ull, sz = 0ull, ax = ~0ull, ay = ~0ull, az = ~0ull;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = base + 64u * (uint32_t)r + lane;
@@ -131,37 +171,75 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                 co = o;
             cd[r] = d;
             tClosest[r] = INFINITY, hu[r] = hv[r] = 0.f, hprim[r] = -1;
-            const V3 id = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
-            mLo = mk(fminf(mLo.x, fabsf(id.x)), fminf(mLo.y, fabsf(id.y)), fminf(mLo.z, fabsf(id.z)));
-            mHi = mk(fmaxf(mHi.x, fabsf(id.x)), fmaxf(mHi.y, fabsf(id.y)), fmaxf(mHi.z, fabsf(id.z)));
-            const unsigned long long bx = __builtin_amdgcn_ballot_w64(id.x < 0.f), by = __builtin_amdgcn_ballot_w64(id.y < 0.f), bz = __builtin_amdgcn_ballot_w64(id.z < 0.f);
-            sx |= bx, sy |= by, sz |= bz, ax &= bx, ay &= by, az &= bz;
+            if constexpr (TWO_LEVEL)
+                ldsSave[pwave][kSaveInst + r][lane] = 0xFFFFFFFFu;
             whole = whole && __builtin_amdgcn_ballot_w64(active) == ~0ull
                 && __builtin_amdgcn_ballot_w64(o.x != asF(uni(asU(co.x))) || o.y != asF(uni(asU(co.y))) || o.z != asF(uni(asU(co.z)))) == 0ull;
         }
-        // every direction component has one sign across the R x 64 rays: no ray negative (the OR of the ballots is empty) or all of them (the AND is full)
-        whole = whole && (sx == 0ull || ax == ~0ull) && (sy == 0ull || ay == ~0ull) && (sz == 0ull || az == ~0ull);
+        V3 mLo, mHi;
+        bool nx, ny, nz;
+        whole = bundleOctant<R>(cd, mLo, mHi, nx, ny, nz) && whole;
 
         if (whole) {
             // ---- beam walk (pt_packet.h) for the bundle of R x 64 rays ---------------------------------------------------------------
-            const bool nx = sx != 0ull, ny = sy != 0ull, nz = sz != 0ull;
             const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
             const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
-            waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z); // the lanes' own intervals (over their R rays) folded over the wave
-            const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
-            const float oA = axis == 0u ? co.x : (axis == 1u ? co.y : co.z); // one origin: the interval of the origins is a point
-            const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
-            const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
-            const float S = neg ? -1.f : 1.f;
-            const float negSO = -(S * oA);
-            const float mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
-            const uint32_t ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
+            float S, negSO, mulPos, mulNeg;
+            uint32_t ofsQ;
+            bundleBeam(co, mLo, mHi, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+            int curInst = -1; // wave-uniform
+            if constexpr (TWO_LEVEL) { // the world-space rays and beam, for the way back out of an instance
+                ldsSave[pwave][kSaveRay + 0][lane] = asU(co.x), ldsSave[pwave][kSaveRay + 1][lane] = asU(co.y), ldsSave[pwave][kSaveRay + 2][lane] = asU(co.z);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    ldsSave[pwave][kSaveRay + 3 + 3 * r][lane] = asU(cd[r].x), ldsSave[pwave][kSaveRay + 4 + 3 * r][lane] = asU(cd[r].y),
+                                  ldsSave[pwave][kSaveRay + 5 + 3 * r][lane] = asU(cd[r].z);
+                ldsSave[pwave][kSaveBeam + 0][lane] = asU(S), ldsSave[pwave][kSaveBeam + 1][lane] = asU(negSO), ldsSave[pwave][kSaveBeam + 2][lane] = asU(mulPos);
+                ldsSave[pwave][kSaveBeam + 3][lane] = asU(mulNeg), ldsSave[pwave][kSaveBeam + 4][lane] = ofsQ;
+            }
             float tcMax = INFINITY; // wave-uniform: the farthest closest hit of the bundle
             uint32_t stRef = 0u; // the stack: entry e is lane e
             uint32_t sp = 0u;
             uint32_t cur = rootRef;
             while (true) {
-                if (refCount(cur) == 0u) {
+                if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
+                    if (cur != kRefLeaveInstance) {
+                        // -------- enter instance refIndex(cur): instances are only ever entered from world space -------------------------
+                        typedef const u4v_t __attribute__((address_space(4)))* ScalarU4i;
+                        const ScalarU4i mrow = (ScalarU4i)(unsigned long long)&sc.instances[refIndex(cur)];
+                        const u4v_t m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
+                        const float4 r0 = make_float4(asF(m0.x), asF(m0.y), asF(m0.z), asF(m0.w)), r1 = make_float4(asF(m1.x), asF(m1.y), asF(m1.z), asF(m1.w)),
+                                     r2 = make_float4(asF(m2.x), asF(m2.y), asF(m2.z), asF(m2.w));
+                        V3 to = co, td[R];
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+                            rayIntoInstance(r0, r1, r2, co, cd[r], &to, &td[r]); // (the origin is the same R times: folded by the compiler)
+                        V3 tLo, tHi;
+                        bool tnx, tny, tnz;
+                        if (!bundleOctant<R>(td, tLo, tHi, tnx, tny, tnz)) {
+                            whole = false; // the bundle no longer points into one octant: start over, sub-packet by sub-packet
+                            break;
+                        }
+                        co = to;
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+                            cd[r] = td[r];
+                        bundleBeam(co, tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                        curInst = (int)refIndex(cur);
+                        stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
+                        sp++;
+                        cur = uni(mrow[3].x);
+                        continue;
+                    }
+                    // -------- the sentinel: back to the world-space rays and beam -------------------------------------------------------
+                    co = mk(asF(ldsSave[pwave][kSaveRay + 0][lane]), asF(ldsSave[pwave][kSaveRay + 1][lane]), asF(ldsSave[pwave][kSaveRay + 2][lane]));
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        cd[r] = mk(asF(ldsSave[pwave][kSaveRay + 3 + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 4 + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 5 + 3 * r][lane]));
+                    S = asF(ldsSave[pwave][kSaveBeam + 0][lane]), negSO = asF(ldsSave[pwave][kSaveBeam + 1][lane]), mulPos = asF(ldsSave[pwave][kSaveBeam + 2][lane]);
+                    mulNeg = asF(ldsSave[pwave][kSaveBeam + 3][lane]), ofsQ = ldsSave[pwave][kSaveBeam + 4][lane];
+                    curInst = -1;
+                } else if (refCount(cur) == 0u) {
                     const uint32_t ni = refIndex(cur);
                     const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
                     const char* nb = (const char*)&sc.wide[ni];
@@ -218,6 +296,8 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                                 hu[r] = u;
                                 hv[r] = v;
                                 hprim[r] = (int)(first + k);
+                                if constexpr (TWO_LEVEL)
+                                    ldsSave[pwave][kSaveInst + r][lane] = (uint32_t)curInst;
                                 any = true;
                             }
                         }
@@ -237,7 +317,8 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                 sp--;
                 cur = __builtin_amdgcn_readlane(stRef, sp);
             }
-        } else {
+        }
+        if (!whole) {
             // ---- not one bundle (ragged tail, several origins or octants): sub-packet by sub-packet, every lane for itself ------------
             // (k_trace_packet's per-lane path: a lane tests the four child boxes for its own ray and takes part only in nodes and
             // leaves whose box it passed -- 64-bit lane masks ride on the stack entries)
@@ -257,8 +338,12 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                 if (o.x == 0.0f) o.x = -FLT_MIN;
                 if (o.y == 0.0f) o.y = -FLT_MIN;
                 if (o.z == 0.0f) o.z = -FLT_MIN;
-                const V3 cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
-                const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                V3 cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
+                bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                const V3 wo = o, wd = d; // TWO_LEVEL: the world-space ray, for the way back out of an instance
+                int curInst = -1; // wave-uniform
+                if constexpr (TWO_LEVEL)
+                    ldsSave[pwave][kSaveInst + r][lane] = 0xFFFFFFFFu; // (a bundle that left the beam walk starts from nothing)
                 float tC = INFINITY, u_ = 0.f, v_ = 0.f;
                 int hp = -1;
                 uint32_t stRef = 0u, stLo = 0u, stHi = 0u; // the stack: entry e is lane e
@@ -268,7 +353,23 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                 if (curMask != 0ull)
                     while (true) {
                         const bool here = __builtin_amdgcn_inverse_ballot_w64(curMask);
-                        if (refCount(cur) == 0u) {
+                        if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
+                            if (cur != kRefLeaveInstance) { // enter: every lane transforms its ray, the lanes of curMask walk the subtree
+                                V3 to, td;
+                                uint32_t root;
+                                packetIntoInstance(sc.instances, refIndex(cur), o, d, &to, &td, &root);
+                                o = to, d = td, cid = mk(rcpSlab(td.x), rcpSlab(td.y), rcpSlab(td.z));
+                                nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                                curInst = (int)refIndex(cur);
+                                lanePush(stRef, stLo, stHi, kRefLeaveInstance, 0u, 0u, uni(sp));
+                                sp++;
+                                cur = uni(root);
+                                continue; // same lane mask
+                            }
+                            o = wo, d = wd, cid = mk(rcpSlab(d.x), rcpSlab(d.y), rcpSlab(d.z));
+                            nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                            curInst = -1;
+                        } else if (refCount(cur) == 0u) {
                             const uint32_t ni = refIndex(cur);
                             const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u];
                             const uint4* wp = (const uint4*)&sc.wide[ni];
@@ -327,8 +428,11 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                                 triOriginHalf(o, v0, e1, e2, &T, &Q, &e2Q);
                                 triRayHalf(d, e1, e2, T, Q, e2Q, &det, &u, &v, &t);
                                 const bool hit = here && !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tC;
-                                if (hit)
+                                if (hit) {
                                     tC = t, u_ = u, v_ = v, hp = (int)(first + k);
+                                    if constexpr (TWO_LEVEL)
+                                        ldsSave[pwave][kSaveInst + r][lane] = (uint32_t)curInst;
+                                }
                             }
                         }
                         if (sp == 0u)
@@ -350,7 +454,9 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
             const uint32_t idx = base + 64u * (uint32_t)r + lane;
             if (idx < count) {
                 int hp = hprim[r], hinst = -1;
-                if (hp >= 0) { // a world-space copy of an instance: back to (original triangle, instance)
+                if constexpr (TWO_LEVEL)
+                    hinst = (int)ldsSave[pwave][kSaveInst + r][lane];
+                if (hp >= 0 && hinst < 0) { // a world-space copy of an instance: back to (original triangle, instance)
                     const float4 tc = sc.tris[hp].c;
                     hp = (int)asU(tc.y);
                     hinst = (int)asU(tc.z);

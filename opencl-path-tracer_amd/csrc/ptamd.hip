@@ -163,7 +163,7 @@ struct pt_ctx {
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks[2] = { 0, 0 };
-    uint32_t multiBlocks = 0; // persistent grid of k_trace_multi
+    uint32_t multiBlocks[2] = { 0, 0 }; // persistent grid of k_trace_multi [without | with instance references in the tree]
     // live entries per pass of the most recent batch whose counters have come back (a HINT for the next batch's k_shade launches:
     // copied to pinned memory by the stream at the end of every batch, never waited for)
     uint32_t* passCountsPinned = nullptr; // kMaxPasses + 1 words
@@ -776,8 +776,10 @@ int ensureSpill(pt_ctx* c)
     }
     {
         int b = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS>, kPacketBlock, 0));
-        c->multiBlocks = (uint32_t)(std::max(1, b) * c->numCUs);
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, false>, kPacketBlock, 0));
+        c->multiBlocks[0] = (uint32_t)(std::max(1, b) * c->numCUs);
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, true>, kPacketBlock, 0));
+        c->multiBlocks[1] = (uint32_t)(std::max(1, b) * c->numCUs);
     }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
@@ -928,11 +930,14 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
     a.ctl = ctl;
     a.pass = pass;
     if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u)) {
-        // camera rays of a pinhole generated in the kernel, one world-space tree: PT_MULTI_RAYS x 64 consecutive entries -- the samples of
+        // camera rays of a pinhole generated in the kernel: PT_MULTI_RAYS x 64 consecutive entries -- the samples of
         // one pixel, or of neighbouring pixels -- are ONE bundle and are walked as one (pt_packet_multi.h)
-        if (PT_MULTI_RAYS > 1 && fused && !c->camera.thinLens && sceneKind(c) == 0 && !(c->packetUse & 8u)) {
+        if (PT_MULTI_RAYS > 1 && fused && !c->camera.thinLens && !(c->packetUse & 8u)) {
             c->packetLaunches++;
-            hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS>), dim3(c->multiBlocks), dim3(kPacketBlock), 0, c->stream, a);
+            if (sceneKind(c) != 0)
+                hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, true>), dim3(c->multiBlocks[1]), dim3(kPacketBlock), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, false>), dim3(c->multiBlocks[0]), dim3(kPacketBlock), 0, c->stream, a);
         } else {
             launchPacket(c, false, a);
         }

@@ -160,16 +160,18 @@ def test_beam_packets_find_the_hits_of_the_per_ray_kernel(gpu, thin, kind):
     per_ray.close()
 
 
-@pytest.mark.parametrize("kind", ["baked", "two_level", "baked_thin_lens"])
+@pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated", "baked_thin_lens"])
 @pytest.mark.parametrize("spp", [64, 16])
 def test_first_pass_of_a_batch_finds_the_hits_of_the_per_ray_kernel(gpu, kind, spp):
     """pt_primary_pass runs the first pass of a batch the way pt_render does: the camera rays are generated inside the traversal kernel
-    and -- pinhole camera, one world-space tree -- bundles of several packets (the samples of one pixel, or of a few neighbouring ones)
-    walk the tree as ONE bundle (pt_packet_multi.h).  The rays it queues for the shading kernel must be the bits k_gen writes, and every
+    and -- pinhole camera -- bundles of several packets (the samples of one pixel, or of a few neighbouring ones) walk the tree as ONE
+    bundle (pt_packet_multi.h).  The rays it queues for the shading kernel must be the bits k_gen writes, and every
     hit record the per-ray kernel's for that ray: same triangle and same t / u / v bits, except at exact-t ties."""
     W, Hh = 96, 54
-    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=kind == "baked_thin_lens", sky_size=(16, 8))
-    base = gpu.FLAG_TWO_LEVEL_ONLY if kind == "two_level" else 0
+    # two_level / unbaked_rotated: the bundle enters instances as a wave; behind a rotation some bundles point into more than one octant
+    # and start over sub-packet by sub-packet
+    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=kind == "baked_thin_lens", sky_size=(16, 8), rotate=kind == "unbaked_rotated")
+    base = {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "unbaked_rotated": gpu.FLAG_NO_BAKED_INSTANCES}.get(kind, 0)
     first = U.make_ctx(gpu, b, W, Hh, flags=base, samples_in_flight=spp)
     queued = U.make_ctx(gpu, b, W, Hh, flags=base | gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=spp)
     n = W * Hh * spp
