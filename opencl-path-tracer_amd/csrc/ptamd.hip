@@ -1253,7 +1253,8 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     if (const char* hs = getenv("PTAMD_SHADE_HEAD_SHIFT"))
         c->shadeHeadShift = (uint32_t)std::max(0, atoi(hs));
     if (const char* pk = getenv("PTAMD_PACKET")) // diagnostics: which launches may use k_trace_packet (bit 0 primary, 1 shadow, 2 pt_intersect)
-        c->packetUse = (uint32_t)atoi(pk);
+        if (!(cfg->flags & PT_FLAG_NO_PACKETS))
+            c->packetUse = (uint32_t)atoi(pk) | (c->packetUse & 4u);
     c->device = cfg->device;
     auto bail = [&](hipError_t err, const char* what) {
         int rc = fail(nullptr, PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(err));
