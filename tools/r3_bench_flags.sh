@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: headline bench lines for scene flags 0 (instances copied to world space) and 2 (entered), no secondary objects.  tools/r4_bench.sh tag
+# GPU box: headline bench lines for scene flags 0 (instances copied to world space) and 2 (entered), no secondary objects.  tools/r3_bench_flags.sh tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 300 python -m pytest tests/test_gpu_intersect.py tests/test_gpu_render.py -m gpu -q -x > $out/pytest.log 2>&1 || { tail -30 $out/pytest.log; exit 1; }
