@@ -881,6 +881,10 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
+#ifndef PT_FRAME_BUNDLES
+#define PT_FRAME_BUNDLES 0 // 1: the camera rays of a 1-spp frame (pinhole) as bundles of 256 neighbouring pixels through k_trace_multi.  Measured (1280 x 720,
+                           // one bundle per wave): 1.39 instead of 1.02 ms per frame -- 3 600 walks of a 32 x 8-pixel beam, each a chain of > 100 dependent leaf visits
+#endif
 #ifndef PT_FUSED_PRIMARY
 #define PT_FUSED_PRIMARY 1 // primary rays regenerated by the packet kernel and the first k_shade instead of queued by k_gen
 #endif
@@ -913,6 +917,12 @@ void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
     }
 }
 
+// first pass of a batch: may the camera rays be generated inside k_trace_multi and walk the tree as bundles (pinhole camera)?
+inline bool primaryBundles(const pt_ctx* c) { return PT_MULTI_RAYS > 1 && !c->camera.thinLens && !(c->packetUse & 8u) && c->dyn[c->active].packetOk && (c->packetUse & 1u); }
+// are consecutive entries of the first queue of a batch rays of one pixel or of neighbouring pixels?  >= 16 samples of a pixel next to each other, or the
+// pixels of a 1-spp frame in the order of the pixel list (8 x 8 blocks unless the caller chose otherwise) where bundles of 256 serve them
+inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
+
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
 void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr)
 {
@@ -932,7 +942,7 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
     if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u)) {
         // camera rays of a pinhole generated in the kernel: PT_MULTI_RAYS x 64 consecutive entries -- the samples of
         // one pixel, or of neighbouring pixels -- are ONE bundle and are walked as one (pt_packet_multi.h)
-        if (PT_MULTI_RAYS > 1 && fused && !c->camera.thinLens && !(c->packetUse & 8u)) {
+        if (fused && primaryBundles(c)) {
             c->packetLaunches++;
             if (sceneKind(c) != 0)
                 hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, true>), dim3(c->multiBlocks[1]), dim3(kPacketBlock), 0, c->stream, a);
@@ -1074,7 +1084,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // 1280x720 frame is 14 k packets for 8 k persistent waves claiming 16 at a time: 2.2-2.4 ms per frame instead of 1.4-1.6.)
     // (8x8-pixel packets for a 1-spp frame were measured again in round 3 with one packet per claim: 271 us for the 14 400 packets of
     // a 1280 x 720 frame against 251 us through the per-ray kernel -- 1.8 rounds of latency-bound packet walks on 8 192 waves)
-    const bool coherentFirst = fp.interleave >= 16u;
+    const bool coherentFirst = firstPassCoherent(c, fp, batch);
     const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
     prof.begin(0);
@@ -2468,7 +2478,7 @@ int pt_primary_pass(pt_ctx* c, uint32_t sample, uint32_t batch, uint32_t n, floa
     if (batch > c->planes || n != c->numOwned * batch)
         return fail(c, PT_ERR_INVALID, "pt_primary_pass: batch exceeds samples_in_flight, or n != owned pixels * batch");
     FrameParams fp = batchFrameParams(c, sample, batch);
-    const bool coherentFirst = fp.interleave >= 16u;
+    const bool coherentFirst = firstPassCoherent(c, fp, batch);
     const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
     if (fused)
