@@ -592,7 +592,10 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
         BYTES_PER_SHADOW_RAY, BYTES_PER_DEPOSIT * dep_shadow)
     add("k_trace<false>", "closest-hit traversal, one ray per lane (bounce rays%s)" % ("" if packets else " and primary rays"),
         ps["ms_intersect"] - ps["ms_packet"], (3 if packets else 4) * batches, ps["rays_extension"] - primary, BYTES_PER_EXT_RAY)
-    add("k_trace_packet<false>", "closest-hit traversal of the primary rays, one packet of 64 per wave"
+    bundles = ps.get("bundle_launches", 0) > 0  # k_trace_multi: one tree walk per 4 x 64 camera rays
+    add("k_trace_multi<4>" if bundles else "k_trace_packet<false>",
+        ("closest-hit traversal of the primary rays, one bundle of 4 x 64 per wave (one tree walk, four rays per lane)" if bundles
+         else "closest-hit traversal of the primary rays, one packet of 64 per wave")
         + (" (generates the camera rays itself and queues them for k_shade: 32 B written per ray instead of 28 B read)" if fused else ""),
         ps["ms_packet"], batches, primary, BYTES_PER_GEN_RAY + 20 if fused else BYTES_PER_EXT_RAY)
     add("k_shade<false>", "shade + NEE + continuation + compaction (+ deposits of emissive hits and sky misses)", ps["ms_shade"], 4 * batches,

@@ -168,11 +168,12 @@ typedef struct {
     double ms_last_render; /* device time of the last pt_render (hipEvent, whole call) */
     double ms_intersect, ms_shade, ms_shadow, ms_gen; /* per-kernel-family device ms of the last pt_render
                                                         (only when PT_PROFILE_KERNELS was requested) */
-    uint64_t packet_launches; /* launches of the packet traversal kernel (primary rays of a world-space scene) */
+    uint64_t packet_launches; /* launches of the packet traversal kernels (first pass of a batch with >= 16 samples of a pixel next to each other) */
     double ms_packet; /* the part of ms_intersect spent in the packet traversal kernel */
     uint64_t deposits_shadow; /* the part of `deposits` made by the any-hit traversal (unoccluded shadow rays,
                                  kernel.cl:132-135); the rest are emissive hits and sky misses in shade */
     uint64_t gen_launches; /* launches of the primary-ray kernel (generatePrimaryRays); 0 where the packet traversal kernel generates the camera rays itself */
+    uint64_t bundle_launches; /* of packet_launches: those that walked the tree once per bundle of several packets (camera rays of a pinhole, generated in the kernel) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

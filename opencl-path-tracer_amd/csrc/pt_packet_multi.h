@@ -201,7 +201,16 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
             uint32_t stRef = 0u; // the stack: entry e is lane e
             uint32_t sp = 0u;
             uint32_t cur = rootRef;
+#ifdef PT_TRACE_STATS
+            uint32_t stNodes = 0u, stLeaves = 0u, stTris = 0u;
+#endif
             while (true) {
+#ifdef PT_TRACE_STATS
+                if (refCount(cur) == 0u)
+                    stNodes++;
+                else if (refCount(cur) != kRefSpecial)
+                    stLeaves++, stTris += refCount(cur);
+#endif
                 if (TWO_LEVEL && refCount(cur) == kRefSpecial) { // wave-uniform
                     if (cur != kRefLeaveInstance) {
                         // -------- enter instance refIndex(cur): instances are only ever entered from world space -------------------------
@@ -317,6 +326,14 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                 sp--;
                 cur = __builtin_amdgcn_readlane(stRef, sp);
             }
+#ifdef PT_TRACE_STATS
+            if (lane == 0) { // bundles on the beam walk: [56] bundles [57] nodes [58] leaves [59] triangles [60] of which started over sub-packet by sub-packet
+                atomicAdd(&g_traceStats[56], 1ull), atomicAdd(&g_traceStats[57], (unsigned long long)stNodes), atomicAdd(&g_traceStats[58], (unsigned long long)stLeaves);
+                atomicAdd(&g_traceStats[59], (unsigned long long)stTris);
+                if (!whole)
+                    atomicAdd(&g_traceStats[60], 1ull);
+            }
+#endif
         }
         if (!whole) {
             // ---- not one bundle (ragged tail, several origins or octants): sub-packet by sub-packet, every lane for itself ------------

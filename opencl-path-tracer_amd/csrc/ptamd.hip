@@ -174,7 +174,7 @@ struct pt_ctx {
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
     bool materialBins = false; // the surfaces are of more than one material type: k_shade shades its tiles in material order
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
-    uint64_t packetLaunches = 0, genLaunches = 0;
+    uint64_t packetLaunches = 0, genLaunches = 0, bundleLaunches = 0;
     float4* accum = nullptr;
     uint32_t planes = 1; // samples in flight (fixed schedule)
     uint32_t spp = 0;
@@ -944,6 +944,7 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
         // one pixel, or of neighbouring pixels -- are ONE bundle and are walked as one (pt_packet_multi.h)
         if (fused && primaryBundles(c)) {
             c->packetLaunches++;
+            c->bundleLaunches++;
             if (sceneKind(c) != 0)
                 hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, true>), dim3(c->multiBlocks[1]), dim3(kPacketBlock), 0, c->stream, a);
             else
@@ -2277,6 +2278,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->ms_gen = c->msGen;
     out->packet_launches = c->packetLaunches;
     out->gen_launches = c->genLaunches;
+    out->bundle_launches = c->bundleLaunches;
     out->ms_packet = c->msPacket;
     return PT_OK;
 }
@@ -2287,7 +2289,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
-    c->packetLaunches = c->genLaunches = 0;
+    c->packetLaunches = c->genLaunches = c->bundleLaunches = 0;
     return PT_OK;
 }
 

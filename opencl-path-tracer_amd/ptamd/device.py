@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("shade_hits", C.c_uint64), ("deposits", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
                 ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double),
-                ("deposits_shadow", C.c_uint64), ("gen_launches", C.c_uint64)]
+                ("deposits_shadow", C.c_uint64), ("gen_launches", C.c_uint64), ("bundle_launches", C.c_uint64)]
 
 
 class RaysSoA(C.Structure):

@@ -191,6 +191,35 @@ def test_first_pass_of_a_batch_finds_the_hits_of_the_per_ray_kernel(gpu, kind, s
             assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
         assert 0.3 < (got["prim"] >= 0).mean() < 1.0
     assert first.stats()["packet_launches"] == 2 and queued.stats()["packet_launches"] == 0
+    assert first.stats()["bundle_launches"] == (2 if kind != "baked_thin_lens" else 0)  # a thin lens has no common origin: packets of 64
+    first.close()
+    queued.close()
+
+
+@pytest.mark.parametrize("spp", [16, 48])
+def test_first_pass_with_a_ragged_tail_and_a_pixel_list(gpu, spp):
+    """The bundles of the first pass where the queue does not end on a bundle boundary and the context owns only some tiles of the frame
+    (pixel = pixelList[k]): the last bundle is walked sub-packet by sub-packet, every entry is written exactly once."""
+    W, Hh = 49, 31
+    b = scenes.instanced_grid(W, Hh, level=3, sky_size=(16, 8))
+    tiles = [(0, 0, 49, 7), (8, 11, 31, 20), (40, 25, 49, 31)]  # x0, y0, x1, y1
+    owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles)
+    n = owned * spp
+    assert n % 256 != 0
+    first = U.make_ctx(gpu, b, W, Hh, samples_in_flight=spp)
+    queued = U.make_ctx(gpu, b, W, Hh, flags=gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=spp)
+    for ctx in (first, queued):
+        ctx.set_tiles(tiles)
+    o, d, pixel, got = first.primary_pass(3, spp, n)
+    o2, d2, pixel2, want = queued.primary_pass(3, spp, n)
+    assert np.array_equal(pixel, pixel2) and len(np.unique(pixel)) == owned
+    assert np.array_equal(o.view(np.uint32), o2.view(np.uint32)) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+    same = (got["prim"] == want["prim"]) & (got["inst"] == want["inst"])
+    assert (~same).mean() < 1e-3
+    assert np.allclose(got["t"][~same], want["t"][~same], rtol=1e-6)
+    for k in ("t", "u", "v"):
+        assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
+    assert first.stats()["bundle_launches"] == 1
     first.close()
     queued.close()
 

@@ -23,7 +23,8 @@ QUARTER = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_
 # <any hit, two level>: the names without a second argument are the instantiations for scenes that are one world-space tree (the headline)
 KERNELS = {"k_traceILb1ELb0": "k_trace<true>", "k_traceILb0ELb0": "k_trace<false>", "k_traceILb1ELb1": "k_trace<true, two-level>",
            "k_traceILb0ELb1": "k_trace<false, two-level>", "k_trace_packetILb0ELb0": "k_trace_packet<false>",
-           "k_trace_packetILb0ELb1": "k_trace_packet<false, two-level>", "k_shadeILb0ELb0ELb0": "k_shade<false>",
+           "k_trace_packetILb0ELb1": "k_trace_packet<false, two-level>", "k_trace_multiILi4ELb0": "k_trace_multi<4>",
+           "k_trace_multiILi4ELb1": "k_trace_multi<4, two-level>", "k_shadeILb0ELb0ELb0": "k_shade<false>",
            "k_shadeILb0ELb1ELb0": "k_shade<false, general>", "5k_genE": "k_gen", "k_fold_planes": "k_fold_planes", "k_resolve": "k_resolve"}
 
 

@@ -29,6 +29,8 @@ def table(name):
         for long, short in (("k_shade<false, false, false, false>", "k_shade<false>"), ("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
                             ("k_trace<true, false>", "k_trace<true>"), ("k_trace<false, false>", "k_trace<false>"),
                             ("k_trace_packet<false, false>", "k_trace_packet<false>"),
+                            ("k_trace_multi<4, false>", "k_trace_multi<4>"),
+                            ("k_trace_multi<4, true>", "k_trace_multi<4>" if TWO_LEVEL_RUN else "k_trace_multi<4,two-level>"),
                             # passes taken with every instance entered (gpurun_out/final_tl): the <., true> instantiations ran; bench.py names
                             # the kernels of its line by what they compute either way
                             ("k_trace<true, true>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,two-level>"),
@@ -55,6 +57,7 @@ HALF_COUNTED = {
     "k_trace<true>": (16.0, "ray origin+length and direction+pixel, 2 x 16 B per ray at hand-out"),
     "k_trace<false>": (16.0, "ray origin and direction, 2 x 16 B per ray at hand-out"),
     "k_trace_packet<false>": (0.0, "generates its rays itself: no queue reads; node and triangle data through the scalar cache and L2"),
+    "k_trace_multi<4>": (0.0, "generates its rays itself: no queue reads; node and triangle data through the scalar cache and L2"),
     "k_shade<false>": (24.0, "ray origin, direction and hit record, 3 x 16 B per entry (a bounce ray's throughput adds 8 B)"),
     "k_gen": (0.0, "writes only"),
 }
