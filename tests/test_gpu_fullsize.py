@@ -49,7 +49,7 @@ def test_full_size_properties(gpu, bundle):
 @pytest.mark.parametrize("flags_name", ["copied", "entered", "thin_lens"])
 def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_name):
     """What bench.py times -- config 4 with 256 samples in flight: ONE 256-sample batch whose primary rays are generated and traced by
-    the packet kernel (beam test, no k_gen launch), 531 M queue entries -- held against the oracle directly: 4 096 sampled pixels at the
+    the bundle kernel (k_trace_multi: beam test, four rays per lane, no k_gen launch), 531 M queue entries -- held against the oracle directly: 4 096 sampled pixels at the
     full 256 spp, at the gates of the room configurations (mean bias < 2e-3, tone-mapped RMSE < 2e-3).  `entered`: the same with every
     instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line; `thin_lens`: config 5's camera
     (f/2 focused on the grid centre) -- the packets are converging bundles walked around their waist on the focal plane."""
@@ -61,6 +61,7 @@ def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_
     ctx.render(256)
     st = ctx.stats()
     assert st["packet_launches"] == 1 and st["gen_launches"] == 0, "the batch must take the path the benchmark times"
+    assert st["bundle_launches"] == (0 if flags_name == "thin_lens" else 1)  # pinhole: bundles of 4 x 64 (k_trace_multi); thin lens: packets of 64
     assert st["rays_generated"] == W * H * 256 and ctx.samples_per_pixel == 256
     a = ctx.read_accum()[:, :3]
     ctx.close()
