@@ -124,8 +124,14 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
     const ScalarU4 wideS = (ScalarU4)(unsigned long long)sc.wide;
     const ScalarU4 trisS = (ScalarU4)(unsigned long long)sc.tris;
 
-    // claims as in k_trace_packet: the first span of a wave is static, later ones come from the queue cursor (one atomic per span)
-    constexpr uint32_t kSpan = PT_PACKET_DYNAMIC / R > 0 ? PT_PACKET_DYNAMIC / R : 1;
+    // claims as in k_trace_packet: the first span of a wave is static, later ones come from the queue cursor (one atomic per span).  Spans of 1 / 2 / 4 / 8 /
+    // 16 bundles: 23.7 / 12.3 / 9.8 / 9.1 / 9.5 ms per 2 M-bundle batch -- with short spans the cursor's atomic rate shows (518 k atomics in 9.8 ms are 53 per
+    // us on a word that sustains ~ 88).  Dealing half, three quarters, nine tenths or all of the spans round-robin WITHOUT the cursor was measured too: 9.1 /
+    // 10.7 / 11.0 / 11.0 ms -- waves that drew cheap spans (sky) cannot take over what the others still hold.
+#ifndef PT_MULTI_SPAN
+#define PT_MULTI_SPAN 8
+#endif
+    constexpr uint32_t kSpan = PT_MULTI_SPAN;
     uint32_t spanBase = uni(gwave) * kSpan, spanLeft = kSpan;
     for (;;) {
         if (spanLeft == 0u) {
