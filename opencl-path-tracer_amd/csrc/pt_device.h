@@ -190,6 +190,7 @@ constexpr int kMaxPasses = 16;
 #define PT_GEN_INTERLEAVE 256 // at most this many samples of one pixel are neighbours in the primary-ray queue (power of two; 1: sample-major order); 32 / 64 / 128 / 256: 8.27 / 8.41 / 8.42 / 8.47 Grays/s with 256 in flight
 #endif
 constexpr uint32_t kGenInterleave = PT_GEN_INTERLEAVE;
+constexpr uint32_t kDepositSlots = 64;
 struct Control {
     uint32_t extCount[kMaxPasses + 1]; // rays in the extension queue at pass p
     uint32_t shadowCount[kMaxPasses + 1];
@@ -200,6 +201,10 @@ struct Control {
     uint32_t depositsShadow; // ... and by the any-hit traversal (unoccluded shadow rays)
     uint32_t generated;
     uint32_t _pad;
+    // k_shade's deposit count, spread: workgroup b adds to slot b mod kDepositSlots, each slot in a cache line of its own.  The queue counters above must be
+    // single words (they hand out slots); this one is a statistic, and as ONE word it cost k_shade 1 ms per 531 M-entry batch: a million workgroups -- half of
+    // them hold nothing but rays that left the scene and would issue no other atomic -- queueing on one address.  k_end_sample sums the slots.
+    uint32_t depositSlots[kDepositSlots][16];
 };
 struct Totals {
     unsigned long long raysExtension, raysShadow, raysGenerated, shadeHits, deposits, depositsShadow;

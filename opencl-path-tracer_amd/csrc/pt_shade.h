@@ -878,9 +878,11 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
                 emitRay = PARITY ? true : !(r.flags & FLAG_FINISHED);
                 emitShadow = PARITY ? true : !(r.shadowFlags & FLAG_FINISHED);
             } else { // miss: skydome (kernel.cl:285-289)
-                const V3 c = throughput * readSkydome(a.sc, normalize(d));
+                // (the accumulator entry is fetched BEFORE the sky is looked up: one dependent round trip to memory less)
                 float4* ap = a.accum.at(plane, pixel);
                 float4 px = *ap;
+                asm volatile("" : "+v"(px.x), "+v"(px.y), "+v"(px.z), "+v"(px.w)); // keeps the load where it is written
+                const V3 c = throughput * readSkydome(a.sc, normalize(d));
                 px.x += c.x, px.y += c.y, px.z += c.z;
                 *ap = px;
                 deposited = true;
@@ -930,7 +932,7 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
             sCount[w][threadIdx.x] = sum;
             sum += n;
         }
-        uint32_t* counter = threadIdx.x == 0 ? a.outCount : (threadIdx.x == 1 ? a.shadowCount : (threadIdx.x == 2 ? a.shadeHits : a.deposits));
+        uint32_t* counter = threadIdx.x == 0 ? a.outCount : (threadIdx.x == 1 ? a.shadowCount : (threadIdx.x == 2 ? a.shadeHits : a.deposits + (blockIdx.x % kDepositSlots) * 16u));
         sBase[threadIdx.x] = sum ? atomicAdd(counter, sum) : 0u;
     }
     __syncthreads();
@@ -1091,7 +1093,12 @@ __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
     tot->raysShadow += sh;
     tot->shadeHits += hits;
     tot->raysGenerated += ctl->generated;
-    tot->deposits += (unsigned long long)ctl->depositsShade + ctl->depositsShadow;
+    unsigned long long slots = 0;
+    for (uint32_t k = 0; k < kDepositSlots; k++) {
+        slots += ctl->depositSlots[k][0];
+        ctl->depositSlots[k][0] = 0;
+    }
+    tot->deposits += slots + ctl->depositsShade + ctl->depositsShadow;
     tot->depositsShadow += ctl->depositsShadow;
     ctl->generated = 0;
     ctl->depositsShade = ctl->depositsShadow = 0;

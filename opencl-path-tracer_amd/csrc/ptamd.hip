@@ -989,7 +989,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.outCount = &ctl->extCount[pass + 1];
     a.shadowCount = &ctl->shadowCount[pass];
     a.shadeHits = &ctl->shadeHits[pass];
-    a.deposits = &ctl->depositsShade;
+    a.deposits = parityMode(c) ? &ctl->depositsShade : &ctl->depositSlots[0][0]; // the production kernel spreads its count over the slots (pt_device.h)
     a.streams = c->streams.p;
     const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock; // those beyond the live count leave at once
     if (parityMode(c)) {
