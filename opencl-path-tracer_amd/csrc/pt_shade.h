@@ -1042,6 +1042,22 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accu
 // context owns were written (pixels == nullptr: all of them), so a rank of an N-GPU job reads 1/N of the planes.
 // Sixteen lanes share a pixel: its planes are adjacent in memory, so they read whole cache lines.
 constexpr uint32_t kFoldLanes = 16;
+// small launches (one sample in flight): the shadow rays deposit into an accumulator of their own (ptamd.hip, renderSampleFixed), added to the accumulator
+// proper -- and cleared -- once per pt_render
+__global__ void __launch_bounds__(256) k_merge_accum(float4* __restrict__ acc, float4* __restrict__ shadowAcc, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 b = shadowAcc[i];
+    if (b.x != 0.f || b.y != 0.f || b.z != 0.f) { // (adding zero changes nothing: pixels no shadow ray reached are neither read nor written)
+        float4 a = acc[i];
+        a.x += b.x, a.y += b.y, a.z += b.z;
+        acc[i] = a;
+        shadowAcc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes, const uint32_t* pixels, uint32_t numOwned)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -138,6 +138,11 @@ struct pt_ctx {
     // the extension rays of bounce b + 1 (independent: both only need shade b; shade b + 1 waits for both)
     hipStream_t sideStream = nullptr;
     hipEvent_t evShaded[kMaxPasses] = {}, evShadowed[kMaxPasses] = {};
+    // ... and, with ONE sample in flight, deposit into an accumulator of their own (merged into the accumulator proper at the end of pt_render) from a shadow
+    // queue per bounce: the shadow passes then depend on nothing but their own shade launch and run back to back on the side stream
+    DevBuf<float4> accumShadow;
+    ShadowQueueBuf shadowQ[kMaxPasses];
+    bool mergePending = false;
     std::vector<VertexShade> hostVerts;
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
@@ -691,6 +696,8 @@ int ensureQueues(pt_ctx* c)
         for (int k = 0; k < 2; k++)
             c->rays[k].o.release(), c->rays[k].d.release(), c->rays[k].thr.release();
         c->shadow.o.release(), c->shadow.d.release(), c->shadow.c.release(), c->hitH.release(), c->hitInst.release(), c->accumPlanes.release();
+        for (ShadowQueueBuf& q : c->shadowQ)
+            q.o.release(), q.d.release(), q.c.release();
         c->stagedRays.o.release(), c->stagedRays.d.release(), c->stagedRays.thr.release();
         c->stagedShadow.o.release(), c->stagedShadow.d.release(), c->stagedShadow.c.release(), c->activeFlag.release();
         c->foldPlanes = 0;
@@ -881,6 +888,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
+#ifndef PT_SPLIT_SHADOW_ACCUM
+#define PT_SPLIT_SHADOW_ACCUM 1 // one sample in flight: shadow rays deposit into an accumulator of their own, a shadow queue per bounce (renderSampleFixed)
+#endif
 #ifndef PT_FRAME_BUNDLES
 #define PT_FRAME_BUNDLES 0 // 1: the camera rays of a 1-spp frame (pinhole) as bundles of 256 neighbouring pixels through k_trace_multi.  Measured (1280 x 720,
                            // one bundle per wave): 1.39 instead of 1.02 ms per frame -- 3 600 walks of a 32 x 8-pixel beam, each a chain of > 100 dependent leaf visits
@@ -957,16 +967,18 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
     }
 }
 
-void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr)
+// `own`: the pass's own shadow queue and the shadow rays' own accumulator (one sample in flight, renderSampleFixed)
+void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr, const ShadowQueueBuf* own = nullptr)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
     if (side) // runs beside the closest-hit traversal of the next bounce: a spill region of its own
         a.spill = c->spill.p + c->spillHalf;
-    a.rayO = c->shadow.o.p;
-    a.rayD = c->shadow.d.p;
-    a.rayC = c->shadow.c.p;
-    a.accum = accumView(c);
+    const ShadowQueueBuf& q = own ? *own : c->shadow;
+    a.rayO = q.o.p;
+    a.rayD = q.d.p;
+    a.rayC = q.c.p;
+    a.accum = own ? AccumView { c->accumShadow.p, nullptr, nullptr, 0u } : accumView(c);
     a.ctl = ctl;
     a.pass = pass;
     if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 2u))
@@ -976,7 +988,7 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t s
 }
 
 // shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
-void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pass, uint32_t launchEntries)
+void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pass, uint32_t launchEntries, const ShadowQueueBuf* ownShadow = nullptr)
 {
     Control* ctl = c->control.p;
     ShadeArgs a {};
@@ -1013,7 +1025,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
         hipLaunchKernelGGL(k_compact_stable, dim3(1), dim3(1024), 0, c->stream, ca);
     } else {
         a.out = c->rays[out].view();
-        a.shadow = c->shadow.view();
+        a.shadow = ownShadow ? ownShadow->view() : c->shadow.view();
         // The queue of pass b holds what survived b bounces -- 23 / 6 / 1.3 % of the capacity on the benchmark scene, more than half per
         // bounce behind glass -- but how much is a device word, and a million workgroups that leave at once cost 0.6 ms per launch to
         // dispatch.  So pass b >= 1 launches the one-tile kernel over as many tiles as the same pass of the previous batch filled (its
@@ -1099,6 +1111,25 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // b + 1 waits for both, so the accumulator sees its deposits in the same order as in the serial schedule (bit-identical images).
     // Large batches fill the machine with one kernel; two traversal kernels side by side only evict each other's nodes (measured: slower).
     const bool overlap = PT_OVERLAP_SMALL && entries <= (4u << 20) && !c->profile && !(c->packetUse & 2u);
+    // One sample in flight (RayTracer::rayTrace's frames): every entry deposits into the accumulator proper, so the shade launch of bounce b + 1 had to wait
+    // for the shadow rays of bounce b (same words, same order as the serial schedule) -- and the shadow passes, the longer ones, were the frame's critical path.
+    // There the shadow rays get an accumulator of their own (added to the other at the end of pt_render, in either schedule: the images stay bit-identical
+    // between them) and a queue per bounce: a shadow pass then waits for its own shade launch only.
+    const bool split = PT_SPLIT_SHADOW_ACCUM && c->planes == 1u && entries <= (4u << 20) && !(c->packetUse & 2u) && bounces <= (uint32_t)kMaxPasses;
+    if (split) {
+        const size_t npx = (size_t)c->cfg.width * c->cfg.height;
+        if (!c->accumShadow.p) {
+            HIPCHK(c, c->accumShadow.alloc(npx));
+            HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, npx * sizeof(float4), c->stream));
+        }
+        for (uint32_t b = 0; b < bounces; b++)
+            if (!c->shadowQ[b].o.p) {
+                HIPCHK(c, c->shadowQ[b].o.alloc(c->capacity));
+                HIPCHK(c, c->shadowQ[b].d.alloc(c->capacity));
+                HIPCHK(c, c->shadowQ[b].c.alloc(c->capacity));
+            }
+        c->mergePending = true;
+    }
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
         prof.begin(1);
@@ -1107,19 +1138,19 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
         launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr);
         prof.end();
-        if (overlap && b > 0)
+        if (overlap && !split && b > 0)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
-        launchShade(c, fp, in, out, b, entries);
+        launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr);
         prof.end();
         prof.begin(3);
         if (overlap) {
             HIPCHK(c, hipEventRecord(c->evShaded[b], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->sideStream, c->evShaded[b], 0));
-            launchShadow(c, b, coherent, c->sideStream);
+            launchShadow(c, b, coherent, c->sideStream, split ? &c->shadowQ[b] : nullptr);
             HIPCHK(c, hipEventRecord(c->evShadowed[b], c->sideStream));
         } else {
-            launchShadow(c, b, coherent);
+            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr);
         }
         prof.end();
         std::swap(in, out);
@@ -1142,6 +1173,11 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
 // batch: 2 x 16 B x planes x owned pixels of traffic each time (3.7 ms at 1080p x 256 planes).
 void foldPlanesNow(pt_ctx* c)
 {
+    if (c->mergePending) { // the shadow rays' own accumulator (one sample in flight) into the accumulator proper
+        const uint32_t n = c->cfg.width * c->cfg.height;
+        hipLaunchKernelGGL(k_merge_accum, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, c->accum, c->accumShadow.p, n);
+        c->mergePending = false;
+    }
     if (c->foldPlanes > 1) {
         const uint32_t n = c->numOwned;
         hipLaunchKernelGGL(k_fold_planes, dim3((uint32_t)(((uint64_t)n * kFoldLanes + 255) / 256)), dim3(256), 0, c->stream, accumView(c), c->foldPlanes,
@@ -1331,6 +1367,9 @@ void pt_destroy(pt_ctx* c)
         (void)hipStreamSynchronize(c->copyStream);
     if (c->sideStream)
         (void)hipStreamSynchronize(c->sideStream);
+    c->accumShadow.release();
+    for (ShadowQueueBuf& q : c->shadowQ)
+        q.o.release(), q.d.release(), q.c.release();
     DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
         &c->rays[1].d, &c->rays[1].thr, &c->stagedRays.o, &c->stagedRays.d, &c->stagedRays.thr, &c->shadow.o, &c->shadow.d, &c->shadow.c,
         &c->stagedShadow.o, &c->stagedShadow.d, &c->stagedShadow.c };
@@ -2124,6 +2163,9 @@ int pt_clear(pt_ctx* c)
         HIPCHK(c, hipMemsetAsync(c->accumPlanes.p, 0, c->accumPlanes.n * sizeof(float4), c->stream));
     c->foldPlanes = 0;
     c->spp = 0;
+    if (c->accumShadow.p) // (zero between pt_render calls unless one failed half-way)
+        HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, c->accumShadow.n * sizeof(float4), c->stream));
+    c->mergePending = false;
     if (parityMode(c) && c->queuesReady) {
         int rc = resetStreams(c);
         if (rc)
