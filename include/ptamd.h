@@ -264,7 +264,8 @@ int pt_intersect(pt_ctx* ctx, const pt_rays_soa* rays, uint32_t n, int any_hit, 
 int pt_gen_rays(pt_ctx* ctx, uint32_t sample, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, uint32_t* pixel);
 /* generatePrimaryRays + the first intersectWalk of one batch (src/raytracer.cpp:323-357) exactly as pt_render issues them for `batch`
  * samples per owned pixel starting at sample index `sample` -- camera rays generated inside the traversal kernel and walked as bundles
- * where pt_render does that.  n = owned pixels * batch; rays (optional) and hit records come back in queue order.  Fixed schedule only. */
+ * where pt_render does that.  n = owned pixels * batch (<= 64 M: everything is read back); rays (optional) and hit records come back in
+ * queue order.  Fixed schedule only. */
 int pt_primary_pass(pt_ctx* ctx, uint32_t sample, uint32_t batch, uint32_t n, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz,
     uint32_t* pixel, pt_hits_soa* hits);
 

@@ -2521,6 +2521,8 @@ int pt_primary_pass(pt_ctx* c, uint32_t sample, uint32_t batch, uint32_t n, floa
         return rc;
     if (batch > c->planes || n != c->numOwned * batch)
         return fail(c, PT_ERR_INVALID, "pt_primary_pass: batch exceeds samples_in_flight, or n != owned pixels * batch");
+    if (n > (1u << 26)) // every entry comes back to the host (68 B each): a hook for tests, not for 531 M-entry batches
+        return fail(c, PT_ERR_INVALID, "pt_primary_pass: %u entries -- the hook reads everything back, use it on small frames (<= 64 M entries)", n);
     FrameParams fp = batchFrameParams(c, sample, batch);
     const bool coherentFirst = firstPassCoherent(c, fp, batch);
     const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
