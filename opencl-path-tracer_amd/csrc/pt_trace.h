@@ -62,6 +62,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
+constexpr int kDescentStack = 3; // entries of a START stack (pt_descend.h: rays that leave one pixel's footprint take the way from the root to their origin together)
+static_assert(kDescentStack <= kLdsStack, "the hand-out copies a start stack into the LDS part of the lane's stack");
 constexpr int kSpillStack = 100; // further entries in global memory
 constexpr int kTraceBlock = 256;
 #ifndef PT_PARKED_BREAK_ANY
@@ -105,6 +107,9 @@ struct TraceArgs {
     uint32_t* spill; // kSpillStack * totalThreads dwords
     uint32_t totalThreads;
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
+    // k_trace<., ., true>: the start state of every queue entry, made by k_descend (pt_descend.h): x = the reference to continue with,
+    // y z w = up to three stacked entries in stack order (kRefNone: unused)
+    const uint4* start;
 };
 
 #ifdef PT_TRACE_STATS
@@ -153,7 +158,9 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 #ifndef PT_TRACE_MIN_WAVES_TL
 #define PT_TRACE_MIN_WAVES_TL 7
 #endif
-template <bool ANY_HIT, bool TWO_LEVEL>
+// DESCENT: rays do not start at the root but where k_descend (pt_descend.h) left them -- a reference and up to kDescentStack stacked
+// entries per queue slot, taken at the hand-out; everything else is the same kernel.
+template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false>
 __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
@@ -318,6 +325,12 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                             hu = hv = 0.f;
                             cur = sc.rootRef;
                             sp = 0;
+                            if constexpr (DESCENT) { // the way from the root to the ray's origin has been walked already (pt_descend.h)
+                                const uint4 ss = a.start[idx];
+                                cur = ss.x;
+                                sp = (ss.y != kRefNone ? 1 : 0) + (ss.z != kRefNone ? 1 : 0) + (ss.w != kRefNone ? 1 : 0);
+                                ldsStack[wave][0][lane] = ss.y, ldsStack[wave][1][lane] = ss.z, ldsStack[wave][2][lane] = ss.w; // (beyond sp: never read)
+                            }
                             active = true;
                         }
                     }

@@ -7,6 +7,7 @@
 #include "pt_packet.h"
 #include "pt_packet_multi.h"
 #include "pt_bake.h"
+#include "pt_descend.h"
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
 #endif
@@ -98,6 +99,7 @@ struct pt_ctx {
         bool stageBusy = false;
         uint32_t numLights = 0, rootRef = 0;
         bool packetOk = false;
+        uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
         bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
         std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
         hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
@@ -195,11 +197,17 @@ struct pt_ctx {
     DevBuf<Totals> totals;
     DevBuf<uint32_t> spill;
     size_t spillHalf = 0;
+    // shared descent (pt_descend.h): start states of one queue (the shadow rays of the primary hits, then the first bounce's extension rays).
+    // bit 0: shadow rays of pass 0, bit 1: extension rays of pass 1, bit 2: the pt_intersect test hook
+    DevBuf<uint4> startState;
+    uint32_t descentUse = 0;
+    uint32_t descendBlocks = 0;
+    uint64_t descentLaunches = 0;
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
 
-    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0;
+    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0, msDescend = 0;
 };
 
 namespace {
@@ -599,20 +607,25 @@ int buildStaticGeom(pt_ctx* c)
         g.roots.push_back(root);
     }
     // worst-case number of pending stack entries below every packed node: visiting a node can leave all its other children on the
-    // stack (children are visited nearest first, so any order can occur: the bound takes the deepest child first).  Children sit
-    // after their parent in a run, so one reverse sweep does it.
+    // stack (children are visited nearest first, so any order can occur: the bound takes the deepest child first).  Inside a run the
+    // children sit after their parent; a child that lies in ANOTHER run (a top-level leaf named an interior node, whose subtree an
+    // earlier root had packed already) lies in an earlier one.  So: run by run in ascending order, each run in reverse -- every child
+    // is final when its parent is reached.  (One reverse sweep over everything took 0 for the shared children: too small a bound.)
     g.stackNeed.assign(g.wide.size(), 0u);
-    for (size_t q = g.wide.size(); q-- > 0;) {
-        uint32_t n = 0, deepest = 0;
-        for (uint32_t r : g.wide[q].child) {
-            if (r == emptyRef)
-                continue;
-            n++;
-            if (refCount(r) == 0u && refIndex(r) < g.wide.size())
-                deepest = std::max(deepest, refIndex(r) > q ? g.stackNeed[refIndex(r)] : 0u);
+    for (const pt_ctx::StaticGeom::Root& root : g.roots)
+        for (size_t q = (size_t)root.nodeBase + root.numNodes; q-- > root.nodeBase;) {
+            if (refCount(root.ref) != 0u || refIndex(root.ref) != root.nodeBase)
+                break; // no run of its own (a single leaf, or the root sits inside an earlier run)
+            uint32_t n = 0, deepest = 0;
+            for (uint32_t r : g.wide[q].child) {
+                if (r == emptyRef)
+                    continue;
+                n++;
+                if (refCount(r) == 0u && refIndex(r) < g.wide.size())
+                    deepest = std::max(deepest, g.stackNeed[refIndex(r)]);
+            }
+            g.stackNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
         }
-        g.stackNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
-    }
     // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h)
     g.fat.resize(c->hostTriShade.size());
     for (size_t t = 0; t < c->hostTriShade.size(); t++) {
@@ -700,12 +713,16 @@ int ensureQueues(pt_ctx* c)
             q.o.release(), q.d.release(), q.c.release();
         c->stagedRays.o.release(), c->stagedRays.d.release(), c->stagedRays.thr.release();
         c->stagedShadow.o.release(), c->stagedShadow.d.release(), c->stagedShadow.c.release(), c->activeFlag.release();
+        c->startState.release();
         c->foldPlanes = 0;
         // Memory budget, checked before anything is allocated so that an oversized configuration fails HERE with a
         // message instead of somewhere in a later hipMalloc: per queue entry two extension queues (3 x 16 B each), the
         // shadow queue (3 x 16 B) and the hit records (20 B); per owned pixel one 16-byte accumulator plane for every
         // extra sample in flight.  (BASELINE config 5 -- 4K, 8 ranks -- at 2 048 samples in flight would be 2.1 G entries.)
-        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0);
+        // ... and, where the shared descent serves the first bounce (>= 16 samples of a pixel next to each other in the queue), a start state
+        // per entry: one 16-byte record
+        const bool descent = (c->descentUse & 3u) != 0u && c->planes >= 16u;
+        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0) + (descent ? sizeof(uint4) : 0);
         const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4);
         size_t freeB = 0, totalB = 0;
         HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
@@ -731,6 +748,8 @@ int ensureQueues(pt_ctx* c)
     HIPCHK(c, c->shadow.c.alloc(cap));
     HIPCHK(c, c->hitH.alloc(cap));
     HIPCHK(c, c->hitInst.alloc(cap));
+    if ((c->descentUse & 3u) != 0u && c->planes >= 16u)
+        HIPCHK(c, c->startState.alloc(cap));
     if (parityMode(c)) {
         HIPCHK(c, c->stagedRays.o.alloc(cap));
         HIPCHK(c, c->stagedRays.d.alloc(cap));
@@ -755,8 +774,8 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     // persistent grids sized to the machine, per instantiation pair ([0]: scenes that are one world-space tree, [1]: scenes with
     // instance references -- pt_trace.h, TWO_LEVEL)
-    const void* variants[2][2] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false> },
-        { (const void*)k_trace<false, true>, (const void*)k_trace<true, true> } };
+    const void* variants[2][4] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false>, (const void*)k_trace<false, false, true>, (const void*)k_trace<true, false, true> },
+        { (const void*)k_trace<false, true>, (const void*)k_trace<true, true>, (const void*)k_trace<false, true, true>, (const void*)k_trace<true, true, true> } };
     const void* packetVariants[2][2] = { { (const void*)k_trace_packet<false, false>, (const void*)k_trace_packet<true, false> },
         { (const void*)k_trace_packet<false, true>, (const void*)k_trace_packet<true, true> } };
     for (int tl = 0; tl < 2; tl++) {
@@ -787,6 +806,13 @@ int ensureSpill(pt_ctx* c)
         c->multiBlocks[0] = (uint32_t)(std::max(1, b) * c->numCUs);
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, true>, kPacketBlock, 0));
         c->multiBlocks[1] = (uint32_t)(std::max(1, b) * c->numCUs);
+        if (const char* e = getenv("PTAMD_PACKET_BLOCKS_PER_CU")) // the documented knob reaches the bundle kernel too
+            for (uint32_t& mb : c->multiBlocks)
+                mb = std::max(1u, std::min(mb, (uint32_t)std::max(1, atoi(e)) * (uint32_t)c->numCUs));
+        int d0 = 0, d1 = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&d0, (const void*)k_descend<false>, kDescendBlock, 0));
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&d1, (const void*)k_descend<true>, kDescendBlock, 0));
+        c->descendBlocks = (uint32_t)(std::max(1, std::min(d0, d1)) * c->numCUs);
     }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
@@ -807,6 +833,20 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a, hipStream_t stream 
     const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
     if (!stream)
         stream = c->stream;
+    if (a.start) { // the rays start where k_descend left them (pt_descend.h)
+        if (anyHit) {
+            if (twoLevel)
+                hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, stream, a);
+        } else {
+            if (twoLevel)
+                hipLaunchKernelGGL((k_trace<false, true, true>), grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, stream, a);
+        }
+        return;
+    }
     if (anyHit) {
         if (twoLevel)
             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
@@ -828,6 +868,19 @@ TraceArgs traceArgsBase(pt_ctx* c)
     a.totalThreads = c->traceBlocks[sceneKind(c)] * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
     return a;
+}
+
+// the way from the root to the rays' origins, taken once per packet of 64 consecutive queue entries (pt_descend.h); `count` = the queue's device word
+void launchDescend(pt_ctx* c, bool anyHit, const float4* rayO, const float4* rayD, const uint32_t* count, uint4* start, hipStream_t stream = nullptr)
+{
+    DescendArgs d {};
+    d.sc = c->scene;
+    d.rayO = rayO, d.rayD = rayD, d.count = count, d.start = start;
+    c->descentLaunches++;
+    if (anyHit)
+        hipLaunchKernelGGL(k_descend<true>, dim3(c->descendBlocks), dim3(kDescendBlock), 0, stream ? stream : c->stream, d);
+    else
+        hipLaunchKernelGGL(k_descend<false>, dim3(c->descendBlocks), dim3(kDescendBlock), 0, stream ? stream : c->stream, d);
 }
 
 FrameParams frameParams(const pt_ctx* c, uint32_t sample)
@@ -908,6 +961,10 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
 #endif
 constexpr uint32_t kPacketUseDefault = PT_PACKET_USE;
+#ifndef PT_DESCENT_USE
+#define PT_DESCENT_USE 0 // bit 0: the shadow rays of the primary hits, bit 1: the first bounce's extension rays.  Off: measured no faster
+#endif
+constexpr uint32_t kDescentUseDefault = PT_DESCENT_USE;
 
 void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
@@ -934,10 +991,12 @@ inline bool primaryBundles(const pt_ctx* c) { return PT_MULTI_RAYS > 1 && !c->ca
 inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
 
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
-void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr)
+void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr, bool descent = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
+    if (descent) // the caller has launched k_descend on this queue
+        a.start = c->startState.p;
     if (fused) {
         a.fused = 1u;
         a.fp = *fused;
@@ -968,10 +1027,12 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
 }
 
 // `own`: the pass's own shadow queue and the shadow rays' own accumulator (one sample in flight, renderSampleFixed)
-void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr, const ShadowQueueBuf* own = nullptr)
+void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr, const ShadowQueueBuf* own = nullptr, bool descent = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
+    if (descent) // the caller has launched k_descend on this queue
+        a.start = c->startState.p;
     if (side) // runs beside the closest-hit traversal of the next bounce: a spill region of its own
         a.spill = c->spill.p + c->spillHalf;
     const ShadowQueueBuf& q = own ? *own : c->shadow;
@@ -1130,19 +1191,35 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             }
         c->mergePending = true;
     }
+    // Shared descent (pt_descend.h) for the rays that leave the primary hits -- their shadow rays (pass 0) and the first bounce's extension rays
+    // (pass 1): with >= 16 samples of a pixel next to each other in the first queue, k_shade's compaction (order kept inside a 512-entry
+    // tile) leaves the 64 consecutive entries of a packet within a pixel's footprint of each other.  Large batches only: the small launches of
+    // an interactive frame are latency-bound, a kernel more in their chain costs more than it saves.
+    const bool descent = c->startState.p && fp.interleave >= 16u && !overlap && !split;
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
+        const bool descentExt = descent && b == 1 && (c->descentUse & 2u), descentShadow = descent && b == 0 && (c->descentUse & 1u);
+        if (descentExt) {
+            prof.begin(6);
+            launchDescend(c, false, c->rays[in].o.p, c->rays[in].d.p, &c->control.p->extCount[b], c->startState.p);
+            prof.end();
+        }
         prof.begin(1);
         const bool coherent = b == 0 && coherentFirst;
         if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
-        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr);
+        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr, descentExt);
         prof.end();
         if (overlap && !split && b > 0)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr);
         prof.end();
+        if (descentShadow) {
+            prof.begin(5);
+            launchDescend(c, true, c->shadow.o.p, c->shadow.d.p, &c->control.p->shadowCount[b], c->startState.p);
+            prof.end();
+        }
         prof.begin(3);
         if (overlap) {
             HIPCHK(c, hipEventRecord(c->evShaded[b], c->stream));
@@ -1150,7 +1227,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             launchShadow(c, b, coherent, c->sideStream, split ? &c->shadowQ[b] : nullptr);
             HIPCHK(c, hipEventRecord(c->evShadowed[b], c->sideStream));
         } else {
-            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr);
+            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr, descentShadow);
         }
         prof.end();
         std::swap(in, out);
@@ -1255,6 +1332,17 @@ int pt_debug_trace_stats(unsigned long long* out, unsigned int n) // n <= 64 cou
 }
 #endif
 
+#ifdef PT_TRACE_STATS
+int pt_debug_descend_stats(unsigned long long* out, unsigned int n) // n <= 16 counters (pt_descend.h, g_descendStats); read and cleared
+{
+    n = std::min(n, 16u);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_descendStats), sizeof(unsigned long long) * n) != hipSuccess)
+        return -1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_descendStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
 // Test hook, no device needed: the host side of quantiseWideNode (pt_bake.h) -- up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
@@ -1297,6 +1385,13 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     c->packetUse = (cfg->flags & PT_FLAG_NO_PACKETS) ? 0u : kPacketUseDefault;
     if (cfg->flags & PT_FLAG_PACKET_INTERSECT)
         c->packetUse |= 4u;
+    c->descentUse = (cfg->flags & PT_FLAG_SHARED_DESCENT) ? 3u : kDescentUseDefault;
+    if (const char* de = getenv("PTAMD_DESCENT")) // diagnostics: which launches take the shared descent (bit 0 shadow rays of pass 0, bit 1 extension rays of pass 1)
+        c->descentUse = (uint32_t)atoi(de) & 3u;
+    if (parityMode(c))
+        c->descentUse = 0u; // parity mode follows the reference to the letter (and keeps finished entries in its queues)
+    if (cfg->flags & PT_FLAG_DESCENT_INTERSECT)
+        c->descentUse |= 4u;
     if (const char* hs = getenv("PTAMD_SHADE_HEAD_SHIFT"))
         c->shadeHeadShift = (uint32_t)std::max(0, atoi(hs));
     if (const char* pk = getenv("PTAMD_PACKET")) // diagnostics: which launches may use k_trace_packet (bit 0 primary, 1 shadow, 2 pt_intersect)
@@ -1368,6 +1463,7 @@ void pt_destroy(pt_ctx* c)
     if (c->sideStream)
         (void)hipStreamSynchronize(c->sideStream);
     c->accumShadow.release();
+    c->startState.release();
     for (ShadowQueueBuf& q : c->shadowQ)
         q.o.release(), q.d.release(), q.c.release();
     DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
@@ -1645,6 +1741,7 @@ struct DynamicHost {
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
     uint32_t bakedNodes = 0, bakedTris = 0;
     bool packetOk = false, hasInstances = false;
+    uint32_t stackNeed = 0;
 };
 
 int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
@@ -1859,6 +1956,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
     // k_trace_packet keeps its stack in the 64 lanes of a register (instance references are entered there too, pt_packet.h)
     out.packetOk = stackNeed <= kPacketStack;
+    out.stackNeed = stackNeed;
     std::vector<Light>& hLights = out.lights;
     hLights.resize(nL);
     for (uint32_t i = 0; i < nL; i++) {
@@ -1997,6 +2095,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     d.numLights = h.numLights;
     d.rootRef = h.rootRef;
     d.packetOk = h.packetOk;
+    d.stackNeed = h.stackNeed;
     d.hasInstances = h.hasInstances;
     d.instanceTopNode = std::move(h.instanceTopNode);
     c->pending = target;
@@ -2203,13 +2302,14 @@ int pt_render(pt_ctx* c, uint32_t spp)
     HIPCHK(c, hipEventRecord(c->evStop, c->stream));
     if (c->profile) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        double fam[5] = { 0, 0, 0, 0, 0 };
+        double fam[7] = { 0, 0, 0, 0, 0, 0, 0 }; // [5], [6]: k_descend ahead of the shadow rays / the extension rays (counted with their family AND apart)
         for (auto& m : prof.marks) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, c->profEvents[m.second], c->profEvents[m.second + 1]);
             fam[m.first] += ms;
         }
-        c->msGen = fam[0], c->msIntersect = fam[1] + fam[4], c->msShade = fam[2], c->msShadow = fam[3], c->msPacket = fam[4];
+        c->msGen = fam[0], c->msIntersect = fam[1] + fam[4] + fam[6], c->msShade = fam[2], c->msShadow = fam[3] + fam[5], c->msPacket = fam[4];
+        c->msDescend = fam[5] + fam[6];
     }
     return PT_OK;
     });
@@ -2322,6 +2422,9 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->gen_launches = c->genLaunches;
     out->bundle_launches = c->bundleLaunches;
     out->ms_packet = c->msPacket;
+    out->descent_launches = c->descentLaunches;
+    out->ms_descend = c->msDescend;
+    out->stack_need = c->dyn[c->active].stackNeed;
     return PT_OK;
 }
 
@@ -2331,7 +2434,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
-    c->packetLaunches = c->genLaunches = c->bundleLaunches = 0;
+    c->packetLaunches = c->genLaunches = c->bundleLaunches = c->descentLaunches = 0;
     return PT_OK;
 }
 
@@ -2397,6 +2500,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     DevBuf<float4> dO, dD, dC, dH, dAcc;
     DevBuf<int32_t> dI;
     DevBuf<uint32_t> dOcc;
+    DevBuf<uint4> dStart;
     DevBuf<Control> dCtl;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) {
@@ -2404,6 +2508,8 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
             e = x;
     };
     chk(dO.alloc(n)), chk(dD.alloc(n)), chk(dC.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dOcc.alloc(n)), chk(dAcc.alloc(1)), chk(dCtl.alloc(1));
+    if (c->descentUse & 4u)
+        chk(dStart.alloc(n));
     if (e == hipSuccess) {
         chk(hipMemcpy(dO.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         chk(hipMemcpy(dD.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -2426,7 +2532,11 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u }, a.occluded = dOcc.p;
         a.ctl = dCtl.p, a.pass = 0;
         chk(hipEventRecord(e0, c->stream));
-        if (c->dyn[c->active].packetOk && (c->packetUse & 4u))
+        if (c->descentUse & 4u) { // consecutive rays in packets of 64 take the way to their origins together (pt_descend.h), then the per-ray kernel
+            launchDescend(c, any_hit != 0, dO.p, dD.p, any_hit ? &dCtl.p->shadowCount[0] : &dCtl.p->extCount[0], dStart.p);
+            a.start = dStart.p;
+            launchTrace(c, any_hit != 0, a);
+        } else if (c->dyn[c->active].packetOk && (c->packetUse & 4u))
             launchPacket(c, any_hit != 0, a);
         else
             launchTrace(c, any_hit != 0, a);
@@ -2459,7 +2569,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    dO.release(), dD.release(), dC.release(), dH.release(), dI.release(), dOcc.release(), dAcc.release(), dCtl.release();
+    dO.release(), dD.release(), dC.release(), dH.release(), dI.release(), dOcc.release(), dAcc.release(), dCtl.release(), dStart.release();
     if (ms_out)
         *ms_out = msTotal / (float)repeat;
     HIPCHK(c, e);
