@@ -269,38 +269,134 @@ def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=
         ctx.close()
 
 
-def dynamic_update_times(D, bundle, W, Hh, device, ticks=12):
-    """RayTracer::frameTick's cost (src/raytracer.cpp:183-189,497-595): per tick the host time pt_upload_dynamic_async blocks the
-    calling thread and the time until the upload's event has fired on the copy stream (pt_frame_tick + a synchronisation, nothing
-    rendering meanwhile), for the benchmark scene with every instance moved a little each tick; baked (the default: instances
-    are copied to world space) and two-level (PT_FLAG_NO_BAKED_INSTANCES).  The reference refits and re-uploads its dynamic data in
-    4-6 ms per frame (lab report)."""
+def _torus_mesh(H, L, nu, nv, material, builder):
+    """2 * nu * nv triangles on a lumpy torus (no poles: every vertex has six neighbours), for the deforming-mesh figures."""
+    u, v = np.meshgrid(np.arange(nu) * (2 * np.pi / nu), np.arange(nv) * (2 * np.pi / nv), indexing="ij")
+    r = 0.16 * (1.0 + 0.25 * np.sin(5 * u) * np.cos(3 * v))
+    p = np.stack([(0.42 + r * np.cos(v)) * np.cos(u), r * np.sin(v), (0.42 + r * np.cos(v)) * np.sin(u)], -1).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a, b, c, d = (i * nv + j).ravel(), (((i + 1) % nu) * nv + j).ravel(), (((i + 1) % nu) * nv + (j + 1) % nv).ravel(), (i * nv + (j + 1) % nv).ravel()
+    f = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)]).astype(np.uint32)
+    return H.Mesh(p, f, [material], builder=builder), p
+
+
+def dynamic_update_times(D, H, L, scenes, bundle, W, Hh, device, ticks=12):
+    """RayTracer::frameTick's cost (src/raytracer.cpp:183-189,497-595) with EVERY instance moved a little each tick.  Per tick, apart:
+    `host_flatten_ms` -- the scene-graph walk, the lights and the top-level BVH build inside the host library (flattenDynamic: what
+    RayTracer::frameTick does before it calls the device library); `host_upload_ms` -- the time pt_upload_dynamic_async blocks the calling
+    thread (top level collapsed to 4-wide nodes, instance table, lights, copy jobs; a few KB into pinned staging); `ms_until_adopted` --
+    flatten + upload + pt_frame_tick + a synchronisation (the world-space copies of the instances are made by the device meanwhile),
+    nothing rendering.  The benchmark scene (14 instances) with its instances copied to world space (the default) and entered
+    (PT_FLAG_NO_BAKED_INSTANCES), then 1 000 and 10 000 instances of a 320-triangle mesh.  Rigid motion only: a deforming mesh is the
+    `refit` object (that is what the reference's 4-6 ms per frame contain)."""
     out = {}
-    flat = bundle.flat
-    for name, flags in (("baked", 0), ("two_level", D.FLAG_NO_BAKED_INSTANCES)):
+
+    def run(name, b, flags, moved_nodes, what):
+        scene, flat = b.scene, b.flat
         ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=1, flags=flags)
         try:
             ctx.upload_scene(flat, sky=None)
-            ctx.set_camera(bundle.camera)
+            ctx.set_camera(b.camera)
             ctx.render(1)
-            host_ms, total_ms = [], []
+            rng = np.random.default_rng(7)
+            base = rng.uniform(-1, 1, (len(moved_nodes), 3)).astype(np.float32)
+            flatten_ms, upload_ms, total_ms = [], [], []
             for k in range(ticks + 2):
+                for n, (node, loc) in enumerate(moved_nodes):  # (driving the scene graph is the application's business: not timed)
+                    scene.set_transform(node, location=(loc[0] + 0.02 * k * base[n, 0], loc[1], loc[2] + 0.02 * k * base[n, 2]))
                 t0 = time.perf_counter()
-                ctx.upload_dynamic_async(flat)
+                f2, lib_s = scene.flatten_dynamic(flat)
                 t1 = time.perf_counter()
+                ctx.upload_dynamic_async(f2)
+                t2 = time.perf_counter()
                 ctx.frame_tick()
                 ctx.synchronize()
-                t2 = time.perf_counter()
+                t3 = time.perf_counter()
                 if k >= 2:  # the first two ticks size the two buffer sets
-                    host_ms.append((t1 - t0) * 1e3)
-                    total_ms.append((t2 - t0) * 1e3)
-            out[name] = {"host_ms_per_upload": round(float(np.median(host_ms)), 3), "ms_until_adopted": round(float(np.median(total_ms)), 3),
-                         "host_ms_min_max": [round(min(host_ms), 3), round(max(host_ms), 3)]}
+                    flatten_ms.append(lib_s * 1e3)
+                    upload_ms.append((t2 - t1) * 1e3)
+                    total_ms.append((t3 - t0) * 1e3 - ((t1 - t0) - lib_s) * 1e3)  # (the binding's array copies out of the host library are not the library's)
+            ctx.render(1)  # the last state renders
+            out[name] = {"what": what, "instances": int(f2.num_instances), "top_level_nodes": int(len(f2.top_nodes)), "instanced_triangles": int(f2.instanced_triangles),
+                         "host_flatten_ms": round(float(np.median(flatten_ms)), 3), "host_upload_ms": round(float(np.median(upload_ms)), 3),
+                         "ms_until_adopted": round(float(np.median(total_ms)), 3), "host_upload_ms_min_max": [round(min(upload_ms), 3), round(max(upload_ms), 3)]}
         finally:
             ctx.close()
-    out["what"] = (f"median over {ticks} ticks of pt_upload_dynamic_async (host time) and upload + pt_frame_tick + synchronise (until adopted), "
-                   f"{len(flat.top_nodes)} top-level nodes, {flat.instanced_triangles} instanced triangles")
-    out["reference_ms_per_frame"] = "4 - 6 (refit + dynamic upload, lab report; hardware not stated)"
+
+    # the benchmark scene: nodes 0 / 1 are the ground and the light, 2 .. the mesh instances (scenes.instanced_grid adds them in this order)
+    grid = [(2 + k, ((k % 4 - 1.5) * 1.5, 0.62 * 1.2, (k // 4 - 1.0) * 1.5)) for k in range(12)]
+    run("benchmark_scene_copied", bundle, 0, grid, "config 4's scene, every mesh instance moved each tick; instances copied to world space by two device kernels per tick")
+    run("benchmark_scene_entered", bundle, D.FLAG_NO_BAKED_INSTANCES, grid, "the same with every instance entered at traversal: nothing to copy")
+    for n in (1000, 10000):
+        field = scenes.instance_field(W, Hh, n=n, level=2)
+        side = 0.45 * n ** 0.5
+        rng = np.random.default_rng(9)
+        moved = [(2 + k, (float(rng.uniform(-side, side)), 0.5, float(rng.uniform(-side, side)))) for k in range(n)]
+        run(f"instances_{n}", field, 0, moved, f"{n} instances of a 320-triangle mesh, all moved each tick (top level: top-down SAH above 256 instances, "
+                                                "the reference's agglomerative clustering -- O(n^2) -- up to there)")
+    out["what"] = f"medians over {ticks} ticks, every instance moved each tick; see the entries"
+    out["reference_ms_per_frame"] = ("4.1 - 6.3 per frame for ONE deforming 36.5 k-triangle mesh (CPU refit + upload of the dynamic data; lab report Table 2, RX 480): "
+                                     "compare with the `refit` object -- rigid instance motion is not timed apart by the reference")
+    return out
+
+
+def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
+    """A deforming mesh per frame, the reference's way (src/model/mesh_sequence.cpp:81-97 + src/bvh/refit_bvh.cpp:6-34 on the host,
+    transferDynamicData src/raytracer.cpp:510-568): per tick Mesh::refit (new vertex positions, smooth normals regenerated, boxes refitted
+    bottom-up -- host library), the scene flattened again, pt_update_geometry (pair-node boxes re-read, 4-wide nodes re-quantised on the
+    host; vertices + nodes through pinned staging; triangle records re-made by a device kernel), pt_upload_dynamic_async, pt_frame_tick
+    and a synchronisation.  Host ms per stage and ms until the new geometry is adopted; the mesh in the five-wall room, SBVH."""
+    out = {}
+    mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
+    for name, make in (("mesh_36k", lambda: _torus_mesh(H, L, 135, 135, mat, H.BVH_SPATIAL_SPLIT)),
+                       ("mesh_82k", lambda: (scenes.blob_mesh(mat, level=6, builder=H.BVH_SPATIAL_SPLIT), None))):
+        mesh, p0 = make()
+        if p0 is None:
+            verts, _ = mesh.geometry()
+            p0 = verts["vertex"][:, :3].copy()
+        scene = H.Scene()
+        mb = scenes._MeshBuilder()
+        mats = scenes._room_materials()
+        scenes._room(mb, mats)
+        scene.add_node(mb.build(mats, H.BVH_BINNED_SAH))
+        scene.add_node(mesh, location=(0.0, 0.8, 0.1), scale=(1.2, 1.2, 1.2))
+        flat = scene.flatten()
+        cam = scenes.blob_room(W, Hh, level=2).camera
+        ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=1)
+        try:
+            ctx.upload_scene(flat, sky=None)
+            ctx.set_camera(cam)
+            ctx.render(1)
+            stage = {k: [] for k in ("mesh_refit", "flatten", "update_geometry", "upload_dynamic", "total")}
+            for k in range(ticks + 2):
+                ang = 0.15 * np.sin(0.7 * (k + 1)) * p0[:, 1] * 4.0
+                p = np.stack([np.cos(ang) * p0[:, 0] - np.sin(ang) * p0[:, 2], p0[:, 1] * (1.0 + 0.05 * np.sin(k + 1.0)),
+                              np.sin(ang) * p0[:, 0] + np.cos(ang) * p0[:, 2]], 1).astype(np.float32)
+                t0 = time.perf_counter()
+                mesh.refit(p)
+                t1 = time.perf_counter()
+                flat = scene.flatten()
+                t2 = time.perf_counter()
+                ctx.update_geometry(flat)
+                t3 = time.perf_counter()
+                ctx.upload_dynamic_async(flat)
+                t4 = time.perf_counter()
+                ctx.frame_tick()
+                ctx.synchronize()
+                t5 = time.perf_counter()
+                if k >= 2:
+                    for key, dt in (("mesh_refit", t1 - t0), ("flatten", t2 - t1), ("update_geometry", t3 - t2), ("upload_dynamic", t4 - t3), ("total", t5 - t0)):
+                        stage[key].append(dt * 1e3)
+            ctx.render(1)
+            st = mesh.stats()
+            out[name] = {"triangles": int(st["num_input_triangles"]), "triangle_references": int(st["num_triangle_refs"]), "sub_bvh_nodes": int(st["num_nodes"]),
+                         "host_ms": {k: round(float(np.median(v)), 3) for k, v in stage.items() if k != "total"},
+                         "ms_until_adopted": round(float(np.median(stage["total"])), 3), "ms_until_adopted_min_max": [round(min(stage["total"]), 3), round(max(stage["total"]), 3)]}
+        finally:
+            ctx.close()
+    out["what"] = (f"medians over {ticks} ticks: Mesh::refit + Scene flatten (host library, through the Python binding: its array copies are in `flatten`) + pt_update_geometry + "
+                   "pt_upload_dynamic_async (host time each), then pt_frame_tick + synchronise (ms_until_adopted = the whole tick)")
+    out["reference_ms_per_frame"] = "4.12 - 6.25 (refit from a binned / SBVH tree + upload, 36.5 k-triangle helicopter, RX 480; lab report Table 2) -- 26.7 - 381.6 with a rebuilt tree"
     return out
 
 
@@ -323,7 +419,11 @@ def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
                                                    what="PT_FLAG_TWO_LEVEL_ONLY: the 12 mesh instances are entered; the two quads (single-leaf meshes) "
                                                         "hang off the top level as world-space leaves"),
         "instances_copied_to_world_space": measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, what="the headline's configuration, measured the same way")})
-    guarded("dynamic", lambda: dynamic_update_times(D, bundle, W, Hh, device))
+    def dynamic():
+        d = dynamic_update_times(D, H, L, scenes, bundle, W, Hh, device)
+        d["refit"] = dynamic_refit_times(D, H, L, scenes, W, Hh, device)
+        return d
+    guarded("dynamic", dynamic)
 
     def configs():
         c = {}

@@ -80,6 +80,10 @@ void pth_scene_destroy(pth_scene* s);
 int pth_scene_add_node(pth_scene* s, const pth_mesh* m, const float location[3], const float orientation_wxyz[4], const float scale[3], int parent);
 int pth_scene_set_transform(pth_scene* s, int node, const float location[3], const float orientation_wxyz[4], const float scale[3]);
 int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts);
+/* The per-tick half alone -- lights and top-level BVH from the scene graph as it stands (flattenDynamic: what RayTracer::frameTick does
+ * on the host before pt_upload_dynamic_async; reference transferDynamicData, src/raytracer.cpp:497-509,569-595); the static arrays of the
+ * last pth_scene_flatten stay as they are.  Copy out with pth_scene_copy (NULL for the arrays that are not wanted). */
+int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts);
 int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top);
 
 int pth_camera_data(const pth_camera_params* p, pt_camera* out);

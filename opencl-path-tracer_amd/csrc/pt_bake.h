@@ -161,4 +161,48 @@ __global__ void __launch_bounds__(256) k_bake_tris(BakeArgs a)
     a.dstTris[j.dstTri + i] = b;
 }
 
+// ---- refit (pt_update_geometry): a deformed frame of the SAME topology ------------------------------------------------------------------
+// The caller's vertex record (pt_vertex, include/ptamd.h: 48 bytes) as the device reads it
+struct VertexIn {
+    float4 pos; // xyz
+    float4 normal;
+    float u, v, _p0, _p1;
+};
+struct RefitArgs {
+    const VertexIn* verts;
+    const TriShade* tri; // vertex indices + material of every triangle of the caller's numbering (static)
+    const Material* mats;
+    TriIsect* tris;
+    TriFat* fat;
+    uint32_t n;
+};
+// one thread per triangle: the intersection record (v0, e1, e2: the very subtractions pt_upload_static does on the host, so that a refitted
+// context and a fresh one hold the same bits) and the 128-byte shading record, from the new vertices
+__global__ void __launch_bounds__(256) k_refit_tris(RefitArgs a)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n)
+        return;
+    const TriShade ts = a.tri[t];
+    const VertexIn a0 = a.verts[ts.i0], a1 = a.verts[ts.i1], a2 = a.verts[ts.i2];
+    const float e1x = a1.pos.x - a0.pos.x, e1y = a1.pos.y - a0.pos.y, e1z = a1.pos.z - a0.pos.z; // shapes.cl:37-38
+    const float e2x = a2.pos.x - a0.pos.x, e2y = a2.pos.y - a0.pos.y, e2z = a2.pos.z - a0.pos.z;
+    TriIsect ti;
+    ti.a = make_float4(a0.pos.x, a0.pos.y, a0.pos.z, e1x);
+    ti.b = make_float4(e1y, e1z, e2x, e2y);
+    ti.c = make_float4(e2z, 0.f, 0.f, 0.f);
+    a.tris[t] = ti;
+    const Material m = a.mats[ts.material];
+    TriFat f;
+    f.n0u = make_float4(a0.normal.x, a0.normal.y, a0.normal.z, a0.u);
+    f.n1u = make_float4(a1.normal.x, a1.normal.y, a1.normal.z, a1.u);
+    f.n2u = make_float4(a2.normal.x, a2.normal.y, a2.normal.z, a2.u);
+    f.vvvm = make_float4(a0.v, a1.v, a2.v, __uint_as_float(ts.material));
+    f.e1e = make_float4(e1x, e1y, e1z, e2x);
+    f.e2v = make_float4(e2y, e2z, a0.pos.x, a0.pos.y);
+    f.v0c = make_float4(a0.pos.z, m.colour.x, m.colour.y, m.colour.z);
+    f.mat = make_float4(m.params.x, m.params.y, m.params.z, m.typeAndPad.x);
+    a.fat[t] = f;
+}
+
 } // namespace ptd

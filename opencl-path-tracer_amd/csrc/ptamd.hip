@@ -115,6 +115,10 @@ struct pt_ctx {
         std::vector<uint32_t> leafOfs; // [node][child]: offset of a leaf child's first triangle reference in its mesh's run
         std::vector<uint32_t> refTri; // triangle references in leaf order, mesh by mesh -> caller's triangle index
         std::vector<uint32_t> stackNeed; // per packed node
+        // what a REFIT needs of the conversion and cannot change: which pair-node child the box of every packed child slot is, which
+        // slots are unused (the collapse's split choices and the packing order stay as they are)
+        std::vector<uint32_t> kidSrc; // [node][child]: (pair node << 1) | side
+        std::vector<uint8_t> kidEmpty; // [node][child]
         std::vector<TriFat> fat;
         struct Root {
             uint32_t ref; // device reference of the mesh root (a packed node, or a leaf)
@@ -132,6 +136,13 @@ struct pt_ctx {
         DevBuf<uint32_t> dLeafOfs, dRefTri;
         DevBuf<TriIsect> dTris;
         DevBuf<TriFat> dFat;
+        // refit (pt_update_geometry): the caller's vertices on the device (the triangles' intersection and shading records are re-made
+        // from them by k_refit_tris), pinned staging for them and for the re-quantised nodes, guarded by an event of its own
+        DevBuf<pt_vertex> dVerts;
+        void* stage = nullptr;
+        size_t stageBytes = 0;
+        hipEvent_t stageRead = nullptr;
+        bool stageBusy = false;
     } sg;
     int active = 0; // set the render kernels read
     int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
@@ -146,6 +157,10 @@ struct pt_ctx {
     ShadowQueueBuf shadowQ[kMaxPasses];
     bool mergePending = false;
     std::vector<VertexShade> hostVerts;
+    std::vector<pt_vertex> rawVerts; // the caller's vertices as last handed in (pt_upload_static / pt_update_geometry)
+    bool hostGeomStale = false; // hostTris / hostVerts / sg.fat are older than rawVerts (a refit re-makes them on the device only)
+    std::vector<uint32_t> denseOfNode; // caller's sub-BVH node -> pair node (0xFFFFFFFF: a leaf or a pad)
+    uint32_t numDensePairs = 0; // pair nodes [0, numDensePairs) mirror the caller's inner nodes; the rest split leaves of more than kMaxLeafTris
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
     std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
@@ -321,6 +336,7 @@ void lfsrJump(uint32_t g[4])
 struct WideKids {
     float lo[4][3], hi[4][3];
     uint32_t ref[4];
+    uint32_t src[4]; // where the box of child k comes from: (pair node << 1) | side -- what a refit re-reads (refitStaticGeom)
     bool empty[4];
 };
 std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
@@ -329,9 +345,11 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
     struct Child {
         float lo[3], hi[3];
         uint32_t ref;
+        uint32_t src;
     };
-    auto childOf = [](const PairNode& n, int side) {
+    auto childOf = [&pair](const PairNode& n, int side) {
         Child c;
+        c.src = ((uint32_t)(&n - pair.data()) << 1) | (uint32_t)side;
         const float* bx = &n.bx.x;
         const float* by = &n.by.x;
         const float* bz = &n.bz.x;
@@ -481,6 +499,7 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
         for (int k = 0; k < 4; k++) {
             wk.empty[k] = k >= n || !(kids[k].lo[0] <= kids[k].hi[0]) || kids[k].ref == kRefNone;
             wk.ref[k] = wk.empty[k] ? kRefNone : kids[k].ref;
+            wk.src[k] = k < n ? kids[k].src : 0u;
             for (int a = 0; a < 3; a++) {
                 wk.lo[k][a] = wk.empty[k] ? 1.f : kids[k].lo[a];
                 wk.hi[k][a] = wk.empty[k] ? -1.f : kids[k].hi[a];
@@ -527,9 +546,56 @@ bool invertTransform(const float* m, double w[4][8])
 // slots (half the footprint in the 4 MB-per-XCD L2, siblings share 128-byte lines) and a mesh's nodes are ONE contiguous run, which is
 // what a world-space copy of an instance (pt_bake.h) is made from.  Roots are the caller's nodes no other node refers to, plus any
 // node a top-level leaf has ever named (`extraRoots`).
+// hostTris / hostVerts from the caller's vertices as last handed in (a refit re-makes the device's records on the device and leaves these behind)
+void refreshHostGeometry(pt_ctx* c)
+{
+    if (!c->hostGeomStale)
+        return;
+    const std::vector<pt_vertex>& verts = c->rawVerts;
+    auto P = [&](uint32_t vi) { return mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]); };
+    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
+        const TriShade& ts = c->hostTriShade[t];
+        const V3 v0 = P(ts.i0);
+        const V3 e1 = P(ts.i1) - v0, e2 = P(ts.i2) - v0; // shapes.cl:37-38
+        c->hostTris[t].a = make_float4(v0.x, v0.y, v0.z, e1.x);
+        c->hostTris[t].b = make_float4(e1.y, e1.z, e2.x, e2.y);
+        c->hostTris[t].c = make_float4(e2.z, 0.f, 0.f, 0.f);
+    }
+    for (size_t v = 0; v < verts.size(); v++) {
+        c->hostVerts[v].n_u = make_float4(verts[v].normal[0], verts[v].normal[1], verts[v].normal[2], verts[v].texCoord[0]);
+        c->hostVerts[v].v_pad = make_float4(verts[v].texCoord[1], 0.f, 0.f, 0.f);
+    }
+    c->hostGeomStale = false;
+}
+
+// shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h)
+void buildFat(pt_ctx* c)
+{
+    pt_ctx::StaticGeom& g = c->sg;
+    g.fat.resize(c->hostTriShade.size());
+    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
+        const TriShade& ts = c->hostTriShade[t];
+        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
+        const TriIsect& ti = c->hostTris[t];
+        TriFat f {};
+        f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
+        float mbits;
+        std::memcpy(&mbits, &ts.material, 4);
+        f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
+        f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
+        f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
+        float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
+        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
+        f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
+        f.mat = make_float4(m[4], m[5], m[6], m[8]);
+        g.fat[t] = f;
+    }
+}
+
 int buildStaticGeom(pt_ctx* c)
 {
     pt_ctx::StaticGeom& g = c->sg;
+    refreshHostGeometry(c);
     const uint32_t nN = c->numRefNodes, nT = c->numTris;
     const std::vector<WideKids> kids = collapseKids(c->hostBottomNodes);
     const uint32_t emptyRef = makeRef(nT, 1u); // the all-zero triangle stored right after the caller's triangles (det == 0: never hit)
@@ -544,7 +610,7 @@ int buildStaticGeom(pt_ctx* c)
     for (uint32_t i = 0; i < nN; i++)
         if (c->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
             rootNodes.push_back(i);
-    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear();
+    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear();
     g.rootOfNode.assign(nN, -1);
     constexpr uint32_t kUnset = 0xFFFFFFFFu;
     std::vector<uint32_t> newIndex(kids.size(), kUnset), order;
@@ -587,10 +653,13 @@ int buildStaticGeom(pt_ctx* c)
         g.wide.resize(order.size());
         g.boxes.resize(order.size());
         g.leafOfs.resize(order.size() * 4, 0u);
+        g.kidSrc.resize(order.size() * 4, 0u);
+        g.kidEmpty.resize(order.size() * 4, 1u);
         for (size_t q = root.nodeBase; q < order.size(); q++) {
             const WideKids& wk = kids[order[q]];
             uint32_t refs[4];
             for (int k = 0; k < 4; k++) {
+                g.kidSrc[q * 4 + k] = wk.src[k], g.kidEmpty[q * 4 + k] = wk.empty[k] ? 1u : 0u;
                 refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
                 if (!wk.empty[k] && !isInner(wk.ref[k])) {
                     g.leafOfs[q * 4 + k] = (uint32_t)g.refTri.size() - root.refBase;
@@ -626,25 +695,7 @@ int buildStaticGeom(pt_ctx* c)
             }
             g.stackNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
         }
-    // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h)
-    g.fat.resize(c->hostTriShade.size());
-    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
-        const TriShade& ts = c->hostTriShade[t];
-        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
-        const TriIsect& ti = c->hostTris[t];
-        TriFat f {};
-        f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
-        float mbits;
-        std::memcpy(&mbits, &ts.material, 4);
-        f.vvvm = make_float4(a0.v_pad.x, a1.v_pad.x, a2.v_pad.x, mbits);
-        f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
-        f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
-        float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
-        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
-        f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
-        f.mat = make_float4(m[4], m[5], m[6], m[8]);
-        g.fat[t] = f;
-    }
+    buildFat(c);
     g.emptyRef = emptyRef;
     g.version++;
     g.onDevice = false;
@@ -659,11 +710,16 @@ int uploadStaticGeom(pt_ctx* c)
         return PT_OK;
     // the copy stream may still be reading the old master (a set being refreshed from it)
     HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    if (c->hostGeomStale) { // refitted before the master copy ever reached the device
+        refreshHostGeometry(c);
+        buildFat(c);
+    }
     std::vector<TriIsect> tris = c->hostTris;
     tris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) }); // what an unused child slot refers to
     int rc;
     if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dBoxes, g.boxes)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs))
-        || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat)))
+        || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat))
+        || (rc = uploadVec(c, g.dVerts, c->rawVerts)) || (rc = uploadVec(c, c->triShade, c->hostTriShade)))
         return rc;
     g.onDevice = true;
     return PT_OK;
@@ -1481,6 +1537,9 @@ void pt_destroy(pt_ctx* c)
         if (d.lastUse) (void)hipEventDestroy(d.lastUse);
     }
     c->sg.dWide.release(), c->sg.dBoxes.release(), c->sg.dLeafOfs.release(), c->sg.dRefTri.release(), c->sg.dTris.release(), c->sg.dFat.release();
+    c->sg.dVerts.release(), c->triShade.release();
+    if (c->sg.stage) (void)hipHostFree(c->sg.stage);
+    if (c->sg.stageRead) (void)hipEventDestroy(c->sg.stageRead);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
@@ -1518,10 +1577,8 @@ int pt_set_stream(pt_ctx* c, void* hip_stream)
     return PT_OK;
 }
 
-// geometryOnly: pt_update_geometry -- same topology, new positions / normals / boxes: only host-side state and (at the next
-// tick) the shading vertices change; what is on the device stays valid for the renders in flight
 static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
-    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN, bool geometryOnly)
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
 {
     {
     if (!c)
@@ -1659,12 +1716,10 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     int rc;
     c->hostTris = hTris;
     c->hostBottomNodes = std::move(hNodes);
-    if (geometryOnly) {
-        c->hostVerts = std::move(hVerts);
-        for (uint32_t i = 0; i < nN; i++) // only the boxes may differ
-            c->hostSubNodes[i] = nodes[i];
-        return buildStaticGeom(c); // new version: the sets take it in with their next upload; what is on the device stays valid meanwhile
-    }
+    c->rawVerts.assign(verts, verts + nV);
+    c->hostGeomStale = false;
+    c->denseOfNode = dense;
+    c->numDensePairs = numInner;
     HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
     if ((rc = uploadVec(c, c->materials, hMats)))
         return rc;
@@ -1699,13 +1754,22 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
 int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
     uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
 {
-    return guarded(c, "pt_upload_static", [&]() -> int { return uploadStaticImpl(c, verts, nV, tris, nT, mats, nM, nodes, nN, false); });
+    return guarded(c, "pt_upload_static", [&]() -> int { return uploadStaticImpl(c, verts, nV, tris, nT, mats, nM, nodes, nN); });
 }
 
 // New vertex data and refitted boxes for an UNCHANGED topology (what refitBVH, src/bvh/refit_bvh.cpp:6-34, leaves of a deforming
 // mesh; the reference rewrites the dynamic tail of its vertex and sub-BVH buffers every tick, src/raytracer.cpp:510-568).  The
 // arrays are the caller's whole vertex and sub-BVH arrays again; triangles, materials and node links must be the ones uploaded.
 // Takes effect with the next pt_upload_dynamic(_async) + pt_frame_tick; renders in flight are not disturbed.
+//
+// A refit cannot change what the conversion of pt_upload_static decided -- which descendants of a binary node became the children of
+// its 4-wide node (the collapse's split choices), the breadth-first packing, the leaves' triangle references, the stack bound -- so all
+// of that is kept (pt_ctx::StaticGeom::kidSrc / kidEmpty / leafOfs / refTri / stackNeed) and only what moves is re-made: the boxes of
+// the pair nodes are re-read from the caller's nodes, every packed node is re-quantised from them (host: a gather and
+// quantiseWideNode per node), and the triangles' intersection and shading records are re-made ON THE DEVICE from the new vertices
+// (k_refit_tris, copy stream).  Vertices and nodes travel through pinned staging guarded by an event of its own: no stream is
+// synchronised.  (Round 3 re-ran the whole conversion here -- collapse, packing, 128 bytes of shading record per triangle on one host
+// thread -- and re-uploaded everything behind a synchronisation of the copy stream.)
 int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_sub_bvh_node* nodes, uint32_t nN)
 {
     return guarded(c, "pt_update_geometry", [&]() -> int {
@@ -1718,10 +1782,112 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
         for (uint32_t i = 0; i < nN; i++)
             if (nodes[i].leftChildOrFirstTriangle != c->hostSubNodes[i].leftChildOrFirstTriangle || nodes[i].triangleCount != c->hostSubNodes[i].triangleCount)
                 return fail(c, PT_ERR_INVALID, "pt_update_geometry: node %u changed its links: a refit keeps the topology (use pt_upload_static for a rebuilt tree)", i);
-        std::vector<pt_triangle> tris(c->numTris);
-        for (uint32_t t = 0; t < c->numTris; t++)
-            tris[t] = { { c->hostTriShade[t].i0, c->hostTriShade[t].i1, c->hostTriShade[t].i2 }, c->hostTriShade[t].material };
-        return uploadStaticImpl(c, verts, nV, tris.data(), c->numTris, c->hostMaterials.data(), (uint32_t)c->hostMaterials.size(), nodes, nN, true);
+        HIPCHK(c, hipSetDevice(c->device));
+        pt_ctx::StaticGeom& g = c->sg;
+        std::vector<PairNode>& pair = c->hostBottomNodes;
+        // ---- pair-node boxes: the caller's refitted boxes for the pairs that mirror its inner nodes ...
+        for (uint32_t i = 0; i < nN; i++) {
+            const uint32_t d = c->denseOfNode[i];
+            if (d == 0xFFFFFFFFu)
+                continue;
+            const uint32_t l = nodes[i].leftChildOrFirstTriangle;
+            const pt_sub_bvh_node &L = nodes[l], &R = nodes[l + 1];
+            pair[d].bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
+            pair[d].by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
+            pair[d].bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
+        }
+        // ... and, for the pairs that split a leaf of more than kMaxLeafTris triangles (appended children first), the bounds of their triangles
+        if (pair.size() > c->numDensePairs) {
+            auto boxOf = [&](uint32_t ref, V3& lo, V3& hi) {
+                lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
+                if (refCount(ref) != 0u) {
+                    for (uint32_t t = refIndex(ref); t < refIndex(ref) + refCount(ref); t++) {
+                        const TriShade& ts = c->hostTriShade[t];
+                        for (uint32_t vi : { ts.i0, ts.i1, ts.i2 }) {
+                            const V3 p = mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]);
+                            lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
+                            hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+                        }
+                    }
+                } else {
+                    const PairNode& n = pair[refIndex(ref)];
+                    lo = mk(fminf(n.bx.x, n.bx.z), fminf(n.by.x, n.by.z), fminf(n.bz.x, n.bz.z));
+                    hi = mk(fmaxf(n.bx.y, n.bx.w), fmaxf(n.by.y, n.by.w), fmaxf(n.bz.y, n.bz.w));
+                }
+            };
+            for (size_t j = c->numDensePairs; j < pair.size(); j++) {
+                V3 llo, lhi, rlo, rhi;
+                boxOf(pair[j].left, llo, lhi);
+                boxOf(pair[j].right, rlo, rhi);
+                pair[j].bx = make_float4(llo.x, lhi.x, rlo.x, rhi.x);
+                pair[j].by = make_float4(llo.y, lhi.y, rlo.y, rhi.y);
+                pair[j].bz = make_float4(llo.z, lhi.z, rlo.z, rhi.z);
+            }
+        }
+        // ---- the packed 4-wide nodes: same children in the same slots, new boxes
+        for (size_t q = 0; q < g.wide.size(); q++) {
+            float lo[4][3], hi[4][3];
+            uint32_t refs[4];
+            bool empty[4];
+            for (int k = 0; k < 4; k++) {
+                empty[k] = g.kidEmpty[q * 4 + k] != 0u;
+                refs[k] = g.wide[q].child[k];
+                if (empty[k]) {
+                    for (int a = 0; a < 3; a++)
+                        lo[k][a] = 1.f, hi[k][a] = -1.f;
+                    continue;
+                }
+                const uint32_t src = g.kidSrc[q * 4 + k];
+                const PairNode& n = pair[src >> 1];
+                const int side = (int)(src & 1u);
+                const float *bx = &n.bx.x, *by = &n.by.x, *bz = &n.bz.x;
+                lo[k][0] = bx[side * 2], hi[k][0] = bx[side * 2 + 1];
+                lo[k][1] = by[side * 2], hi[k][1] = by[side * 2 + 1];
+                lo[k][2] = bz[side * 2], hi[k][2] = bz[side * 2 + 1];
+            }
+            for (int k = 0; k < 4; k++)
+                for (int a = 0; a < 3; a++)
+                    g.boxes[q].lo[k][a] = lo[k][a], g.boxes[q].hi[k][a] = hi[k][a];
+            quantiseWideNode(lo, hi, refs, empty, g.emptyRef, &g.wide[q]);
+        }
+        c->rawVerts.assign(verts, verts + nV);
+        c->hostGeomStale = true; // hostTris / hostVerts / sg.fat are re-made only if the whole conversion ever runs again
+        g.version++;
+        if (!g.onDevice)
+            return PT_OK; // nothing of the old geometry is on the device yet: the first upload takes everything from the host arrays
+        // ---- the device's master copy: vertices and nodes through pinned staging on the copy stream, triangles re-made there
+        static_assert(sizeof(VertexIn) == sizeof(pt_vertex), "k_refit_tris reads the caller's vertex records as they are");
+        const size_t bytesV = (size_t)nV * sizeof(pt_vertex), bytesW = g.wide.size() * sizeof(WideNode), bytesB = g.boxes.size() * sizeof(WideBoxes);
+        const size_t total = bytesV + bytesW + bytesB;
+        if (!g.stageRead)
+            HIPCHK(c, hipEventCreateWithFlags(&g.stageRead, hipEventDisableTiming));
+        if (g.stageBusy) { // the previous refit's copies out of the staging memory (normally long done)
+            HIPCHK(c, hipEventSynchronize(g.stageRead));
+            g.stageBusy = false;
+        }
+        if (g.stageBytes < total) {
+            if (g.stage)
+                (void)hipHostFree(g.stage);
+            g.stage = nullptr;
+            g.stageBytes = total + total / 8;
+            HIPCHK(c, hipHostMalloc(&g.stage, g.stageBytes, hipHostMallocDefault));
+        }
+        unsigned char* st = (unsigned char*)g.stage;
+        std::memcpy(st, verts, bytesV);
+        HIPCHK(c, hipMemcpyAsync(g.dVerts.p, st, bytesV, hipMemcpyHostToDevice, c->copyStream));
+        if (bytesW) {
+            std::memcpy(st + bytesV, g.wide.data(), bytesW);
+            std::memcpy(st + bytesV + bytesW, g.boxes.data(), bytesB);
+            HIPCHK(c, hipMemcpyAsync(g.dWide.p, st + bytesV, bytesW, hipMemcpyHostToDevice, c->copyStream));
+            HIPCHK(c, hipMemcpyAsync(g.dBoxes.p, st + bytesV + bytesW, bytesB, hipMemcpyHostToDevice, c->copyStream));
+        }
+        HIPCHK(c, hipEventRecord(g.stageRead, c->copyStream));
+        g.stageBusy = true;
+        RefitArgs ra {};
+        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->triShade.p, ra.mats = c->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->numTris;
+        hipLaunchKernelGGL(k_refit_tris, dim3((c->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
+        HIPCHK(c, hipGetLastError());
+        return PT_OK;
     });
 }
 

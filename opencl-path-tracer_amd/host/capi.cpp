@@ -22,7 +22,8 @@ struct SceneHandle {
     Scene scene;
     std::vector<SceneNode*> nodes; // by id
     FlattenedScene flat;
-    bool flattened = false;
+    bool flattened = false; // `flat` is current
+    bool staticFlattened = false; // its static arrays are (a moved node leaves them valid; a new node does not)
 };
 
 template <typename F>
@@ -265,7 +266,7 @@ int pth_scene_add_node(pth_scene* s, const pth_mesh* m, const float location[3],
         SceneNode& n = h.scene.addNode(((const MeshHandle*)m)->mesh, t, p);
         id = (int)h.nodes.size();
         h.nodes.push_back(&n);
-        h.flattened = false;
+        h.flattened = h.staticFlattened = false;
     });
     return rc == 0 ? id : -1;
 }
@@ -289,6 +290,25 @@ int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts)
     return guarded([&] {
         SceneHandle& h = *(SceneHandle*)s;
         h.flat = flattenScene(h.scene);
+        h.flattened = h.staticFlattened = true;
+        counts->num_vertices = (uint32_t)h.flat.vertices.size();
+        counts->num_triangles = (uint32_t)h.flat.triangles.size();
+        counts->num_materials = (uint32_t)h.flat.materials.size();
+        counts->num_sub_nodes = (uint32_t)h.flat.subBvhNodes.size();
+        counts->num_lights = (uint32_t)h.flat.emissiveTriangles.size();
+        counts->num_top_nodes = (uint32_t)h.flat.topBvhNodes.size();
+        counts->top_root = h.flat.topBvhRoot;
+        counts->num_instances = (uint32_t)h.scene.numInstances();
+    });
+}
+
+int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts)
+{
+    return guarded([&] {
+        SceneHandle& h = *(SceneHandle*)s;
+        if (!h.staticFlattened)
+            throw std::logic_error("pth_scene_flatten_dynamic: call pth_scene_flatten first (and again after adding nodes)");
+        flattenDynamic(h.scene, h.flat);
         h.flattened = true;
         counts->num_vertices = (uint32_t)h.flat.vertices.size();
         counts->num_triangles = (uint32_t)h.flat.triangles.size();

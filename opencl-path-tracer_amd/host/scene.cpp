@@ -1,6 +1,8 @@
 #include "scene.h"
 #include <algorithm>
 #include <cstring>
+#include <functional>
+#include <limits>
 #include <stdexcept>
 
 namespace raytracer {
@@ -77,6 +79,86 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
     });
     if (active.empty())
         throw std::invalid_argument("buildTopBVH: scene has no mesh instances");
+    // The agglomerative clustering below is the reference's (top_bvh_build.cpp:42-93): every merge searches ALL clusters still active
+    // for a best partner -- O(n) per search, O(n^2) and worse per tree: 0.03 ms for 14 instances, 16 ms for 1 000, 240 ms for 4 000, every
+    // tick.  It is kept where it is cheap (the reference's scenes hold a handful of instances: the identical tree); larger scenes get a
+    // top-down build over the instance boxes -- 16-bin SAH on the centroids along the longest axis, median where the bins do not separate
+    // -- which is O(n log n).  Either tree is just as valid an input to the traversal (inner nodes after their children, root last).
+    if (active.size() > kAgglomerativeMaxInstances) {
+        struct Range {
+            uint32_t first, count;
+        };
+        std::vector<uint32_t> order = active;
+        std::function<uint32_t(Range)> build = [&](Range r) -> uint32_t {
+            if (r.count == 1)
+                return order[r.first];
+            AABB cb, nb;
+            for (uint32_t k = 0; k < r.count; k++) {
+                const AABB b = getBox(out.nodes[order[r.first + k]]);
+                cb.fit(b.center());
+                nb.fit(b);
+            }
+            const vec3 ext = cb.extent();
+            const int axis = ext.x >= ext.y ? (ext.x >= ext.z ? 0 : 2) : (ext.y >= ext.z ? 1 : 2);
+            auto comp = [&](const vec3& v) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); };
+            const float lo = comp(cb.min), width = comp(ext);
+            uint32_t mid = r.count / 2;
+            bool split = false;
+            if (width > 0.0f && r.count > 4) {
+                constexpr int kBins = 16;
+                AABB binBox[kBins];
+                uint32_t binCount[kBins] = {};
+                auto binOf = [&](uint32_t node) { return std::min(kBins - 1, (int)((comp(getBox(out.nodes[node]).center()) - lo) / width * kBins)); };
+                for (uint32_t k = 0; k < r.count; k++) {
+                    const int b = binOf(order[r.first + k]);
+                    binBox[b].fit(getBox(out.nodes[order[r.first + k]]));
+                    binCount[b]++;
+                }
+                float rightArea[kBins];
+                AABB acc;
+                for (int b = kBins - 1; b > 0; b--) {
+                    acc.fit(binBox[b]);
+                    rightArea[b] = acc.surfaceArea();
+                }
+                acc = AABB();
+                uint32_t nLeft = 0;
+                float best = std::numeric_limits<float>::max();
+                int bestBin = -1;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.fit(binBox[b]);
+                    nLeft += binCount[b];
+                    if (nLeft == 0 || nLeft == r.count)
+                        continue;
+                    const float cost = acc.surfaceArea() * (float)nLeft + rightArea[b + 1] * (float)(r.count - nLeft);
+                    if (cost < best)
+                        best = cost, bestBin = b;
+                }
+                if (bestBin >= 0) {
+                    auto it = std::partition(order.begin() + r.first, order.begin() + r.first + r.count, [&](uint32_t node) { return binOf(node) <= bestBin; });
+                    mid = (uint32_t)(it - (order.begin() + r.first));
+                    split = mid > 0 && mid < r.count;
+                }
+            }
+            if (!split) { // all centroids in one place (or a handful of boxes): the median along the axis
+                mid = r.count / 2;
+                std::nth_element(order.begin() + r.first, order.begin() + r.first + mid, order.begin() + r.first + r.count,
+                    [&](uint32_t x, uint32_t y) { return comp(getBox(out.nodes[x]).center()) < comp(getBox(out.nodes[y]).center()); });
+            }
+            const uint32_t l = build({ r.first, mid }), rr = build({ r.first + mid, r.count - mid });
+            TopBVHNode inner;
+            std::memset(&inner, 0, sizeof(inner));
+            setBox(inner, nb);
+            mat4 identity;
+            std::memcpy(inner.invTransform, identity.data(), sizeof(inner.invTransform));
+            inner.a = l;
+            inner.b = rr;
+            inner.isLeaf = 0;
+            out.nodes.push_back(inner);
+            return (uint32_t)out.nodes.size() - 1;
+        };
+        out.rootNode = build({ 0, (uint32_t)order.size() });
+        return out;
+    }
 
     auto mergedArea = [&](uint32_t x, uint32_t y) { return getBox(out.nodes[x]).merged(getBox(out.nodes[y])).surfaceArea(); };
     auto bestPartner = [&](uint32_t x) {

@@ -49,6 +49,8 @@ struct TopBvhBuildResult {
     uint32_t rootNode = 0;
     std::vector<TopBVHNode> nodes;
 };
+// more instances than this: a top-down SAH build instead of the reference's O(n^2) agglomerative clustering (scene.cpp)
+constexpr size_t kAgglomerativeMaxInstances = 256;
 TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>& meshBvhOffsets);
 
 // Everything pt_upload_static / pt_upload_dynamic consume.

@@ -68,6 +68,7 @@ def lib():
         _lib.pth_scene_add_node.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.pth_scene_set_transform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.pth_scene_flatten.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
+        _lib.pth_scene_flatten_dynamic.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
         _lib.pth_scene_copy.argtypes = [C.c_void_p] * 7
         _lib.pth_camera_data.argtypes = [C.POINTER(CameraParams), C.c_void_p]
         _lib.pth_image_hdr_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -249,6 +250,21 @@ class Scene:
         if lib().pth_scene_copy(self._h, _ptr(v), _ptr(t), _ptr(m), _ptr(n), _ptr(l), _ptr(top)):
             _err("pth_scene_copy")
         return FlatScene(v, t, m, n, l, top, c.top_root, c.num_instances)
+
+    def flatten_dynamic(self, flat):
+        """The per-tick half of flatten(): lights and top-level BVH from the scene graph as it stands (what RayTracer::frameTick
+        does on the host); the static arrays of `flat` are shared, not copied.  Returns (new FlatScene, seconds inside the host library)."""
+        import time
+        c = SceneCounts()
+        t0 = time.perf_counter()
+        if lib().pth_scene_flatten_dynamic(self._h, C.byref(c)):
+            _err("pth_scene_flatten_dynamic")
+        dt = time.perf_counter() - t0
+        l = np.zeros(c.num_lights, L.EMISSIVE_TRIANGLE)
+        top = np.zeros(c.num_top_nodes, L.TOP_BVH_NODE)
+        if lib().pth_scene_copy(self._h, None, None, None, None, _ptr(l), _ptr(top)):
+            _err("pth_scene_copy")
+        return FlatScene(flat.vertices, flat.triangles, flat.materials, flat.sub_nodes, l, top, c.top_root, c.num_instances), dt
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

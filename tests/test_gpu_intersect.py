@@ -441,3 +441,31 @@ def test_deep_trees_use_the_spilled_stack_and_too_deep_ones_are_rejected(gpu):
     with pytest.raises(RuntimeError, match="stack"):
         ctx.upload_scene(flat2)
     ctx.close()
+
+
+def test_stack_bound_of_a_root_that_shares_its_subtree_with_an_earlier_root(gpu):
+    """Two roots of the caller's sub-BVH array may share a subtree (nothing in the boundary's contract says the array is a forest): the
+    second one is packed as a run of its own whose children lie in the FIRST root's run.  Its worst-case stack is then its own siblings
+    plus the shared subtree's -- taking 0 for children packed earlier (round 3) would let a 100-level chain pass as shallow, and the packet
+    kernel's 64-entry lane stack would wrap.  Node 1 (the reference allocator's unused dummy) becomes a second root over the chain from
+    node 4 on; the top-level leaf names it."""
+    n = 100
+    flat, z = _chain_scene(n)
+    flat.sub_nodes[1] = flat.sub_nodes[3]  # an inner node with the children of node 3: (leaf 1, the rest of the chain)
+    assert flat.sub_nodes[1]["count"] == 0 and flat.sub_nodes[1]["left"] == 4
+    leaves = np.flatnonzero(flat.top_nodes["isLeaf"] != 0)
+    assert len(leaves) == 1
+    flat.top_nodes["a"][leaves[0]] = 1
+    ctx = gpu.Context(8, 8, flags=gpu.FLAG_PACKET_INTERSECT)
+    ctx.upload_scene(flat)
+    m = 1000
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0.05, 0.45, (m, 2)).astype(np.float32)
+    o = np.concatenate([np.c_[xy, np.full(m, 100.0, np.float32)], np.c_[xy, np.full(m, -100.0, np.float32)]]).astype(np.float32)
+    d = np.concatenate([np.tile([0, 0, -1], (m, 1)), np.tile([0, 0, 1], (m, 1))]).astype(np.float32)
+    got = ctx.intersect(o, d)
+    assert (got["prim"][:m] == n - 1).all() and (got["prim"][m:] == 1).all()  # triangle 0 hangs off node 0 only
+    st = ctx.stats()
+    assert st["stack_need"] >= n - 4, st["stack_need"]
+    assert st["packet_launches"] == 0, "a tree that needs more than 64 stack entries must not reach the packet kernel"
+    ctx.close()

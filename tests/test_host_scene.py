@@ -539,3 +539,46 @@ def test_refit_keeps_topology_and_restores_the_invariants(builder):
     assert np.array_equal(m.geometry()[0]["normal"], verts0["normal"])
     with pytest.raises(RuntimeError):
         m.refit(p0[:-1])
+
+
+def test_flatten_dynamic_is_the_per_tick_half_of_flatten():
+    """pth_scene_flatten_dynamic = flattenDynamic alone (what RayTracer::frameTick runs on the host): after a node moved it yields the
+    lights and the top-level BVH a full flatten yields, and leaves the static arrays alone; a new node needs a full flatten first."""
+    b = scenes.instanced_grid(64, 36, level=2, sky_size=(16, 8))
+    flat = b.flat
+    b.scene.set_transform(3, location=(0.1, 0.7, 0.2))
+    part, _ = b.scene.flatten_dynamic(flat)
+    full = b.scene.flatten()
+    assert np.array_equal(part.top_nodes, full.top_nodes) and np.array_equal(part.lights, full.lights) and part.top_root == full.top_root
+    assert not np.array_equal(part.top_nodes, flat.top_nodes)
+    assert part.vertices is flat.vertices and part.sub_nodes is flat.sub_nodes
+    b.scene.add_node(scenes.blob_mesh(L.material_diffuse((1, 1, 1)), level=1))
+    with pytest.raises(RuntimeError, match="pth_scene_flatten first"):
+        b.scene.flatten_dynamic(flat)
+
+
+@pytest.mark.parametrize("n", [300, 3000])
+def test_top_level_build_for_many_instances(n):
+    """More than kAgglomerativeMaxInstances (256) instances: top-down SAH over the instance boxes instead of the reference's O(n^2)
+    agglomerative clustering (top_bvh_build.cpp:42-93).  The contract of the array is the reference's: every instance is a leaf reached
+    exactly once from the root, children are stored before their parent and lie inside it, the root is the last node."""
+    b = scenes.instance_field(64, 36, n=n, level=1)
+    import time
+    t0 = time.perf_counter()
+    flat = b.scene.flatten()
+    dt = time.perf_counter() - t0
+    top = flat.top_nodes
+    assert flat.top_root == len(top) - 1 and len(top) == 2 * flat.num_instances - 1
+    seen, stack = np.zeros(len(top), bool), [flat.top_root]
+    while stack:
+        i = stack.pop()
+        assert not seen[i]
+        seen[i] = True
+        if top[i]["isLeaf"]:
+            continue
+        for ch in (int(top[i]["a"]), int(top[i]["b"])):
+            assert ch < i
+            assert (top[ch]["min"][:3] >= top[i]["min"][:3]).all() and (top[ch]["max"][:3] <= top[i]["max"][:3]).all()
+            stack.append(ch)
+    assert seen.all() and int((top["isLeaf"] != 0).sum()) == flat.num_instances
+    assert dt < 1.0, f"{n} instances flattened in {dt:.2f} s"
