@@ -162,8 +162,19 @@ def cpu_baseline(bundle, seconds, width, height):
 
 def plan_in_flight(requested, world, owned_pixels, max_entries=MAX_ENTRIES):
     """Samples in flight per pixel on one rank: `requested` x ranks (weak scaling: every rank keeps the same number of path
-    segments resident whatever N is), bounded by the library's 4096 planes and by the entries that fit in HBM."""
-    return max(1, min(requested * world, 4096, max_entries // max(owned_pixels, 1)))
+    segments resident whatever N is), bounded by the library's 4096 planes and by the entries that fit in HBM -- and a MULTIPLE OF 256
+    (a power of two below that): the library keeps up to 256 samples of a pixel next to each other in its queues, which is what the
+    bundle kernel and the coherent first bounce live on, only when the batch divides that way.  (Round 3 returned 2 046 for an eighth of
+    the 1080p frame -- the 32 x 32 tiles leave the ranks' shares uneven by a fraction of a percent, 259 328 instead of 259 200 pixels --
+    and a batch of 2 046 = 2 x 1 023 keeps only TWO samples of a pixel together: the emulated rank traced 7 100 instead of 10 600
+    Mrays/s, profiles/round4/r4e_rank_emul_config4_weak.txt.  The budget now carries 1.5 % of slack for the uneven shares.)"""
+    fit = (max_entries + max_entries // 64) // max(owned_pixels, 1)
+    n = max(1, min(requested * world, 4096, fit))
+    if n >= 256:
+        n -= n % 256
+    elif n >= 2:
+        n = 1 << (n.bit_length() - 1)
+    return n
 
 
 def reduce_accumulator(dist, accum, backend, world):

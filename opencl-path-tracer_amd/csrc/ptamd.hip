@@ -2455,7 +2455,16 @@ int pt_render(pt_ctx* c, uint32_t spp)
     HIPCHK(c, hipEventRecord(c->evStart, c->stream));
     const bool fixedSchedule = !parityMode(c) && c->cfg.max_active_rays == 0;
     for (uint32_t s = 0; s < spp;) {
-        const uint32_t batch = fixedSchedule ? std::min(c->planes, spp - s) : 1u;
+        uint32_t batch = fixedSchedule ? std::min(c->planes, spp - s) : 1u;
+        if (fixedSchedule) {
+            // Up to kGenInterleave samples of a pixel are queue neighbours only if the batch is a multiple of that power of two (k_gen,
+            // primaryEntry): a batch of 2 046 would keep TWO together and lose the bundle kernel and every coherent launch behind it.
+            // Cut the batch at the largest such multiple; what is left follows as smaller batches.
+            uint32_t g = kGenInterleave;
+            while (g > 1u && batch < g)
+                g >>= 1;
+            batch -= batch % g;
+        }
         rc = fixedSchedule ? renderSampleFixed(c, c->spp, batch, prof) : renderSampleRefill(c, c->spp);
         if (rc) {
             foldPlanesNow(c); // what the earlier batches of this call deposited belongs to the samples already counted

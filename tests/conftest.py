@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """What the image gates of the GPU tests measured (gpu_util.record_margin) goes to gpurun_out/parity_margins.json."""
+    try:
+        import json
+        import gpu_util
+        if gpu_util.MARGINS:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_margins.json"), "w") as f:
+                json.dump(gpu_util.MARGINS, f, indent=1, sort_keys=True)
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Build every native piece once per session (no-op when up to date)."""

@@ -104,3 +104,22 @@ def tonemap(accum_rgb, spp, camera):
 
 def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+# ---- parity margins on the record: what every image gate measured, next to the gate (tests/conftest.py writes them out at the end of
+# the session: gpurun_out/parity_margins.json on the GPU box, copied to profiles/roundN/ and quoted in DESIGN.md section 2)
+MARGINS = {}
+
+
+def record_margin(name, **values):
+    MARGINS[name] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+
+
+def image_margins(name, got, want, spp, camera, bias_gate, rmse_gate, **extra):
+    """bias of the image mean and tone-mapped RMSE (SURVEY 8(d)'s two statistics) of `got` against the oracle's `want`, recorded and gated"""
+    bias = abs(float(got.mean()) - float(want.mean())) / float(want.mean())
+    e = rmse(tonemap(got, spp, camera), tonemap(want, spp, camera))
+    record_margin(name, bias=bias, bias_gate=bias_gate, tonemapped_rmse=e, rmse_gate=rmse_gate, spp=spp, pixels=int(len(got)), **extra)
+    assert bias < bias_gate, (name, bias)
+    assert e < rmse_gate, (name, e)
+    return bias, e

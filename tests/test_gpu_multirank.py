@@ -59,6 +59,27 @@ def test_bench_starts_its_own_ranks_and_strong_scaling_keeps_the_job_fixed(gpu, 
     assert np.array_equal(np.load(one), np.load(two))
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_four_rank_job_on_one_gpu_equals_the_single_rank_job(gpu, tmp_path, scaling):
+    """Four ranks on the test box's one GPU (the box admits six processes on its card; the driver's own scaling run uses N = 1, 2, 4, 8
+    GPUs -- the eight-rank planning is rehearsed on the CPU, tests/test_multirank_gloo.py): interleaved 32x32 tiles over four ranks, the
+    smallest share deciding the batch, the reduce and the aggregation over four processes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    one, four = str(tmp_path / "one.npy"), str(tmp_path / "four.npy")
+    j4 = _run([sys.executable, "bench.py", "--gpus", "4", "--share-gpu", "--backend", "gloo", "--scaling", scaling, "--in-flight", "4", "--dump-accum", four] + COMMON, env)
+    if scaling == "weak":  # 4 ranks x 4 x 4 = 16 in flight on a quarter of the pixels, two batches per step: 32 samples per pixel
+        j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--in-flight", "16", "--dump-accum", one] + COMMON, env)
+        assert j4["config"]["samples_in_flight"] == 16 and j4["rays"]["primary"] == 192 * 128 * 32
+    else:  # the job is 4 x 2 = 8 samples per pixel whatever N is
+        j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--in-flight", "8", "--dump-accum", one]
+                  + [a if a != "2" or COMMON[i - 1] != "--rounds" else "1" for i, a in enumerate(COMMON)], env)
+        assert j4["config"]["spp_per_step"] == 8 == j1["config"]["spp_per_step"] and j4["rays"]["primary"] == 192 * 128 * 8
+    assert j4["n_gpus"] == 4 and j4["scaling"] == scaling and j4["config"]["pixels_per_rank"] == 192 * 128 // 4
+    assert j4["rays"] == j1["rays"]
+    assert np.array_equal(np.load(one), np.load(four)), "tile-sharded render + reduce must equal the single-rank image bit for bit"
+
+
 def test_oversized_jobs_and_overlapping_tiles_fail_with_a_message(gpu):
     """BASELINE config 5 sized naively -- 4K, a rank's eighth of the pixels, 2 048 samples in flight = 2.1 G queue entries,
     ~350 GB -- must be refused when the queues are set up, with a message that says what to change, not die in a later

@@ -44,8 +44,9 @@ def test_parity_mode_256spp_gate(gpu, golden, name):
     g = golden[f"image_{name}_accum_256spp"]
     e = U.rmse(U.tonemap(a, 256, cam), U.tonemap(g, 256, cam))
     bias = abs(a.mean() - g.mean()) / g.mean()
+    U.record_margin(f"parity mode vs the reference kernels' image, {name}, 64x36, 256 spp", tonemapped_rmse=e, rmse_gate=1e-3, bias=bias, bias_gate=3e-3, spp=256, pixels=len(a))
     assert e < 1e-3, f"RMSE {e:.2e}"
-    assert bias < 1e-2, f"mean bias {bias:.2e}"
+    assert bias < 3e-3, f"mean bias {bias:.2e}"  # two independent 256-spp estimates (paths flip behind glass): measured 1.0e-3
     # resolve == accumulate kernel of the reference on the same sums
     ctx.write_accum(np.concatenate([g, np.zeros((len(g), 1), np.float32)], axis=1), 256)
     img = ctx.resolve()
@@ -90,7 +91,7 @@ CASES = {
 def test_production_render_matches_oracle(gpu, case):
     """Counter PRNG: the GPU and the oracle draw identical random numbers per (pixel, sample, depth, dim), so
     the images agree path by path except where fp32 round-off flips a branch.  Gates: mean bias < 1e-3,
-    ray counts within 0.1 %, > 97 % of pixels within 1e-3 relative, RMSE (tonemapped) < 5e-3 at 32 spp."""
+    ray counts within 0.1 %, > 97 % of pixels within 1e-3 relative, RMSE (tonemapped) < 1e-3 at 32 spp (measured <= 5e-5)."""
     b = CASES[case]()
     spp = 32
     ctx = U.make_ctx(gpu, b, 96, 54, seed=3, samples_in_flight=1)
@@ -103,10 +104,9 @@ def test_production_render_matches_oracle(gpu, case):
     assert st["rays_generated"] == cnt["raysGenerated"] == 96 * 54 * spp
     for k, ck in (("rays_extension", "raysExtension"), ("rays_shadow", "raysShadow"), ("shade_hits", "shadeHits")):
         assert abs(st[k] - cnt[ck]) <= 1e-3 * cnt[ck] + 2, (k, st[k], cnt[ck])
-    assert abs(a.mean() - ref.mean()) / ref.mean() < 1e-3
+    U.image_margins(f"production PRNG vs the oracle path by path, {case}, 96x54, 32 spp", a, ref, spp, b.camera, 1e-3, 1e-3)
     close = np.isclose(a, ref, rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1)
     assert close.mean() > 0.97, close.mean()
-    assert U.rmse(U.tonemap(a, spp, b.camera), U.tonemap(ref, spp, b.camera)) < 5e-3
     ctx.close()
 
 

@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -62,10 +63,13 @@ def test_tile_partition_is_exact():
         assert max(counts) - min(counts) <= 0.02 * 1920 * 1080 / world, "interleaved tiles balance the ranks"
 
 
-def test_two_rank_render_and_reduce(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_render_and_reduce(tmp_path, world):
+    """world = 8: the rank count of the driver's scaling run (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) -- eight
+    processes through bench.py's planning (tile lists, samples in flight from the rank's share), the one reduce and the aggregation."""
     out = str(tmp_path / "rank0.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     z = np.load(out)
     for p in (os.path.join(ROOT, "opencl-path-tracer_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
@@ -75,7 +79,23 @@ def test_two_rank_render_and_reduce(tmp_path):
     full, cnt = O.render(O.BoundScene(b.flat, sky=b.sky), b.camera, W, H, SPP, seed=1, threads=2)
     assert np.array_equal(z["accum"], full), "reduced tile renders != single-rank render"
     assert z["rays"][0] == cnt["raysExtension"] + cnt["raysShadow"]
-    assert z["tmax"][0] == 2.0 and 0 < z["owned"] < W * H
+    assert z["tmax"][0] == float(world) and 0 < z["owned"] < W * H  # elapsed = the slowest rank's
+
+
+def test_planning_of_the_eight_rank_jobs():
+    """What every rank of the driver's N = 8 runs computes before it touches its GPU (bench.main): config 4 and config 5, weak and strong."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for (w, h), want_weak in (((1920, 1080), 2048), ((3840, 2160), 512)):
+        owned = []
+        for r in range(8):
+            rects = bench.tile_rects(w, h, r, 8)
+            owned.append(sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects))
+        assert sum(owned) == w * h
+        plans = [bench.plan_in_flight(256, 8, o, bench.MAX_ENTRIES) for o in owned]
+        assert min(plans) <= want_weak and min(plans) >= want_weak * 0.95, (plans, want_weak)  # 4K: capped by the entries that fit in HBM
+        assert min(plans) * max(owned) <= bench.MAX_ENTRIES * 1.001
+        assert min(min(plans), 256 * 5) == min(min(plans), 1280)  # strong scaling: the job's 256 x 5 samples per pixel bound the batch
 
 
 def test_bench_without_a_launcher_starts_its_ranks_as_child_processes():
