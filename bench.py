@@ -44,7 +44,8 @@ sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a device copy reaches on the box at hand is measured live
+                       # (roofline.peak_measured_copy: 4.9 - 6.3 TB/s box to box)
 BYTES_PER_EXT_RAY = 48  # closest-hit intersect reads 28 B ray, writes 20 B hit record
 BYTES_PER_SHADOW_RAY = 44  # 28 B ray + 12 B contribution + 4 B pixel
 BYTES_PER_DEPOSIT = 24  # 12 B read + 12 B written per accumulator update (unoccluded shadow ray, emissive hit, sky miss)

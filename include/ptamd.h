@@ -235,7 +235,9 @@ int pt_set_accum_buffer(pt_ctx* ctx, void* device_float4);
 int pt_clear(pt_ctx* ctx); /* clearAccumulationBuffer, src/raytracer.cpp:452-462; also resets spp */
 
 /* ---- render -- replaces RayTracer::traceRays (src/raytracer.cpp:289-430): `spp` samples per owned pixel,
- * asynchronous on the context's stream. */
+ * asynchronous on the context's stream.  The accumulator is bit-reproducible for the same sequence of pt_render calls (whatever
+ * the schedule inside, the tile partition or the GPU count); another grouping of the same samples -- pt_render(N) against N x
+ * pt_render(1) -- sums in another order and agrees to round-off only. */
 int pt_render(pt_ctx* ctx, uint32_t spp);
 int pt_synchronize(pt_ctx* ctx);
 /* accumulate kernel, assets/cl/accumulate.cl:6-34: mean -> exposure -> Reinhard -> sRGB; width*height*4 floats out (host) */

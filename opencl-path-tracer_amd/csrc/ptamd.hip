@@ -13,6 +13,10 @@
 #endif
 #include <algorithm>
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h> // only for the two enumerators pt_reduce_accum passes (the library itself is bound at run time, below)
+#define PT_HAVE_RCCL_HEADER 1
+#endif
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -302,7 +306,8 @@ int uploadVec(pt_ctx* c, DevBuf<T>& buf, const std::vector<T>& host)
 // src/lfsr113.c:183-240): stream k+1 starts 2^55 steps after stream k.
 void lfsrJump(uint32_t g[4])
 {
-    int z, b;
+    uint32_t z, b; // (the library computes in int: its left shifts overflow -- undefined in C++, found by UBSan; every right shift is masked down to
+                   // the bits a logical shift yields, so unsigned arithmetic gives the same words)
     z = g[0] & (uint32_t)(-2);
     b = (z << 6) ^ z;
     z = (z) ^ (z << 2) ^ (z << 3) ^ (z << 10) ^ (z << 13) ^ (z << 16) ^ (z << 19) ^ (z << 22) ^ (z << 25) ^ (z << 27) ^ (z << 28)
@@ -739,6 +744,15 @@ int resetStreams(pt_ctx* c)
     return uploadVec(c, c->streams, host);
 }
 
+#ifndef PT_SPLIT_SHADOW_ACCUM
+#define PT_SPLIT_SHADOW_ACCUM 1 // one sample in flight: shadow rays deposit into an accumulator of their own, a shadow queue per bounce (renderSampleFixed)
+#endif
+// does a context with queues of `cap` entries render with the shadow rays' own accumulator and a shadow queue per bounce (renderSampleFixed)?
+inline bool splitShadowAccum(const pt_ctx* c, uint64_t cap)
+{
+    return PT_SPLIT_SHADOW_ACCUM && c->planes == 1u && !parityMode(c) && c->cfg.max_active_rays == 0 && cap <= (4u << 20) && !(c->packetUse & 2u) && maxBounces(c) <= (uint32_t)kMaxPasses;
+}
+
 int ensureQueues(pt_ctx* c)
 {
     if (c->queuesReady)
@@ -779,7 +793,11 @@ int ensureQueues(pt_ctx* c)
         // per entry: one 16-byte record
         const bool descent = (c->descentUse & 3u) != 0u && c->planes >= 16u;
         const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0) + (descent ? sizeof(uint4) : 0);
-        const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4);
+        // one sample in flight and a small queue (the 1-spp frames of RayTracer::rayTrace): the shadow rays' own accumulator (16 B per pixel of the
+        // image) and a shadow queue per bounce (48 B per entry and bounce), renderSampleFixed -- set aside HERE, not in the first frame
+        const bool split = splitShadowAccum(c, cap);
+        const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4)
+            + (split ? (uint64_t)cap * 48 * maxBounces(c) + (uint64_t)c->cfg.width * c->cfg.height * sizeof(float4) : 0);
         size_t freeB = 0, totalB = 0;
         HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
         if (need > (uint64_t)freeB)
@@ -817,6 +835,18 @@ int ensureQueues(pt_ctx* c)
         int rc = resetStreams(c);
         if (rc)
             return rc;
+    }
+    if (splitShadowAccum(c, cap)) { // (a first-frame stall otherwise: thirteen hipMallocs inside the first pt_render)
+        const size_t npx = (size_t)c->cfg.width * c->cfg.height;
+        if (!c->accumShadow.p) {
+            HIPCHK(c, c->accumShadow.alloc(npx));
+            HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, npx * sizeof(float4), c->stream));
+        }
+        for (uint32_t b = 0; b < maxBounces(c); b++) {
+            HIPCHK(c, c->shadowQ[b].o.alloc(cap));
+            HIPCHK(c, c->shadowQ[b].d.alloc(cap));
+            HIPCHK(c, c->shadowQ[b].c.alloc(cap));
+        }
     }
     HIPCHK(c, c->control.alloc(1));
     HIPCHK(c, hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
@@ -997,9 +1027,6 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
         first, n, slotBase, c->streams.p, &ctl->extCount[pass], &ctl->generated);
 }
 
-#ifndef PT_SPLIT_SHADOW_ACCUM
-#define PT_SPLIT_SHADOW_ACCUM 1 // one sample in flight: shadow rays deposit into an accumulator of their own, a shadow queue per bounce (renderSampleFixed)
-#endif
 #ifndef PT_FRAME_BUNDLES
 #define PT_FRAME_BUNDLES 0 // 1: the camera rays of a 1-spp frame (pinhole) as bundles of 256 neighbouring pixels through k_trace_multi.  Measured (1280 x 720,
                            // one bundle per wave): 1.39 instead of 1.02 ms per frame -- 3 600 walks of a 32 x 8-pixel beam, each a chain of > 100 dependent leaf visits
@@ -1232,19 +1259,10 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // for the shadow rays of bounce b (same words, same order as the serial schedule) -- and the shadow passes, the longer ones, were the frame's critical path.
     // There the shadow rays get an accumulator of their own (added to the other at the end of pt_render, in either schedule: the images stay bit-identical
     // between them) and a queue per bounce: a shadow pass then waits for its own shade launch only.
-    const bool split = PT_SPLIT_SHADOW_ACCUM && c->planes == 1u && entries <= (4u << 20) && !(c->packetUse & 2u) && bounces <= (uint32_t)kMaxPasses;
-    if (split) {
-        const size_t npx = (size_t)c->cfg.width * c->cfg.height;
-        if (!c->accumShadow.p) {
-            HIPCHK(c, c->accumShadow.alloc(npx));
-            HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, npx * sizeof(float4), c->stream));
-        }
-        for (uint32_t b = 0; b < bounces; b++)
-            if (!c->shadowQ[b].o.p) {
-                HIPCHK(c, c->shadowQ[b].o.alloc(c->capacity));
-                HIPCHK(c, c->shadowQ[b].d.alloc(c->capacity));
-                HIPCHK(c, c->shadowQ[b].c.alloc(c->capacity));
-            }
+    const bool split = splitShadowAccum(c, c->capacity);
+    if (split) { // (its buffers were set aside with the queues: ensureQueues)
+        if (!c->accumShadow.p || !c->shadowQ[bounces - 1].o.p)
+            return fail(c, PT_ERR_STATE, "the buffers of the one-sample-in-flight schedule are missing");
         c->mergePending = true;
     }
     // Shared descent (pt_descend.h) for the rays that leave the primary hits -- their shadow rays (pass 0) and the first bounce's extension rays
@@ -2647,7 +2665,15 @@ int pt_reduce_accum(pt_ctx* c, void* nccl_comm, int root)
     HIPCHK(c, hipSetDevice(c->device));
     float* buf = (float*)c->accum; // in place on the root (sendbuff == recvbuff is allowed there), send-only elsewhere
     const size_t count = (size_t)c->cfg.width * c->cfg.height * 4;
-    const int rc = reduce(buf, buf, count, /*ncclFloat*/ 7, /*ncclSum*/ 0, root, nccl_comm, c->stream);
+#ifdef PT_HAVE_RCCL_HEADER
+    constexpr int kFloat = (int)ncclFloat, kSum = (int)ncclSum;
+    static_assert(kFloat == 7 && kSum == 0, "the values this file falls back to where rccl.h is absent at build time");
+#else
+    constexpr int kFloat = 7, kSum = 0; // ncclFloat, ncclSum (rccl.h: ncclDataType_t / ncclRedOp_t)
+#endif
+    // (all four floats of every pixel travel, although w is unused: the accumulator is one contiguous float4 array and a strided reduce
+    // would be three collectives instead of one; 33 MB at 1080p is 0.2 ms on one xGMI link)
+    const int rc = reduce(buf, buf, count, kFloat, kSum, root, nccl_comm, c->stream);
     if (rc != 0)
         return fail(c, PT_ERR_HIP, "pt_reduce_accum: ncclReduce returned %d", rc);
     return PT_OK;

@@ -490,6 +490,10 @@ BvhStats checkBVH(const BvhBuildResult& bvh, const VertexSceneData* vertices, si
 {
     BvhStats s;
     std::vector<uint8_t> seen(numInputTriangles, 0);
+    // spatial splits: per input triangle the union of (leaf box x triangle box) over the leaves that reference it.  The clipped pieces add up
+    // to the triangle, so that union has the triangle's own extent; a leaf whose box was shrunk (a doctored cache file: found by
+    // tools/fuzz_loaders.py) leaves a side uncovered -- rays would pass the triangle there.
+    std::vector<AABB> cover(exactLeafContainment ? 0 : numInputTriangles), triBox(exactLeafContainment ? 0 : numInputTriangles);
     struct Item {
         uint32_t node, depth;
     };
@@ -519,10 +523,12 @@ BvhStats checkBVH(const BvhBuildResult& bvh, const VertexSceneData* vertices, si
                 if (exactLeafContainment) {
                     if (!box.contains(tb))
                         s.trianglesInsideLeaves = false;
-                } else { // spatial splits hold clipped references: the triangle must at least overlap the leaf
+                } else { // spatial splits hold clipped references: the triangle must at least overlap the leaf ...
                     AABB x = box.intersection(tb);
                     if (x.min.x > x.max.x + eps || x.min.y > x.max.y + eps || x.min.z > x.max.z + eps)
                         s.trianglesInsideLeaves = false;
+                    else // ... and the leaves that reference it must, between them, reach every side of its box (checked below)
+                        cover[bvh.originalTriangle[ti]].fit(x), triBox[bvh.originalTriangle[ti]] = tb;
                 }
             }
         } else {
@@ -537,6 +543,10 @@ BvhStats checkBVH(const BvhBuildResult& bvh, const VertexSceneData* vertices, si
     for (uint8_t f : seen)
         if (!f)
             s.allTrianglesReferenced = false;
+    for (size_t t = 0; t < cover.size(); t++)
+        if (seen[t] && !(cover[t].min.x <= triBox[t].min.x && cover[t].min.y <= triBox[t].min.y && cover[t].min.z <= triBox[t].min.z
+                         && cover[t].max.x >= triBox[t].max.x && cover[t].max.y >= triBox[t].max.y && cover[t].max.z >= triBox[t].max.z))
+            s.trianglesInsideLeaves = false;
     return s;
 }
 

@@ -1,6 +1,7 @@
 #include "image.h"
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -48,6 +49,16 @@ ImageRGBAF loadRadianceHDR(const std::string& path)
     if (std::sscanf(line.c_str(), "%c%c %ld %c%c %ld", &sy, &ay, &h, &sx, &ax, &w) != 6 || ay != 'Y' || ax != 'X' || h <= 0 || w <= 0 || h > 65535 || w > 65535)
         throw std::runtime_error(path + ": unsupported resolution line '" + line + "'");
     const bool topDown = sy == '-', leftToRight = sx == '+';
+    {   // the resolution line is untrusted: every scanline costs at least its 4-byte head and 2 bytes per run of <= 127 pixels and component
+        // (run-length form), or 4 bytes per pixel (flat form) -- a picture the file cannot hold is refused before 16 bytes per pixel are set aside
+        const std::streamoff here = in.tellg();
+        in.seekg(0, std::ios::end);
+        const uint64_t left = here < 0 ? 0 : (uint64_t)(in.tellg() - here);
+        in.seekg(here);
+        const uint64_t rowMin = (w >= 8 && w < 32768) ? std::min<uint64_t>(4 + 8 * (((uint64_t)w + 126) / 127), 4 * (uint64_t)w) : 4 * (uint64_t)w;
+        if ((uint64_t)h * rowMin > left)
+            throw std::runtime_error(path + ": truncated (the resolution line announces more scanlines than the file holds)");
+    }
     ImageRGBAF img;
     img.width = (uint32_t)w, img.height = (uint32_t)h;
     img.rgba.resize((size_t)w * h * 4);
@@ -281,6 +292,10 @@ ImageRGBA8 loadPNG(const std::string& path)
         if (w > passes[p][0] && h > passes[p][1])
             rawSize += (((size_t)pw * bitsPerPixel + 7) / 8 + 1) * ph;
     }
+    // deflate expands by a factor of 1032 at most: a header that implies more than the image data can inflate to is refused before
+    // anything is sized by it (a 100-byte file may announce 32 768 x 32 768 pixels: 8 GB of scanlines)
+    if (rawSize > idat.size() * 1032 + 1024)
+        throw std::runtime_error(path + ": PNG image data does not inflate to the size the header implies");
     std::vector<uint8_t> raw(rawSize);
     uLongf got = (uLongf)rawSize;
     if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != rawSize)

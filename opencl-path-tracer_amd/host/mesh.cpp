@@ -149,7 +149,9 @@ bool Mesh::loadBvh(const std::string& fileName)
             }
         }
     }
-    const BvhStats st = checkBVH(r, m_vertices.data(), m_inputTriangles.size(), false);
+    // an object-split tree holds whole triangles in its leaves; only a spatial-split tree may hold clipped references (checkBVH then asks
+    // that the leaves referencing a triangle cover it between them)
+    const BvhStats st = checkBVH(r, m_vertices.data(), m_inputTriangles.size(), m_builder != BvhBuilder::SpatialSplit);
     if (!st.childrenInsideParents || !st.trianglesInsideLeaves || !st.allTrianglesReferenced)
         return false;
     m_bvh = std::move(r);
@@ -418,43 +420,71 @@ std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& mat
     }
     if (vertexProps < 3)
         throw std::runtime_error("PLY: vertices need x y z");
+    if (vertexProps > 64)
+        throw std::runtime_error("PLY: more than 64 vertex properties");
+    // The counts of the header are untrusted: held against what the file can hold BEFORE anything is sized by them (a header that
+    // announces four billion vertices must cost an error message, not 48 GB and four billion reads of an exhausted stream -- found by
+    // tools/fuzz_loaders.py), and every read is checked: a truncated body is an error, not a mesh of zeros.
+    const std::streamoff bodyStart = in.tellg();
+    in.seekg(0, std::ios::end);
+    const uint64_t bodyBytes = bodyStart < 0 ? 0 : (uint64_t)(in.tellg() - bodyStart);
+    in.seekg(bodyStart);
+    const uint64_t minVertex = ascii ? 6 : (uint64_t)vertexProps * sizeof(float), minFace = ascii ? 8 : 1 + 3 * sizeof(int32_t); // "0 0 0\n", "3 0 0 0\n"
+    if (nv == 0 || nf == 0 || nv > bodyBytes / minVertex || nf > bodyBytes / minFace || nv * minVertex + nf * minFace > bodyBytes)
+        throw std::runtime_error("PLY: the header announces " + std::to_string(nv) + " vertices and " + std::to_string(nf) + " faces, the file holds "
+            + std::to_string(bodyBytes) + " bytes after it");
     std::vector<float> pos(nv * 3);
     std::vector<uint32_t> idx;
     idx.reserve(nf * 3);
     if (ascii) {
         for (size_t i = 0; i < nv; i++) {
-            std::getline(in, line);
+            if (!std::getline(in, line))
+                throw std::runtime_error("PLY: truncated vertex list");
             std::istringstream ls(line);
-            ls >> pos[3 * i] >> pos[3 * i + 1] >> pos[3 * i + 2];
+            if (!(ls >> pos[3 * i] >> pos[3 * i + 1] >> pos[3 * i + 2]))
+                throw std::runtime_error("PLY: bad vertex line");
         }
         for (size_t f = 0; f < nf; f++) {
-            std::getline(in, line);
+            if (!std::getline(in, line))
+                throw std::runtime_error("PLY: truncated face list");
             std::istringstream ls(line);
-            int n;
-            ls >> n;
-            std::vector<uint32_t> poly(n);
-            for (int k = 0; k < n; k++) ls >> poly[k];
-            for (int k = 1; k + 1 < n; k++) { // fan-triangulate
+            long n = 0;
+            if (!(ls >> n) || n < 3 || n > 255) // (the binary form counts a face's vertices in one byte)
+                throw std::runtime_error("PLY: a face needs 3 to 255 vertices");
+            std::vector<uint32_t> poly((size_t)n);
+            for (long k = 0; k < n; k++) {
+                long long v = -1;
+                if (!(ls >> v) || v < 0 || (uint64_t)v >= nv)
+                    throw std::runtime_error("PLY: bad vertex index in a face");
+                poly[(size_t)k] = (uint32_t)v;
+            }
+            for (long k = 1; k + 1 < n; k++) { // fan-triangulate
                 idx.push_back(poly[0]);
-                idx.push_back(poly[k]);
-                idx.push_back(poly[k + 1]);
+                idx.push_back(poly[(size_t)k]);
+                idx.push_back(poly[(size_t)k + 1]);
             }
         }
     } else { // all vertex properties assumed float32, faces uchar count + int32 indices
         std::vector<float> row(vertexProps);
         for (size_t i = 0; i < nv; i++) {
-            in.read((char*)row.data(), vertexProps * sizeof(float));
+            if (!in.read((char*)row.data(), vertexProps * sizeof(float)))
+                throw std::runtime_error("PLY: truncated vertex list");
             pos[3 * i] = row[0], pos[3 * i + 1] = row[1], pos[3 * i + 2] = row[2];
         }
         for (size_t f = 0; f < nf; f++) {
-            uint8_t n;
-            in.read((char*)&n, 1);
+            uint8_t n = 0;
+            if (!in.read((char*)&n, 1) || n < 3)
+                throw std::runtime_error("PLY: truncated face list (or a face of fewer than 3 vertices)");
             std::vector<int32_t> poly(n);
-            in.read((char*)poly.data(), n * sizeof(int32_t));
+            if (!in.read((char*)poly.data(), n * sizeof(int32_t)))
+                throw std::runtime_error("PLY: truncated face list");
+            for (int k = 0; k < n; k++)
+                if (poly[k] < 0 || (uint64_t)poly[k] >= nv)
+                    throw std::runtime_error("PLY: bad vertex index in a face");
             for (int k = 1; k + 1 < n; k++) {
-                idx.push_back(poly[0]);
-                idx.push_back(poly[k]);
-                idx.push_back(poly[k + 1]);
+                idx.push_back((uint32_t)poly[0]);
+                idx.push_back((uint32_t)poly[k]);
+                idx.push_back((uint32_t)poly[k + 1]);
             }
         }
     }

@@ -29,6 +29,31 @@ def build_host(force=False):
     return out
 
 
+# PTAMD_SANITIZE=1: the host library (the parsers of untrusted bytes: PNG / Radiance / OBJ / MTL / PLY / .bvh) and the oracle built with
+# AddressSanitizer + UndefinedBehaviorSanitizer next to the regular files (lib*_san.so); ptamd.host and oracle/orclib.py load those when
+# the variable is set.  CPU build only (the GPU pool refuses sanitizer runs).  Run python with the sanitizer runtime preloaded:
+#   PTAMD_SANITIZE=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_scene.py ...
+SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def sanitize():
+    return os.environ.get("PTAMD_SANITIZE", "") not in ("", "0")
+
+
+def build_sanitized(force=False):
+    out = os.path.join(HOST_DIR, "libptamd_host_san.so")
+    deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
+    if force or _newer(out, deps):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-fPIC", "-shared"] + SANITIZE_FLAGS + HOST_SOURCES + ["-o", out, "-lz"], cwd=HOST_DIR, check=True)
+    odir = os.path.abspath(os.path.join(ROOT, "..", "oracle"))
+    oout = os.path.join(odir, "liboracle_san.so")
+    osrc = [f for f in os.listdir(odir) if f.endswith(".cpp")]
+    if force or _newer(oout, _all_files(odir, (".cpp", ".h"))):
+        subprocess.run(["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"] + SANITIZE_FLAGS
+                       + osrc + ["-o", oout], cwd=odir, check=True)
+    return out, oout
+
+
 # Division and square root as v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded expansions (~10
 # instructions each): a quarter of k_shade's instructions were those expansions.  The reference builds its kernels
 # with -cl-fast-relaxed-math (raytracer.cpp:819); every parity test passes either way.
@@ -61,6 +86,8 @@ def build_raytracer(force=False):
 
 
 def build_all(force=False):
+    if sanitize():
+        build_sanitized(force)
     host, dev = build_host(force), build_device(force)
     build_raytracer(force)
     return host, dev

@@ -140,10 +140,11 @@ inline uint32_t lfsrNext(uint32_t g[4])
 }
 
 // jump one stream spacing ahead (clRNG src/lfsr113.c:183-240, lfsr113AdvanceState): the published
-// xor/shift network, signed-int arithmetic exactly as the library does it.
+// xor/shift network (in unsigned arithmetic: see below).
 inline void lfsrJump(uint32_t g[4])
 {
-    int z, b;
+    uint32_t z, b; // (the library computes in int: its left shifts overflow -- undefined in C++, found by UBSan; every right shift is masked down to
+                   // the bits a logical shift yields, so unsigned arithmetic gives the same words)
     z = g[0] & (uint32_t)(-2);
     b = (z << 6) ^ z;
     z = (z) ^ (z << 2) ^ (z << 3) ^ (z << 10) ^ (z << 13) ^ (z << 16) ^ (z << 19) ^ (z << 22) ^ (z << 25) ^ (z << 27) ^ (z << 28)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(_HERE, "..", "opencl-path-tracer_amd"))
 from ptamd import layout as L  # noqa: E402  (layout definitions only: plain numpy dtypes)
 
-ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+ORACLE_SO = os.path.join(_HERE, "liboracle_san.so" if os.environ.get("PTAMD_SANITIZE", "") not in ("", "0") else "liboracle.so")  # _san: ASan + UBSan build (ptamd/build.py)
 ORACLE_FAST_SO = os.path.join(_HERE, "liboracle_fast.so")
 REF_KERNELS_SO = os.path.join(_HERE, "_ref", "libref_kernels.so")
 REF_KERNELS_MIS_SO = os.path.join(_HERE, "_ref", "libref_kernels_mis.so")  # the same kernels built with -DCOMPARE_SHADING
