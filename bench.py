@@ -406,6 +406,47 @@ def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
                          "ms_until_adopted": round(float(np.median(stage["total"])), 3), "ms_until_adopted_min_max": [round(min(stage["total"]), 3), round(max(stage["total"]), 3)]}
         finally:
             ctx.close()
+    # the other branch of MeshSequence::buildBvh (src/model/mesh_sequence.cpp:81-97): a REBUILT tree per frame (fast binned builder, longest axis) --
+    # a new mesh, the scene flattened, pt_upload_static + pt_upload_dynamic (everything converted and uploaded again, the render stream synchronised)
+    try:
+        v, f = scenes.icosphere(5)
+        p0 = (v * 0.5).astype(np.float32)
+        f = f.astype(np.uint32)
+        mb = scenes._MeshBuilder()
+        mats = scenes._room_materials()
+        scenes._room(mb, mats)
+        room = mb.build(mats, H.BVH_BINNED_SAH)
+        cam = scenes.blob_room(W, Hh, level=2).camera
+        ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=1)
+        try:
+            build_ms, flatten_ms, upload_ms, total_ms = [], [], [], []
+            for k in range(6):
+                p = (p0 * (1.0 + 0.1 * np.sin(k + 1.0 + 5.0 * p0[:, :1]))).astype(np.float32)
+                t0 = time.perf_counter()
+                mesh = H.Mesh(p, f, [mat], builder=H.BVH_BINNED_FAST)
+                t1 = time.perf_counter()
+                scene = H.Scene()
+                scene.add_node(room)
+                scene.add_node(mesh, location=(0.0, 0.8, 0.1), scale=(1.2, 1.2, 1.2))
+                flat = scene.flatten()
+                t2 = time.perf_counter()
+                ctx.upload_scene(flat, sky=None)
+                t3 = time.perf_counter()
+                ctx.synchronize()
+                t4 = time.perf_counter()
+                if k == 0:
+                    ctx.set_camera(cam)
+                ctx.render(1)
+                if k >= 1:
+                    build_ms.append((t1 - t0) * 1e3), flatten_ms.append((t2 - t1) * 1e3), upload_ms.append((t3 - t2) * 1e3), total_ms.append((t4 - t0) * 1e3)
+            out["rebuild_20k"] = {"triangles": int(len(f)), "host_ms": {"mesh_build_fast_binned": round(float(np.median(build_ms)), 3), "flatten": round(float(np.median(flatten_ms)), 3),
+                                                                        "upload_static_and_dynamic": round(float(np.median(upload_ms)), 3)},
+                                  "ms_until_adopted": round(float(np.median(total_ms)), 3),
+                                  "what": "a rebuilt tree per frame: new Mesh (fast binned builder), flatten, pt_upload_static + pt_upload_dynamic, synchronise; 20 480 triangles"}
+        finally:
+            ctx.close()
+    except Exception as e:
+        out["rebuild_20k"] = {"error": str(e)[:200]}
     out["what"] = (f"medians over {ticks} ticks: Mesh::refit + Scene flatten (host library, through the Python binding: its array copies are in `flatten`) + pt_update_geometry + "
                    "pt_upload_dynamic_async (host time each), then pt_frame_tick + synchronise (ms_until_adopted = the whole tick)")
     out["reference_ms_per_frame"] = "4.12 - 6.25 (refit from a binned / SBVH tree + upload, 36.5 k-triangle helicopter, RX 480; lab report Table 2) -- 26.7 - 381.6 with a rebuilt tree"

@@ -1,8 +1,8 @@
 #!/bin/bash
-# here, after tools/final_profiles.sh ran on the GPU box: copy the evidence into profiles/round3/ under a tag: tools/collect_profiles.sh r3a
+# here, after tools/final_profiles.sh ran on the GPU box: copy the evidence into profiles/<round>/ under a tag: tools/collect_profiles.sh r4h [round4]
 set -e
 cd "$(dirname "$0")/.."
-tag=$1; dst=profiles/round3; mkdir -p $dst
+tag=$1; dst=profiles/${2:-round4}; mkdir -p $dst
 for pair in "final:$tag" "final_tl:${tag}_two_level"; do
   src=gpurun_out/${pair%%:*}; t=${pair##*:}
   [ -d $src ] || continue

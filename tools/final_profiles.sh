@@ -22,5 +22,5 @@ timeout -k 10 600 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/fi
 echo "bench done"
 run_set gpurun_out/final_tl --flags 2
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --no-secondary --flags 2 > gpurun_out/final_tl/bench.json 2> gpurun_out/final_tl/bench.log
-timeout -k 10 400 python tools/rank_emul.py 1 2 4 8 > gpurun_out/final/rank_emul.txt 2>&1 || true
+# (the rank-by-rank emulation of the N = 1 .. 8 jobs is a session of its own: tools/r4_session.sh)
 tail -c 1500 gpurun_out/final/bench.json

@@ -27,6 +27,9 @@ def table(name):
         # the production instantiations: k_shade one tile per workgroup (k_shade<false, false, true> is the tile-walking safety net), the
         # traversal kernels for scenes that are one world-space tree (<., true>: the ones that enter instances)
         for long, short in (("k_shade<false, false, false, false>", "k_shade<false>"), ("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
+                            ("k_trace<true, false, false>", "k_trace<true>"), ("k_trace<false, false, false>", "k_trace<false>"),  # round 4: a third parameter (DESCENT)
+                            ("k_trace<true, true, false>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,two-level>"),
+                            ("k_trace<false, true, false>", "k_trace<false>" if TWO_LEVEL_RUN else "k_trace<false,two-level>"),
                             ("k_trace<true, false>", "k_trace<true>"), ("k_trace<false, false>", "k_trace<false>"),
                             ("k_trace_packet<false, false>", "k_trace_packet<false>"),
                             ("k_trace_multi<4, false>", "k_trace_multi<4>"),
