@@ -2,11 +2,11 @@
 """Headline benchmark: Mrays/s of the ray-queue render path on the ~1M-triangle two-level-BVH scene at
 1080p (BASELINE.json metric), one process per GPU.
 
-A *step* is one pass of the hot path over one batch: `256*N*R` samples per pixel for the pixels this rank
-owns (N = ranks, R = --rounds, default 5: with the driver's 20 steps the timed region is ~12 s), i.e. R x [gen ->
-4 x (intersect, shade, shadow intersect)] over ~531 M path segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
-large batches matter (64 / 128 / 256 samples in flight: 7.8 / 8.1 / 8.3 Grays/s); 256 in flight keep ~100 GB of
-queues + accumulator planes resident, which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
+A *step* is one pass of the hot path over one batch: `512*N*R` samples per pixel for the pixels this rank
+owns (N = ranks, R = --rounds, default 3: with the driver's 20 steps the timed region is ~11 s), i.e. R x [gen ->
+4 x (intersect, shade, shadow intersect)] over ~1.06 G path segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
+large batches matter (64 / 128 / 256 samples in flight: 7.8 / 8.1 / 8.3 Grays/s in round 1; 256 / 512 / 768 on round 4's build, one box: 10 916 / 11 122 / 11 160
+Mrays/s); 512 in flight keep ~200 GB of queues + accumulator planes resident (round 1-3: 256, ~100 GB), which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
 shard across ranks, every rank traces the same number of paths per step whatever N is (weak scaling: the image
 simply receives N x more samples per step), and there is no data-path collective: the only exchange is ONE
 RCCL reduce of the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the
@@ -49,7 +49,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a de
 BYTES_PER_EXT_RAY = 48  # closest-hit intersect reads 28 B ray, writes 20 B hit record
 BYTES_PER_SHADOW_RAY = 44  # 28 B ray + 12 B contribution + 4 B pixel
 BYTES_PER_DEPOSIT = 24  # 12 B read + 12 B written per accumulator update (unoccluded shadow ray, emissive hit, sky miss)
-MAX_ENTRIES = 1920 * 1080 * 256  # path segments resident per rank (~100 GB of queues and planes): the 1080p job at any N; caps 4K
+IN_FLIGHT = 512  # samples in flight per pixel at 1080p on one rank (x N on 1/N of the pixels)
+MAX_ENTRIES = 1920 * 1080 * IN_FLIGHT  # path segments resident per rank (~200 GB of queues and planes): the 1080p job at any N; caps 4K
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
 
@@ -509,8 +510,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rounds", type=int, default=5, help="batches per step (5: the driver's 20 steps time ~12 s of rendering)")
-    ap.add_argument("--in-flight", type=int, default=256, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
+    ap.add_argument("--rounds", type=int, default=3, help="batches per step (3: the driver's 20 steps time ~11 s of rendering)")
+    ap.add_argument("--in-flight", type=int, default=IN_FLIGHT, help="samples in flight per pixel and per rank-share (batch = in_flight*N samples)")
     ap.add_argument("--max-entries", type=int, default=MAX_ENTRIES, help="path segments resident per rank (memory: ~190 B each)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

@@ -48,30 +48,34 @@ def test_full_size_properties(gpu, bundle):
 
 @pytest.mark.parametrize("flags_name", ["copied", "entered", "thin_lens"])
 def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_name):
-    """What bench.py times -- config 4 with 256 samples in flight: ONE 256-sample batch whose primary rays are generated and traced by
-    the bundle kernel (k_trace_multi: beam test, four rays per lane, no k_gen launch), 531 M queue entries -- held against the oracle directly: 4 096 sampled pixels at the
-    full 256 spp, at north_star's gate (mean bias < 1e-3, tone-mapped RMSE < 1e-3; measured 2e-5 / 2e-6, profiles/round4/parity_margins.json).  `entered`: the same with every
-    instance entered at traversal (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line; `thin_lens`: config 5's camera
-    (f/2 focused on the grid centre) -- the packets are converging bundles walked around their waist on the focal plane."""
+    """What bench.py times -- config 4 with bench.IN_FLIGHT (512 since round 4: ~200 GB of queues and planes) samples in flight: ONE batch whose primary
+    rays are generated and traced by the bundle kernel (k_trace_multi: beam test, four rays per lane, no k_gen launch), 1.06 G queue entries -- held against
+    the oracle directly: 4 096 sampled pixels at the full sample count, at north_star's gate (mean bias < 1e-3, tone-mapped RMSE < 1e-3; measured 2e-5 /
+    2e-6 at 256 in flight, profiles/round4/parity_margins.json).  `entered`: the same with every instance entered at traversal
+    (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line; `thin_lens`: config 5's camera (f/2 focused on the grid centre) -- the packets
+    are converging bundles walked around their waist on the focal plane."""
+    import bench
+    n = bench.IN_FLIGHT
     flags = gpu.FLAG_NO_BAKED_INSTANCES if flags_name == "entered" else 0
     if flags_name == "thin_lens":
         bundle = scenes.instanced_grid(W, H, level=6, thin_lens=True)
         assert bundle.camera["thinLensEnabled"]
-    ctx = U.make_ctx(gpu, bundle, W, H, seed=1, samples_in_flight=256, flags=flags)
-    ctx.render(256)
+    ctx = U.make_ctx(gpu, bundle, W, H, seed=1, samples_in_flight=n, flags=flags)
+    ctx.render(n)
     st = ctx.stats()
     assert st["packet_launches"] == 1 and st["gen_launches"] == 0, "the batch must take the path the benchmark times"
     assert st["bundle_launches"] == (0 if flags_name == "thin_lens" else 1)  # pinhole: bundles of 4 x 64 (k_trace_multi); thin lens: packets of 64
-    assert st["rays_generated"] == W * H * 256 and ctx.samples_per_pixel == 256
+    assert st["descent_launches"] == 0  # (the shared descent is opt-in)
+    assert st["rays_generated"] == W * H * n and ctx.samples_per_pixel == n
     a = ctx.read_accum()[:, :3]
     ctx.close()
     px = np.random.default_rng(4).choice(W * H, 4096, replace=False).astype(np.uint32)
-    ref, _ = O.render(U.oracle_scene(bundle), bundle.camera, W, H, 256, seed=1, pixels=px, threads=16)
+    ref, _ = O.render(U.oracle_scene(bundle), bundle.camera, W, H, n, seed=1, pixels=px, threads=16)
     got, want = a[px], ref[px, :3]
-    U.image_margins(f"config4 as timed (256 in flight), 256 spp, {flags_name}", got, want, 256, bundle.camera, 1e-3, 1e-3)
-    # path by path most pixels agree to round-off (a pixel holds 256 paths here; one fp32 decision flip per pixel is common)
+    U.image_margins(f"config4 as timed ({n} in flight), {n} spp, {flags_name}", got, want, n, bundle.camera, 1e-3, 1e-3)
+    # path by path most pixels agree to round-off (a pixel holds hundreds of paths here; one fp32 decision flip per pixel is common)
     close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * want.max()).all(axis=1)
-    assert close.mean() > 0.9, close.mean()
+    assert close.mean() > 0.85, close.mean()
 
 
 def test_config5_4k_thin_lens_properties(gpu):
