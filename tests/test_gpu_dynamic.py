@@ -218,3 +218,39 @@ def test_top_level_leaf_that_names_an_interior_node(gpu, flags_name):
     whole = O.intersect_batch(U.oracle_scene(b), o, d, threads=8)
     assert (want["prim"] != whole["prim"]).mean() > 0.005, "the modified instance must show less of its mesh"
     ctx.close()
+
+
+def test_refit_of_a_mesh_with_leaves_larger_than_a_device_leaf(gpu):
+    """100 coincident triangles make one 100-triangle leaf, which pt_upload_static splits into a small subtree of its own (device leaves hold
+    <= 30): those pair nodes mirror no node of the caller's, so a refit (pt_update_geometry) recomputes their boxes from the moved triangles.
+    After the refit the context must see what a fresh context sees on the same arrays."""
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (100, 1))
+    pos[:, 2] = np.repeat(np.arange(100) * 1e-4, 3)
+    mesh = H.Mesh(pos, np.arange(300, dtype=np.uint32).reshape(100, 3), [L.material_diffuse((1, 1, 1))], builder=H.BVH_BINNED_SAH)
+    sc = H.Scene()
+    sc.add_node(mesh)
+    flat = sc.flatten()
+    assert int(flat.sub_nodes["count"].max()) > 30
+    ctx = gpu.Context(8, 8)
+    ctx.upload_scene(flat)
+    rng = np.random.default_rng(3)
+    o = np.c_[rng.uniform(-0.5, 3.5, (4000, 2)), np.full(4000, -1.0)].astype(np.float32)
+    d = np.tile(np.array([[0, 0, 1]], np.float32), (4000, 1))
+    before = ctx.intersect(o, d)
+    moved = pos.copy()
+    moved[:, 0] = pos[:, 0] * 0.5 + 2.0  # the stack of triangles shrinks and slides to x in [2, 2.5]
+    mesh.refit(moved)
+    flat2 = sc.flatten()
+    ctx.update_geometry(flat2)
+    ctx.upload_dynamic(flat2)
+    got = ctx.intersect(o, d)
+    fresh = gpu.Context(8, 8)
+    fresh.upload_scene(flat2)
+    want = fresh.intersect(o, d)
+    for k in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got[k], want[k]), k
+    ref = O.intersect_batch(O.BoundScene(flat2), o, d)
+    assert np.array_equal(got["prim"] >= 0, ref["prim"] >= 0)
+    assert (got["prim"] >= 0).sum() > 50 and not np.array_equal(before["prim"] >= 0, got["prim"] >= 0)
+    ctx.close()
+    fresh.close()

@@ -457,3 +457,22 @@ def test_shared_descent_renders_like_the_per_ray_kernels_alone(gpu, instances):
     same = np.all(images[0] == images[1], axis=1)
     assert same.mean() > 0.999, f"{(~same).sum()} of {len(same)} pixels differ"
     assert np.allclose(images[0].mean(0), images[1].mean(0), rtol=1e-5)
+
+
+@pytest.mark.parametrize("in_flight", [48, 100])
+def test_batches_that_are_not_a_power_of_two(gpu, in_flight):
+    """pt_render cuts a batch at the largest multiple of the interleave it can hold (48 -> 32 + 16, 100 -> 64 + 32 + 4: up to 256 samples of a
+    pixel are queue neighbours only if the batch is a multiple of that power of two -- a batch of 2 046 once kept TWO together):
+    every sample is rendered exactly once, the coherent batches take the packet kernels, the image is the oracle's."""
+    W, Hh = 96, 54
+    b = scenes.instanced_grid(W, Hh, level=3, sky_size=(64, 32))
+    ctx = U.make_ctx(gpu, b, W, Hh, seed=3, samples_in_flight=in_flight)
+    ctx.render(in_flight)
+    st = ctx.stats()
+    assert st["rays_generated"] == W * Hh * in_flight and ctx.samples_per_pixel == in_flight
+    assert st["packet_launches"] == (2 if in_flight == 48 else 2)  # 32 + 16 / 64 + 32 (+ 4 through the per-ray kernel)
+    a = ctx.read_accum()[:, :3]
+    ref, cnt = O.render(U.oracle_scene(b), b.camera, W, Hh, in_flight, seed=3, threads=8)
+    assert st["rays_generated"] == cnt["raysGenerated"]
+    U.image_margins(f"ragged batch, {in_flight} in flight, 96x54", a, ref[:, :3], in_flight, b.camera, 1e-3, 1e-3)
+    ctx.close()
