@@ -356,8 +356,8 @@ def dynamic_update_times(D, H, L, scenes, bundle, W, Hh, device, ticks=12):
 def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
     """A deforming mesh per frame, the reference's way (src/model/mesh_sequence.cpp:81-97 + src/bvh/refit_bvh.cpp:6-34 on the host,
     transferDynamicData src/raytracer.cpp:510-568): per tick Mesh::refit (new vertex positions, smooth normals regenerated, boxes refitted
-    bottom-up -- host library), the scene flattened again, pt_update_geometry (pair-node boxes re-read, 4-wide nodes re-quantised on the
-    host; vertices + nodes through pinned staging; triangle records re-made by a device kernel), pt_upload_dynamic_async, pt_frame_tick
+    bottom-up -- host library), the scene flattened again, pt_update_geometry (the caller's vertices and nodes through pinned staging; packed nodes
+    re-quantised and triangle records re-made by two device kernels on the copy stream), pt_upload_dynamic_async, pt_frame_tick
     and a synchronisation.  Host ms per stage and ms until the new geometry is adopted; the mesh in the five-wall room, SBVH."""
     out = {}
     mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)

@@ -176,6 +176,57 @@ struct RefitArgs {
     TriFat* fat;
     uint32_t n;
 };
+// The caller's sub-BVH node record (pt_sub_bvh_node, include/ptamd.h: 48 bytes) as the device reads it
+struct SubNodeIn {
+    float mn[4], mx[4];
+    uint32_t left, count, _p0, _p1;
+};
+struct RefitNodeArgs {
+    const SubNodeIn* nodes; // the caller's refitted nodes, as handed in
+    const uint32_t* kidBoxNode; // [packed node][child]: the caller's node whose box this child slot takes; 0x80000000 | i: entry i of `extra`; ~0: unused slot
+    const float* extra; // boxes (lo.xyz, hi.xyz) of the pair nodes that split an oversized leaf: recomputed on the host (rare)
+    WideNode* wide; // in place: the child references stay, the planes are re-made
+    WideBoxes* boxes;
+    uint32_t emptyRef, n;
+};
+// one thread per packed 4-wide node: the gather and the re-quantisation pt_upload_static does on the host, from the same boxes with the
+// same routine (quantiseWideNode) -- a refitted context and a fresh one hold the same bytes
+__global__ void __launch_bounds__(128) k_refit_nodes(RefitNodeArgs a)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.n)
+        return;
+    const WideNode w = a.wide[q];
+    float lo[4][3], hi[4][3];
+    uint32_t refs[4];
+    bool empty[4];
+    WideBoxes bx;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t src = a.kidBoxNode[(size_t)q * 4 + k];
+        empty[k] = src == 0xFFFFFFFFu;
+        refs[k] = w.child[k];
+        for (int ax = 0; ax < 3; ax++)
+            lo[k][ax] = 1.f, hi[k][ax] = -1.f;
+        if (!empty[k]) {
+            if (src & 0x80000000u) {
+                const float* e = a.extra + (size_t)(src & 0x7FFFFFFFu) * 6;
+                for (int ax = 0; ax < 3; ax++)
+                    lo[k][ax] = e[ax], hi[k][ax] = e[3 + ax];
+            } else {
+                const SubNodeIn n = a.nodes[src];
+                for (int ax = 0; ax < 3; ax++)
+                    lo[k][ax] = n.mn[ax], hi[k][ax] = n.mx[ax];
+            }
+        }
+        for (int ax = 0; ax < 3; ax++)
+            bx.lo[k][ax] = lo[k][ax], bx.hi[k][ax] = hi[k][ax];
+    }
+    a.boxes[q] = bx;
+    WideNode out;
+    quantiseWideNode(lo, hi, refs, empty, a.emptyRef, &out);
+    a.wide[q] = out;
+}
+
 // one thread per triangle: the intersection record (v0, e1, e2: the very subtractions pt_upload_static does on the host, so that a refitted
 // context and a fresh one hold the same bits) and the 128-byte shading record, from the new vertices
 __global__ void __launch_bounds__(256) k_refit_tris(RefitArgs a)

@@ -123,6 +123,7 @@ struct pt_ctx {
         // slots are unused (the collapse's split choices and the packing order stay as they are)
         std::vector<uint32_t> kidSrc; // [node][child]: (pair node << 1) | side
         std::vector<uint8_t> kidEmpty; // [node][child]
+        std::vector<uint32_t> kidBoxNode; // [node][child]: the same as a caller's node index (k_refit_nodes, pt_bake.h), 0x80000000 | i: extra box i, ~0: unused
         std::vector<TriFat> fat;
         struct Root {
             uint32_t ref; // device reference of the mesh root (a packed node, or a leaf)
@@ -143,6 +144,10 @@ struct pt_ctx {
         // refit (pt_update_geometry): the caller's vertices on the device (the triangles' intersection and shading records are re-made
         // from them by k_refit_tris), pinned staging for them and for the re-quantised nodes, guarded by an event of its own
         DevBuf<pt_vertex> dVerts;
+        DevBuf<pt_sub_bvh_node> dNodes; // the caller's nodes as last handed in
+        DevBuf<uint32_t> dKidBoxNode;
+        DevBuf<float> dExtra;
+        bool latestInStage = false; // the caller's latest vertices and nodes live in `stage` (vertices first), not in rawVerts / hostSubNodes
         void* stage = nullptr;
         size_t stageBytes = 0;
         hipEvent_t stageRead = nullptr;
@@ -162,7 +167,8 @@ struct pt_ctx {
     bool mergePending = false;
     std::vector<VertexShade> hostVerts;
     std::vector<pt_vertex> rawVerts; // the caller's vertices as last handed in (pt_upload_static / pt_update_geometry)
-    bool hostGeomStale = false; // hostTris / hostVerts / sg.fat are older than rawVerts (a refit re-makes them on the device only)
+    bool hostGeomStale = false; // hostTris / hostVerts / hostBottomNodes' boxes / sg.wide / sg.boxes / sg.fat are older than the caller's latest arrays (a refit
+                                // re-makes the device's copies on the device only; the host's are refreshed if the whole conversion ever runs again)
     std::vector<uint32_t> denseOfNode; // caller's sub-BVH node -> pair node (0xFFFFFFFF: a leaf or a pad)
     uint32_t numDensePairs = 0; // pair nodes [0, numDensePairs) mirror the caller's inner nodes; the rest split leaves of more than kMaxLeafTris
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
@@ -551,12 +557,102 @@ bool invertTransform(const float* m, double w[4][8])
 // slots (half the footprint in the 4 MB-per-XCD L2, siblings share 128-byte lines) and a mesh's nodes are ONE contiguous run, which is
 // what a world-space copy of an instance (pt_bake.h) is made from.  Roots are the caller's nodes no other node refers to, plus any
 // node a top-level leaf has ever named (`extraRoots`).
-// hostTris / hostVerts from the caller's vertices as last handed in (a refit re-makes the device's records on the device and leaves these behind)
+// pair-node boxes of a refit: the caller's refitted boxes for the pairs that mirror its inner nodes (`onlyExtra`: skipped) and, for the pairs that
+// split a leaf of more than kMaxLeafTris triangles (appended children first), the bounds of their triangles
+void refitPairBoxes(pt_ctx* c, const pt_vertex* verts, const pt_sub_bvh_node* nodes, bool onlyExtra)
+{
+    std::vector<PairNode>& pair = c->hostBottomNodes;
+    if (!onlyExtra)
+        for (uint32_t i = 0; i < c->numRefNodes; i++) {
+            const uint32_t d = c->denseOfNode[i];
+            if (d == 0xFFFFFFFFu)
+                continue;
+            const uint32_t l = nodes[i].leftChildOrFirstTriangle;
+            const pt_sub_bvh_node &L = nodes[l], &R = nodes[l + 1];
+            pair[d].bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
+            pair[d].by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
+            pair[d].bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
+        }
+    if (pair.size() <= c->numDensePairs)
+        return;
+    auto boxOf = [&](uint32_t ref, V3& lo, V3& hi) {
+        lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
+        if (refCount(ref) != 0u) {
+            for (uint32_t t = refIndex(ref); t < refIndex(ref) + refCount(ref); t++) {
+                const TriShade& ts = c->hostTriShade[t];
+                for (uint32_t vi : { ts.i0, ts.i1, ts.i2 }) {
+                    const V3 p = mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]);
+                    lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
+                    hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+                }
+            }
+        } else {
+            const PairNode& n = pair[refIndex(ref)];
+            lo = mk(fminf(n.bx.x, n.bx.z), fminf(n.by.x, n.by.z), fminf(n.bz.x, n.bz.z));
+            hi = mk(fmaxf(n.bx.y, n.bx.w), fmaxf(n.by.y, n.by.w), fmaxf(n.bz.y, n.bz.w));
+        }
+    };
+    for (size_t j = c->numDensePairs; j < pair.size(); j++) {
+        V3 llo, lhi, rlo, rhi;
+        boxOf(pair[j].left, llo, lhi);
+        boxOf(pair[j].right, rlo, rhi);
+        pair[j].bx = make_float4(llo.x, lhi.x, rlo.x, rhi.x);
+        pair[j].by = make_float4(llo.y, lhi.y, rlo.y, rhi.y);
+        pair[j].bz = make_float4(llo.z, lhi.z, rlo.z, rhi.z);
+    }
+}
+
+// the packed 4-wide nodes of a refit on the host: same children in the same slots, new boxes (what k_refit_nodes does on the device)
+void refitWideOnHost(pt_ctx* c)
+{
+    pt_ctx::StaticGeom& g = c->sg;
+    const std::vector<PairNode>& pair = c->hostBottomNodes;
+    for (size_t q = 0; q < g.wide.size(); q++) {
+        float lo[4][3], hi[4][3];
+        uint32_t refs[4];
+        bool empty[4];
+        for (int k = 0; k < 4; k++) {
+            empty[k] = g.kidEmpty[q * 4 + k] != 0u;
+            refs[k] = g.wide[q].child[k];
+            if (empty[k]) {
+                for (int a = 0; a < 3; a++)
+                    lo[k][a] = 1.f, hi[k][a] = -1.f;
+                continue;
+            }
+            const uint32_t src = g.kidSrc[q * 4 + k];
+            const PairNode& n = pair[src >> 1];
+            const int side = (int)(src & 1u);
+            const float *bx = &n.bx.x, *by = &n.by.x, *bz = &n.bz.x;
+            lo[k][0] = bx[side * 2], hi[k][0] = bx[side * 2 + 1];
+            lo[k][1] = by[side * 2], hi[k][1] = by[side * 2 + 1];
+            lo[k][2] = bz[side * 2], hi[k][2] = bz[side * 2 + 1];
+        }
+        for (int k = 0; k < 4; k++)
+            for (int a = 0; a < 3; a++)
+                g.boxes[q].lo[k][a] = lo[k][a], g.boxes[q].hi[k][a] = hi[k][a];
+        quantiseWideNode(lo, hi, refs, empty, g.emptyRef, &g.wide[q]);
+    }
+}
+
+// the caller's latest vertices / nodes: in the pinned staging memory after a device-side refit, in the host vectors otherwise
+inline const pt_vertex* latestVerts(const pt_ctx* c) { return c->sg.latestInStage ? (const pt_vertex*)c->sg.stage : c->rawVerts.data(); }
+inline const pt_sub_bvh_node* latestNodes(const pt_ctx* c)
+{
+    return c->sg.latestInStage ? (const pt_sub_bvh_node*)((const unsigned char*)c->sg.stage + (size_t)c->numVerts * sizeof(pt_vertex)) : c->hostSubNodes.data();
+}
+
+// The host's mirrors from the caller's arrays as last handed in (a refit re-makes the device's records on the device and leaves these behind): pair-node
+// boxes, the packed nodes, hostTris / hostVerts.
 void refreshHostGeometry(pt_ctx* c)
 {
     if (!c->hostGeomStale)
         return;
-    const std::vector<pt_vertex>& verts = c->rawVerts;
+    const pt_vertex* verts = latestVerts(c);
+    if (c->sg.latestInStage) {
+        refitPairBoxes(c, verts, latestNodes(c), false);
+        if (c->sg.wide.size() == c->sg.kidEmpty.size() / 4)
+            refitWideOnHost(c);
+    }
     auto P = [&](uint32_t vi) { return mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]); };
     for (size_t t = 0; t < c->hostTriShade.size(); t++) {
         const TriShade& ts = c->hostTriShade[t];
@@ -566,9 +662,15 @@ void refreshHostGeometry(pt_ctx* c)
         c->hostTris[t].b = make_float4(e1.y, e1.z, e2.x, e2.y);
         c->hostTris[t].c = make_float4(e2.z, 0.f, 0.f, 0.f);
     }
-    for (size_t v = 0; v < verts.size(); v++) {
+    for (size_t v = 0; v < c->numVerts; v++) {
         c->hostVerts[v].n_u = make_float4(verts[v].normal[0], verts[v].normal[1], verts[v].normal[2], verts[v].texCoord[0]);
         c->hostVerts[v].v_pad = make_float4(verts[v].texCoord[1], 0.f, 0.f, 0.f);
+    }
+    if (c->sg.latestInStage) { // the host vectors take the latest arrays over (the staging memory is rewritten by the next refit)
+        c->rawVerts.assign(verts, verts + c->numVerts);
+        const pt_sub_bvh_node* nodes = latestNodes(c);
+        c->hostSubNodes.assign(nodes, nodes + c->numRefNodes);
+        c->sg.latestInStage = false;
     }
     c->hostGeomStale = false;
 }
@@ -615,7 +717,11 @@ int buildStaticGeom(pt_ctx* c)
     for (uint32_t i = 0; i < nN; i++)
         if (c->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
             rootNodes.push_back(i);
-    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear();
+    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear(), g.kidBoxNode.clear();
+    std::vector<uint32_t> pairLeft(c->numDensePairs, 0u); // pair node -> the caller's node that is its left child
+    for (uint32_t i = 0; i < nN; i++)
+        if (c->denseOfNode[i] != 0xFFFFFFFFu)
+            pairLeft[c->denseOfNode[i]] = c->hostSubNodes[i].leftChildOrFirstTriangle;
     g.rootOfNode.assign(nN, -1);
     constexpr uint32_t kUnset = 0xFFFFFFFFu;
     std::vector<uint32_t> newIndex(kids.size(), kUnset), order;
@@ -660,11 +766,16 @@ int buildStaticGeom(pt_ctx* c)
         g.leafOfs.resize(order.size() * 4, 0u);
         g.kidSrc.resize(order.size() * 4, 0u);
         g.kidEmpty.resize(order.size() * 4, 1u);
+        g.kidBoxNode.resize(order.size() * 4, 0xFFFFFFFFu);
         for (size_t q = root.nodeBase; q < order.size(); q++) {
             const WideKids& wk = kids[order[q]];
             uint32_t refs[4];
             for (int k = 0; k < 4; k++) {
                 g.kidSrc[q * 4 + k] = wk.src[k], g.kidEmpty[q * 4 + k] = wk.empty[k] ? 1u : 0u;
+                if (!wk.empty[k]) { // the caller's node whose box this slot takes: the left / right child of the node its pair mirrors
+                    const uint32_t pr = wk.src[k] >> 1, side = wk.src[k] & 1u;
+                    g.kidBoxNode[q * 4 + k] = pr < c->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->numDensePairs) * 2u + side));
+                }
                 refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
                 if (!wk.empty[k] && !isInner(wk.ref[k])) {
                     g.leafOfs[q * 4 + k] = (uint32_t)g.refTri.size() - root.refBase;
@@ -724,7 +835,8 @@ int uploadStaticGeom(pt_ctx* c)
     int rc;
     if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dBoxes, g.boxes)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs))
         || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat))
-        || (rc = uploadVec(c, g.dVerts, c->rawVerts)) || (rc = uploadVec(c, c->triShade, c->hostTriShade)))
+        || (rc = uploadVec(c, g.dVerts, c->rawVerts)) || (rc = uploadVec(c, c->triShade, c->hostTriShade))
+        || (rc = uploadVec(c, g.dNodes, c->hostSubNodes)) || (rc = uploadVec(c, g.dKidBoxNode, g.kidBoxNode)))
         return rc;
     g.onDevice = true;
     return PT_OK;
@@ -1555,7 +1667,7 @@ void pt_destroy(pt_ctx* c)
         if (d.lastUse) (void)hipEventDestroy(d.lastUse);
     }
     c->sg.dWide.release(), c->sg.dBoxes.release(), c->sg.dLeafOfs.release(), c->sg.dRefTri.release(), c->sg.dTris.release(), c->sg.dFat.release();
-    c->sg.dVerts.release(), c->triShade.release();
+    c->sg.dVerts.release(), c->triShade.release(), c->sg.dNodes.release(), c->sg.dKidBoxNode.release(), c->sg.dExtra.release();
     if (c->sg.stage) (void)hipHostFree(c->sg.stage);
     if (c->sg.stageRead) (void)hipEventDestroy(c->sg.stageRead);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
@@ -1736,6 +1848,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->hostBottomNodes = std::move(hNodes);
     c->rawVerts.assign(verts, verts + nV);
     c->hostGeomStale = false;
+    c->sg.latestInStage = false;
     c->denseOfNode = dense;
     c->numDensePairs = numInner;
     HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
@@ -1782,12 +1895,14 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
 //
 // A refit cannot change what the conversion of pt_upload_static decided -- which descendants of a binary node became the children of
 // its 4-wide node (the collapse's split choices), the breadth-first packing, the leaves' triangle references, the stack bound -- so all
-// of that is kept (pt_ctx::StaticGeom::kidSrc / kidEmpty / leafOfs / refTri / stackNeed) and only what moves is re-made: the boxes of
-// the pair nodes are re-read from the caller's nodes, every packed node is re-quantised from them (host: a gather and
-// quantiseWideNode per node), and the triangles' intersection and shading records are re-made ON THE DEVICE from the new vertices
-// (k_refit_tris, copy stream).  Vertices and nodes travel through pinned staging guarded by an event of its own: no stream is
-// synchronised.  (Round 3 re-ran the whole conversion here -- collapse, packing, 128 bytes of shading record per triangle on one host
-// thread -- and re-uploaded everything behind a synchronisation of the copy stream.)
+// of that is kept (pt_ctx::StaticGeom::kidSrc / kidBoxNode / kidEmpty / leafOfs / refTri / stackNeed) and only what moves is re-made, ON THE
+// DEVICE: the caller's vertex and node arrays travel as they are through pinned staging on the copy stream (an event of its own guards
+// the staging memory: no stream is synchronised), k_refit_nodes gathers every packed node's child boxes from the caller's nodes and
+// re-quantises it (quantiseWideNode: the host's routine), k_refit_tris re-makes the triangles' intersection and shading records.  The
+// host's half is the topology check and two copies into pinned memory; its own mirrors of the converted arrays go stale and are
+// refreshed from the staging memory only if the whole conversion ever runs again.  (Round 3 re-ran the whole conversion here --
+// collapse, packing, 128 bytes of shading record per triangle on one host thread -- and re-uploaded everything behind a
+// synchronisation of the copy stream.)
 int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_sub_bvh_node* nodes, uint32_t nN)
 {
     return guarded(c, "pt_update_geometry", [&]() -> int {
@@ -1802,81 +1917,34 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
                 return fail(c, PT_ERR_INVALID, "pt_update_geometry: node %u changed its links: a refit keeps the topology (use pt_upload_static for a rebuilt tree)", i);
         HIPCHK(c, hipSetDevice(c->device));
         pt_ctx::StaticGeom& g = c->sg;
-        std::vector<PairNode>& pair = c->hostBottomNodes;
-        // ---- pair-node boxes: the caller's refitted boxes for the pairs that mirror its inner nodes ...
-        for (uint32_t i = 0; i < nN; i++) {
-            const uint32_t d = c->denseOfNode[i];
-            if (d == 0xFFFFFFFFu)
-                continue;
-            const uint32_t l = nodes[i].leftChildOrFirstTriangle;
-            const pt_sub_bvh_node &L = nodes[l], &R = nodes[l + 1];
-            pair[d].bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
-            pair[d].by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
-            pair[d].bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
+        if (!g.onDevice) {
+            // nothing of the old geometry is on the device yet: everything on the host, the first upload takes it from the host arrays
+            refreshHostGeometry(c); // (an earlier device-side refit may have left the host mirrors behind)
+            refitPairBoxes(c, verts, nodes, false);
+            refitWideOnHost(c);
+            c->rawVerts.assign(verts, verts + nV);
+            c->hostSubNodes.assign(nodes, nodes + nN);
+            g.latestInStage = false;
+            c->hostGeomStale = true; // hostTris / hostVerts / sg.fat follow at the upload
+            g.version++;
+            return PT_OK;
         }
-        // ... and, for the pairs that split a leaf of more than kMaxLeafTris triangles (appended children first), the bounds of their triangles
-        if (pair.size() > c->numDensePairs) {
-            auto boxOf = [&](uint32_t ref, V3& lo, V3& hi) {
-                lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
-                if (refCount(ref) != 0u) {
-                    for (uint32_t t = refIndex(ref); t < refIndex(ref) + refCount(ref); t++) {
-                        const TriShade& ts = c->hostTriShade[t];
-                        for (uint32_t vi : { ts.i0, ts.i1, ts.i2 }) {
-                            const V3 p = mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]);
-                            lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
-                            hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
-                        }
-                    }
-                } else {
-                    const PairNode& n = pair[refIndex(ref)];
-                    lo = mk(fminf(n.bx.x, n.bx.z), fminf(n.by.x, n.by.z), fminf(n.bz.x, n.bz.z));
-                    hi = mk(fmaxf(n.bx.y, n.bx.w), fmaxf(n.by.y, n.by.w), fmaxf(n.bz.y, n.bz.w));
-                }
-            };
-            for (size_t j = c->numDensePairs; j < pair.size(); j++) {
-                V3 llo, lhi, rlo, rhi;
-                boxOf(pair[j].left, llo, lhi);
-                boxOf(pair[j].right, rlo, rhi);
-                pair[j].bx = make_float4(llo.x, lhi.x, rlo.x, rhi.x);
-                pair[j].by = make_float4(llo.y, lhi.y, rlo.y, rhi.y);
-                pair[j].bz = make_float4(llo.z, lhi.z, rlo.z, rhi.z);
-            }
-        }
-        // ---- the packed 4-wide nodes: same children in the same slots, new boxes
-        for (size_t q = 0; q < g.wide.size(); q++) {
-            float lo[4][3], hi[4][3];
-            uint32_t refs[4];
-            bool empty[4];
-            for (int k = 0; k < 4; k++) {
-                empty[k] = g.kidEmpty[q * 4 + k] != 0u;
-                refs[k] = g.wide[q].child[k];
-                if (empty[k]) {
-                    for (int a = 0; a < 3; a++)
-                        lo[k][a] = 1.f, hi[k][a] = -1.f;
-                    continue;
-                }
-                const uint32_t src = g.kidSrc[q * 4 + k];
-                const PairNode& n = pair[src >> 1];
-                const int side = (int)(src & 1u);
-                const float *bx = &n.bx.x, *by = &n.by.x, *bz = &n.bz.x;
-                lo[k][0] = bx[side * 2], hi[k][0] = bx[side * 2 + 1];
-                lo[k][1] = by[side * 2], hi[k][1] = by[side * 2 + 1];
-                lo[k][2] = bz[side * 2], hi[k][2] = bz[side * 2 + 1];
-            }
-            for (int k = 0; k < 4; k++)
-                for (int a = 0; a < 3; a++)
-                    g.boxes[q].lo[k][a] = lo[k][a], g.boxes[q].hi[k][a] = hi[k][a];
-            quantiseWideNode(lo, hi, refs, empty, g.emptyRef, &g.wide[q]);
-        }
-        c->rawVerts.assign(verts, verts + nV);
-        c->hostGeomStale = true; // hostTris / hostVerts / sg.fat are re-made only if the whole conversion ever runs again
-        g.version++;
-        if (!g.onDevice)
-            return PT_OK; // nothing of the old geometry is on the device yet: the first upload takes everything from the host arrays
-        // ---- the device's master copy: vertices and nodes through pinned staging on the copy stream, triangles re-made there
+        // ---- the device's master copy: the caller's vertices and nodes AS THEY ARE through pinned staging on the copy stream; the packed nodes
+        // re-quantised (k_refit_nodes) and the triangle records re-made (k_refit_tris) there.  The staging memory doubles as the host's copy of the
+        // caller's latest arrays (refreshHostGeometry reads it if the whole conversion ever runs again).
         static_assert(sizeof(VertexIn) == sizeof(pt_vertex), "k_refit_tris reads the caller's vertex records as they are");
-        const size_t bytesV = (size_t)nV * sizeof(pt_vertex), bytesW = g.wide.size() * sizeof(WideNode), bytesB = g.boxes.size() * sizeof(WideBoxes);
-        const size_t total = bytesV + bytesW + bytesB;
+        static_assert(sizeof(SubNodeIn) == sizeof(pt_sub_bvh_node), "k_refit_nodes reads the caller's node records as they are");
+        std::vector<float> extra; // boxes of the pair nodes that split an oversized leaf (rare): recomputed here
+        if (c->hostBottomNodes.size() > c->numDensePairs) {
+            refitPairBoxes(c, verts, nodes, true);
+            for (size_t j = c->numDensePairs; j < c->hostBottomNodes.size(); j++) {
+                const PairNode& n = c->hostBottomNodes[j];
+                const float b[12] = { n.bx.x, n.by.x, n.bz.x, n.bx.y, n.by.y, n.bz.y, n.bx.z, n.by.z, n.bz.z, n.bx.w, n.by.w, n.bz.w };
+                extra.insert(extra.end(), b, b + 12);
+            }
+        }
+        const size_t bytesV = (size_t)nV * sizeof(pt_vertex), bytesN = (size_t)nN * sizeof(pt_sub_bvh_node), bytesE = extra.size() * sizeof(float);
+        const size_t total = bytesV + bytesN + bytesE;
         if (!g.stageRead)
             HIPCHK(c, hipEventCreateWithFlags(&g.stageRead, hipEventDisableTiming));
         if (g.stageBusy) { // the previous refit's copies out of the staging memory (normally long done)
@@ -1884,6 +1952,8 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
             g.stageBusy = false;
         }
         if (g.stageBytes < total) {
+            if (g.latestInStage)
+                refreshHostGeometry(c); // (the staging memory holds the host's only copy of the latest arrays: take it over before it goes)
             if (g.stage)
                 (void)hipHostFree(g.stage);
             g.stage = nullptr;
@@ -1892,15 +1962,26 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
         }
         unsigned char* st = (unsigned char*)g.stage;
         std::memcpy(st, verts, bytesV);
+        std::memcpy(st + bytesV, nodes, bytesN);
+        g.latestInStage = true;
+        c->hostGeomStale = true;
+        g.version++;
         HIPCHK(c, hipMemcpyAsync(g.dVerts.p, st, bytesV, hipMemcpyHostToDevice, c->copyStream));
-        if (bytesW) {
-            std::memcpy(st + bytesV, g.wide.data(), bytesW);
-            std::memcpy(st + bytesV + bytesW, g.boxes.data(), bytesB);
-            HIPCHK(c, hipMemcpyAsync(g.dWide.p, st + bytesV, bytesW, hipMemcpyHostToDevice, c->copyStream));
-            HIPCHK(c, hipMemcpyAsync(g.dBoxes.p, st + bytesV + bytesW, bytesB, hipMemcpyHostToDevice, c->copyStream));
+        HIPCHK(c, hipMemcpyAsync(g.dNodes.p, st + bytesV, bytesN, hipMemcpyHostToDevice, c->copyStream));
+        if (bytesE) {
+            std::memcpy(st + bytesV + bytesN, extra.data(), bytesE);
+            if (g.dExtra.n < extra.size())
+                HIPCHK(c, g.dExtra.alloc(extra.size()));
+            HIPCHK(c, hipMemcpyAsync(g.dExtra.p, st + bytesV + bytesN, bytesE, hipMemcpyHostToDevice, c->copyStream));
         }
         HIPCHK(c, hipEventRecord(g.stageRead, c->copyStream));
         g.stageBusy = true;
+        if (!g.wide.empty()) {
+            RefitNodeArgs rn {};
+            rn.nodes = (const SubNodeIn*)g.dNodes.p, rn.kidBoxNode = g.dKidBoxNode.p, rn.extra = g.dExtra.p, rn.wide = g.dWide.p, rn.boxes = g.dBoxes.p;
+            rn.emptyRef = g.emptyRef, rn.n = (uint32_t)g.wide.size();
+            hipLaunchKernelGGL(k_refit_nodes, dim3((rn.n + 127u) / 128u), dim3(128), 0, c->copyStream, rn);
+        }
         RefitArgs ra {};
         ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->triShade.p, ra.mats = c->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->numTris;
         hipLaunchKernelGGL(k_refit_tris, dim3((c->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);

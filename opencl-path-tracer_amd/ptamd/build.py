@@ -82,6 +82,10 @@ def build_raytracer(force=False):
     if force or _newer(exe, [os.path.join(ex_dir, "render_cornell.cpp"), out]):
         subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "render_cornell.cpp", "-o", "render_cornell", "-L" + HOST_DIR, "-lptamd_raytracer",
                         "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
+    exe2 = os.path.join(ex_dir, "deform_loop")
+    if force or _newer(exe2, [os.path.join(ex_dir, "deform_loop.cpp"), out]):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "deform_loop.cpp", "-o", "deform_loop", "-L" + HOST_DIR, "-lptamd_raytracer",
+                        "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
     return out, exe
 
 
