@@ -254,3 +254,85 @@ def test_refit_of_a_mesh_with_leaves_larger_than_a_device_leaf(gpu):
     assert (got["prim"] >= 0).sum() > 50 and not np.array_equal(before["prim"] >= 0, got["prim"] >= 0)
     ctx.close()
     fresh.close()
+
+
+def _deformed(p0, k):
+    ang = 0.7 * k * p0[:, 1]
+    return np.stack([np.cos(ang) * p0[:, 0] - np.sin(ang) * p0[:, 2], (1 - 0.15 * k) * p0[:, 1], np.sin(ang) * p0[:, 0] + np.cos(ang) * p0[:, 2]], 1).astype(np.float32)
+
+
+def test_refit_before_the_first_dynamic_upload_and_rebuild_after_a_refit(gpu):
+    """The two corners of pt_update_geometry's bookkeeping.  (1) A refit BEFORE anything of the scene is on the device (pt_upload_static, then
+    pt_update_geometry, then the first pt_upload_dynamic): everything is refitted on the host and uploaded once.  (2) A refit on the device
+    (k_refit_nodes / k_refit_tris: the host's mirrors of the converted arrays go stale), then a state whose top-level leaf names an interior
+    node, which makes the whole conversion run again -- from the caller's LATEST arrays, which live in the refit's staging memory.  Either way
+    the context must hold what a fresh context holds that only ever saw the final arrays."""
+    mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
+    v, f = scenes.icosphere(3)
+    p0 = (v * 0.5).astype(np.float32)
+    blob = H.Mesh(p0, f.astype(np.uint32), [mat], builder=H.BVH_SPATIAL_SPLIT)
+    scene = H.Scene()
+    mb = scenes._MeshBuilder()
+    mats = scenes._room_materials()
+    scenes._room(mb, mats)
+    scene.add_node(mb.build(mats, H.BVH_BINNED_SAH))
+    scene.add_node(blob, location=(0.0, 0.8, 0.1), scale=(1.2, 1.2, 1.2))
+    flat0 = scene.flatten()
+    cam = scenes.blob_room(W, Hh, level=3).camera
+    o, d = U.random_rays(20000, 4, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
+
+    def fresh_hits(flat):
+        c = U.make_ctx(gpu, flat, W, Hh, camera=cam, seed=8)
+        h = c.intersect(o, d)
+        c.render(8)
+        a = c.read_accum().copy()
+        c.close()
+        return h, a
+
+    # (1) refit before the first dynamic upload
+    ctx = gpu.Context(W, Hh, seed=8)
+    ctx._chk(gpu.lib().pt_upload_static(ctx._h, flat0.vertices.ctypes.data, len(flat0.vertices), flat0.triangles.ctypes.data, len(flat0.triangles),
+                                        flat0.materials.ctypes.data, len(flat0.materials), flat0.sub_nodes.ctypes.data, len(flat0.sub_nodes)), "pt_upload_static")
+    blob.refit(_deformed(p0, 1))
+    flat1 = scene.flatten()
+    ctx.update_geometry(flat1)
+    ctx.upload_dynamic(flat1)
+    ctx.set_camera(cam)
+    want_h, want_a = fresh_hits(flat1)
+    got_h = ctx.intersect(o, d)
+    for k in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got_h[k], want_h[k]), ("before the first upload", k)
+    ctx.render(8)
+    assert np.array_equal(ctx.read_accum(), want_a)
+    # (2) a device-side refit, then a rebuild of the static part from the latest arrays
+    blob.refit(_deformed(p0, 2))
+    flat2 = scene.flatten()
+    ctx.update_geometry(flat2)
+    ctx.upload_dynamic(flat2)
+    import copy
+    part = copy.copy(flat2)
+    part.top_nodes = flat2.top_nodes.copy()
+    leaves = [int(l) for l in np.flatnonzero(part.top_nodes["isLeaf"] != 0) if flat2.sub_nodes["count"][int(part.top_nodes["a"][l])] == 0]
+    leaf = max(leaves, key=lambda l: int(part.top_nodes["a"][l]))  # the blob's instance
+    part.top_nodes["a"][leaf] = int(flat2.sub_nodes["left"][int(part.top_nodes["a"][leaf])]) + 1  # its root's right child: an interior node
+    ctx.upload_dynamic(part)  # a new root: the conversion runs again
+    want_h, want_a = fresh_hits(part)
+    got_h = ctx.intersect(o, d)
+    for k in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got_h[k], want_h[k]), ("rebuild after a refit", k)
+    ctx.clear()
+    ctx.render(8)
+    assert np.array_equal(ctx.read_accum(), want_a)
+    # ... and refits keep working on the re-converted arrays
+    blob.refit(_deformed(p0, 3))
+    flat3 = scene.flatten()
+    part3 = copy.copy(flat3)
+    part3.top_nodes = flat3.top_nodes.copy()
+    part3.top_nodes["a"][leaf] = part.top_nodes["a"][leaf]
+    ctx.update_geometry(part3)
+    ctx.upload_dynamic(part3)
+    want_h, _ = fresh_hits(part3)
+    got_h = ctx.intersect(o, d)
+    for k in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got_h[k], want_h[k]), ("refit after the rebuild", k)
+    ctx.close()
