@@ -52,6 +52,7 @@ BYTES_PER_DEPOSIT = 24  # 12 B read + 12 B written per accumulator update (unocc
 IN_FLIGHT = 512  # samples in flight per pixel at 1080p on one rank (x N on 1/N of the pixels)
 MAX_ENTRIES = 1920 * 1080 * IN_FLIGHT  # path segments resident per rank (~200 GB of queues and planes): the 1080p job at any N; caps 4K
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
+BYTES_PER_QUEUE_ENTRY = 164  # resident per queue entry: two extension queues (2 x 48 B), the shadow queue (48 B), the hit record (20 B) -- ensureQueues' accounting
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
 
 
@@ -153,7 +154,7 @@ def cpu_baseline(bundle, seconds, width, height):
     except Exception as e:  # never let the secondary figure take the bench down
         ref = {"error": str(e)[:200]}
     value = rays / t_used / 1e6
-    return {"value": round(value, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(value, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "segments_mrays_per_s": [round(x, 3) for x in segments],
             "spread": round((max(segments) - min(segments)) / value, 4),
             "reference_kernels": ref,
@@ -177,6 +178,37 @@ def plan_in_flight(requested, world, owned_pixels, max_entries=MAX_ENTRIES):
     elif n >= 2:
         n = 1 << (n.bit_length() - 1)
     return n
+
+
+def resident_bytes(in_flight, owned_pixels):
+    """HBM the queues and the extra accumulator planes of one context keep resident (what ensureQueues, csrc/ptamd.hip, checks against hipMemGetInfo)."""
+    return owned_pixels * in_flight * BYTES_PER_QUEUE_ENTRY + max(in_flight - 1, 0) * owned_pixels * 16
+
+
+def shrink_in_flight(n):
+    """The next smaller batch the library keeps coherent: multiples of 256 down to 256, then powers of two."""
+    if n > 256:
+        return n - 256 if n % 256 == 0 else n - n % 256
+    return max(1, n // 2)
+
+
+def fit_in_flight(in_flight, owned_pixels, free_bytes, reserve=6 << 30):
+    """`in_flight`, lowered until its queues and planes fit what the device has free (another tenant on the card, a context that is not
+    freed yet, a part with less HBM): the bench line degrades by a percent or two (512 -> 256 in flight: -1.9 %) instead of failing.  `reserve`
+    covers the scene, the sky, the spill region and the accumulator."""
+    while in_flight > 1 and resident_bytes(in_flight, owned_pixels) + reserve > free_bytes:
+        in_flight = shrink_in_flight(in_flight)
+    return in_flight
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def reduce_accumulator(dist, accum, backend, world):
@@ -583,26 +615,56 @@ def main():
     flat = bundle.flat
     rects = tile_rects(W, Hh, rank, world) if world > 1 else []
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
-    in_flight = plan_in_flight(args.in_flight, world, owned, args.max_entries)
+    in_flight = planned = plan_in_flight(args.in_flight, world, owned, args.max_entries)
     if args.scaling == "strong":  # the job is `in_flight x rounds` samples per pixel: a rank cannot keep more of them in flight than that
-        in_flight = min(in_flight, args.in_flight * args.rounds)
-    if world > 1:  # every rank must use the same batch: the smallest share decides
-        t = torch.tensor([in_flight], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        in_flight = planned = min(in_flight, args.in_flight * args.rounds)
+    # ... and what the card has free right now decides (512 in flight want ~200 GB; a second tenant, a context not yet freed or a
+    # smaller part must cost a percent or two, not the line)
+    free_b, total_b = torch.cuda.mem_get_info(local_rank)
+    if args.share_gpu:
+        free_b //= world
+    in_flight = fit_in_flight(in_flight, owned, free_b)
+
+    def agree(value):  # every rank must use the same batch: the smallest share decides
+        if world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        in_flight = int(t.item())
+        return int(t.item())
+
+    in_flight = agree(in_flight)
     # torch owns the stream and the accumulator: everything below -- render kernels, the reduce, the statistics -- is enqueued
     # on ONE explicit stream.  (torch's default stream is the legacy null stream, whose handle is 0; pt_set_stream(NULL)
     # would mean "the library's own non-blocking stream", which the collective would NOT be ordered after.)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight, flags=args.flags)
-        ctx.set_stream(stream.cuda_stream)
-        ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
-        ctx.set_camera(bundle.camera)
-        if world > 1:
-            ctx.set_tiles(rects)
         accum = torch.zeros(W * Hh, 4, device="cuda", dtype=torch.float32)
-        ctx.set_accum_buffer(accum.data_ptr())
+        fallbacks = []
+        while True:
+            # the context, and ONE batch through it: the queues are set up at the first render, which is where an oversized configuration is refused
+            ctx, err = None, ""
+            try:
+                ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight, flags=args.flags)
+                ctx.set_stream(stream.cuda_stream)
+                ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
+                ctx.set_camera(bundle.camera)
+                if world > 1:
+                    ctx.set_tiles(rects)
+                ctx.set_accum_buffer(accum.data_ptr())
+                ctx.render(in_flight, sync=True)
+            except D.PtError as e:
+                err = str(e)
+                if ctx is not None:
+                    ctx.close()
+                ctx = None
+            if agree(1 if ctx is not None else 0):
+                break
+            if ctx is not None:  # another rank was refused: everybody starts over with the smaller batch
+                ctx.close()
+            if in_flight <= 1:
+                raise SystemExit(f"bench.py: no batch size fits this device: {err}")
+            fallbacks.append({"samples_in_flight": in_flight, "refused": err[-240:]})
+            in_flight = agree(shrink_in_flight(in_flight))
         spp_step = in_flight * args.rounds if args.scaling == "weak" else args.in_flight * args.rounds
 
         def barrier():
@@ -614,6 +676,7 @@ def main():
         for _ in range(args.warmup):
             ctx.render(spp_step, sync=False)
         barrier()
+        free_after, _ = torch.cuda.mem_get_info(local_rank)
         ctx.clear()
         ctx.reset_stats()
         barrier()
@@ -675,6 +738,9 @@ def main():
                                "object times the same scene with the instances entered instead)"),
                 "scene_flags": args.flags,
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
+                "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
+                "resident_gb": round(resident_bytes(in_flight, owned) / 1e9, 1),  # queues + accumulator planes of this rank (164 B per entry, 16 B per plane and pixel)
+                "device_memory_gb": {"total": round(total_b / 1e9, 1), "free_before": round(free_b / 1e9, 1), "free_while_rendering": round(free_after / 1e9, 1)},
                 "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
                 "pixels_per_rank": owned, "paths_per_step_per_rank": owned * spp_step,
                 "collective": "none" if world == 1 else f"1 x reduce(SUM) of the HDR accumulator ({args.backend}) per job, inside the timed region",

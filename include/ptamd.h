@@ -131,6 +131,8 @@ typedef struct {
     uint32_t flags; /* PT_FLAG_* */
     uint32_t samples_in_flight; /* samples of one pixel traced concurrently, each into its own accumulator
                                    plane (folded at the end of pt_render); 0 = auto (~32M path segments per launch), max 4096.
+                                   Rounded DOWN to a multiple of 256, below 256 to a power of two (only such batches keep
+                                   the samples of a pixel next to each other in the queues).
                                    Only with max_active_rays == 0 and PT_RNG_COUNTER. */
 } pt_config;
 

@@ -82,7 +82,9 @@ int pth_scene_set_transform(pth_scene* s, int node, const float location[3], con
 int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts);
 /* The per-tick half alone -- lights and top-level BVH from the scene graph as it stands (flattenDynamic: what RayTracer::frameTick does
  * on the host before pt_upload_dynamic_async; reference transferDynamicData, src/raytracer.cpp:497-509,569-595); the static arrays of the
- * last pth_scene_flatten stay as they are.  Copy out with pth_scene_copy (NULL for the arrays that are not wanted). */
+ * last pth_scene_flatten stay as they are.  Copy out with pth_scene_copy (NULL for the arrays that are not wanted).
+ * Fails (-1) when a node was added or a mesh of the scene was refitted (pth_mesh_refit) since that pth_scene_flatten: the static arrays
+ * are then stale, and lights / top-level boxes made from the new mesh would not belong to them -- call pth_scene_flatten again. */
 int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts);
 int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top);
 

@@ -878,6 +878,17 @@ int ensureQueues(pt_ctx* c)
         if (want == 0) // auto: keep ~32M path segments per launch (the latency-bound tail of every launch is then a few % of it)
             want = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (32u << 20) / std::max(c->numOwned, 1u)));
         c->planes = std::min(want, 4096u);
+        // a multiple of kGenInterleave, or the power of two below: only such batches keep the samples of a pixel together in the queue, and pt_render
+        // cuts every batch that way -- planes (and queue entries) beyond it would be budgeted, allocated and never used (auto at 1280 x 720 gave 36:
+        // pt_render(72) ran as 32 + 32 + 8)
+        if (c->planes >= kGenInterleave) {
+            c->planes -= c->planes % kGenInterleave;
+        } else {
+            uint32_t p2 = 1;
+            while (p2 * 2u <= c->planes)
+                p2 *= 2u;
+            c->planes = p2;
+        }
     }
     uint64_t cap64 = c->cfg.max_active_rays ? c->cfg.max_active_rays : (uint64_t)c->numOwned * c->planes;
     if (cap64 > 0x7FFFFFC0ull)

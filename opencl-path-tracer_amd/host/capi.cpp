@@ -24,6 +24,14 @@ struct SceneHandle {
     FlattenedScene flat;
     bool flattened = false; // `flat` is current
     bool staticFlattened = false; // its static arrays are (a moved node leaves them valid; a new node does not)
+    std::vector<uint64_t> meshGenerations; // IMesh::generation() of every mesh when the static arrays were made (a refit leaves them stale)
+    std::vector<uint64_t> generationsNow() const
+    {
+        std::vector<uint64_t> g;
+        for (const MeshBvhPair& p : scene.getMeshes())
+            g.push_back(p.meshPtr->generation());
+        return g;
+    }
 };
 
 template <typename F>
@@ -291,6 +299,7 @@ int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts)
         SceneHandle& h = *(SceneHandle*)s;
         h.flat = flattenScene(h.scene);
         h.flattened = h.staticFlattened = true;
+        h.meshGenerations = h.generationsNow();
         counts->num_vertices = (uint32_t)h.flat.vertices.size();
         counts->num_triangles = (uint32_t)h.flat.triangles.size();
         counts->num_materials = (uint32_t)h.flat.materials.size();
@@ -308,6 +317,9 @@ int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts)
         SceneHandle& h = *(SceneHandle*)s;
         if (!h.staticFlattened)
             throw std::logic_error("pth_scene_flatten_dynamic: call pth_scene_flatten first (and again after adding nodes)");
+        if (h.meshGenerations != h.generationsNow()) // (the lights and the top-level boxes below would follow the new mesh, the vertices and sub-BVH boxes not)
+            throw std::logic_error("pth_scene_flatten_dynamic: a mesh of the scene was refitted since pth_scene_flatten: its vertices and sub-BVH boxes in the "
+                                   "static arrays are stale -- call pth_scene_flatten again");
         flattenDynamic(h.scene, h.flat);
         h.flattened = true;
         counts->num_vertices = (uint32_t)h.flat.vertices.size();

@@ -150,7 +150,8 @@ bool Mesh::loadBvh(const std::string& fileName)
         }
     }
     // an object-split tree holds whole triangles in its leaves; only a spatial-split tree may hold clipped references (checkBVH then asks
-    // that the leaves referencing a triangle cover it between them)
+    // that the leaves referencing a triangle cover its EXTENT between them -- a heuristic, necessary but not sufficient: a doctored file that
+    // shrinks an interior clipped piece leaves a hole the extents do not show; a cache that must be trusted needs a content hash)
     const BvhStats st = checkBVH(r, m_vertices.data(), m_inputTriangles.size(), m_builder != BvhBuilder::SpatialSplit);
     if (!st.childrenInsideParents || !st.trianglesInsideLeaves || !st.allTrianglesReferenced)
         return false;
@@ -383,6 +384,7 @@ void Mesh::refit(const float* positions, const float* normals)
         generateSmoothNormals();
     refitBVH(m_bvh.nodes, m_bvh.rootNode, m_bvh.triangles, m_vertices);
     m_bvhFromCache = false;
+    m_generation++;
 }
 
 std::shared_ptr<Mesh> Mesh::fromPLY(const std::string& path, const Material& material, BvhBuilder builder)

@@ -29,6 +29,8 @@ public:
     virtual uint32_t maxNumBvhNodes() const = 0;
     virtual void buildBvh() = 0;
     virtual uint32_t getBvhRootNode() const = 0;
+    // bumped whenever the arrays above change (a refit, a rebuild): what a flattened copy of them is held against
+    virtual uint64_t generation() const { return 0; }
 };
 
 class Mesh : public IMesh {
@@ -80,6 +82,7 @@ public:
     const BvhBuildResult& getBvh() const { return m_bvh; }
     size_t numInputTriangles() const { return m_inputTriangles.size(); }
     BvhBuilder builder() const { return m_builder; }
+    uint64_t generation() const override { return m_generation; }
 
 private:
     void generateSmoothNormals();
@@ -91,6 +94,7 @@ private:
     AABB m_bounds;
     BvhBuilder m_builder;
     bool m_bvhFromCache = false;
+    uint64_t m_generation = 0;
 };
 
 } // namespace raytracer

@@ -89,7 +89,13 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
             uint32_t first, count;
         };
         std::vector<uint32_t> order = active;
-        std::function<uint32_t(Range)> build = [&](Range r) -> uint32_t {
+        // A SAH split that peels one box off per level (geometrically spaced instances) makes a tree as deep as the instance count, which the
+        // device library then refuses for its traversal stack -- a balanced tree over the same boxes would do.  Lop-sided splits (fewer than an
+        // eighth on one side) are only taken while the depth stays within 2 log2(n); beyond that the median decides.
+        uint32_t depthBudget = 2;
+        for (size_t n = order.size(); n > 1; n >>= 1)
+            depthBudget += 2;
+        std::function<uint32_t(Range, uint32_t)> build = [&](Range r, uint32_t depth) -> uint32_t {
             if (r.count == 1)
                 return order[r.first];
             AABB cb, nb;
@@ -137,6 +143,8 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
                     auto it = std::partition(order.begin() + r.first, order.begin() + r.first + r.count, [&](uint32_t node) { return binOf(node) <= bestBin; });
                     mid = (uint32_t)(it - (order.begin() + r.first));
                     split = mid > 0 && mid < r.count;
+                    if (split && depth > depthBudget / 2 && std::min(mid, r.count - mid) < r.count / 8)
+                        split = false; // deep already, and this split makes little progress: the median instead
                 }
             }
             if (!split) { // all centroids in one place (or a handful of boxes): the median along the axis
@@ -144,7 +152,7 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
                 std::nth_element(order.begin() + r.first, order.begin() + r.first + mid, order.begin() + r.first + r.count,
                     [&](uint32_t x, uint32_t y) { return comp(getBox(out.nodes[x]).center()) < comp(getBox(out.nodes[y]).center()); });
             }
-            const uint32_t l = build({ r.first, mid }), rr = build({ r.first + mid, r.count - mid });
+            const uint32_t l = build({ r.first, mid }, depth + 1), rr = build({ r.first + mid, r.count - mid }, depth + 1);
             TopBVHNode inner;
             std::memset(&inner, 0, sizeof(inner));
             setBox(inner, nb);
@@ -156,7 +164,7 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
             out.nodes.push_back(inner);
             return (uint32_t)out.nodes.size() - 1;
         };
-        out.rootNode = build({ 0, (uint32_t)order.size() });
+        out.rootNode = build({ 0, (uint32_t)order.size() }, 0);
         return out;
     }
 

@@ -55,7 +55,12 @@ def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_
     (PT_FLAG_NO_BAKED_INSTANCES), the `two_level` object of the bench line; `thin_lens`: config 5's camera (f/2 focused on the grid centre) -- the packets
     are converging bundles walked around their waist on the focal plane."""
     import bench
-    n = bench.IN_FLIGHT
+    import torch
+    # bench.IN_FLIGHT where the card has the ~200 GB free that it wants; otherwise the largest multiple of 256 that fits, as bench.py itself falls
+    # back (the note goes on the record with the margins: a box with another tenant must not turn a PARITY test red)
+    free_b, _ = torch.cuda.mem_get_info(0)
+    n = bench.fit_in_flight(bench.IN_FLIGHT, W * H, free_b)
+    assert n >= 256, f"{free_b / 1e9:.0f} GB free: not even 256 samples in flight fit"
     flags = gpu.FLAG_NO_BAKED_INSTANCES if flags_name == "entered" else 0
     if flags_name == "thin_lens":
         bundle = scenes.instanced_grid(W, H, level=6, thin_lens=True)
@@ -72,7 +77,9 @@ def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_
     px = np.random.default_rng(4).choice(W * H, 4096, replace=False).astype(np.uint32)
     ref, _ = O.render(U.oracle_scene(bundle), bundle.camera, W, H, n, seed=1, pixels=px, threads=16)
     got, want = a[px], ref[px, :3]
-    U.image_margins(f"config4 as timed ({n} in flight), {n} spp, {flags_name}", got, want, n, bundle.camera, 1e-3, 1e-3)
+    U.image_margins(f"config4 as timed ({n} in flight), {n} spp, {flags_name}", got, want, n, bundle.camera, 1e-3, 1e-3,
+                    in_flight_wanted=bench.IN_FLIGHT, device_free_gb=round(free_b / 1e9, 1),
+                    note="" if n == bench.IN_FLIGHT else f"fell back from {bench.IN_FLIGHT} to {n} samples in flight: {free_b / 1e9:.0f} GB of device memory free")
     # path by path most pixels agree to round-off (a pixel holds hundreds of paths here; one fp32 decision flip per pixel is common)
     close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * want.max()).all(axis=1)
     assert close.mean() > 0.85, close.mean()
@@ -169,7 +176,9 @@ def test_config2_diffuse_mesh_binned_sah_1080p_256spp(gpu):
     b = scenes.blob_room(W, H, level=6, builder=gpu_host().BVH_BINNED_SAH)
     assert 70000 < len(b.flat.triangles) < 100000
     st = _config_room_test(gpu, b, 256, seed=21, label="config2 diffuse, binned SAH")
-    assert st["packet_launches"] == 0 or st["packet_launches"] >= 1  # either traversal kernel may serve the primary rays
+    # 8 samples first (one batch of 8: fewer than 16 samples of a pixel side by side -- k_gen and the per-ray kernel), then 248 in batches of the
+    # context's 16 samples in flight, whose camera rays the bundle kernel generates and walks itself
+    assert st["gen_launches"] >= 1 and st["bundle_launches"] >= 240 // 16, (st["gen_launches"], st["bundle_launches"], st["packet_launches"])
 
 
 def test_config3_glass_mesh_sbvh_1080p_1024spp(gpu):

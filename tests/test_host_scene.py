@@ -557,6 +557,47 @@ def test_flatten_dynamic_is_the_per_tick_half_of_flatten():
         b.scene.flatten_dynamic(flat)
 
 
+def test_flatten_dynamic_refuses_static_arrays_a_refit_left_behind():
+    """after Mesh.refit the vertices and sub-BVH boxes of the last full flatten are stale, while the lights and top-level boxes
+    flatten_dynamic makes follow the NEW mesh -- a mix that renders wrongly without any error.  The host library holds a generation counter
+    per mesh against the ones it flattened and refuses; a full flatten makes it current again."""
+    v, f = scenes.icosphere(2)
+    mesh = H.Mesh((v * 0.5).astype(np.float32), f.astype(np.uint32), [L.material_diffuse((0.8, 0.8, 0.8))])
+    scene = H.Scene()
+    scene.add_node(mesh)
+    scene.add_node(mesh, location=(2.0, 0.0, 0.0))
+    flat = scene.flatten()
+    scene.flatten_dynamic(flat)
+    mesh.refit((v * 0.7).astype(np.float32))
+    with pytest.raises(RuntimeError, match="refitted since pth_scene_flatten"):
+        scene.flatten_dynamic(flat)
+    flat2 = scene.flatten()
+    assert not np.array_equal(flat2.vertices["vertex"], flat.vertices["vertex"])
+    part, _ = scene.flatten_dynamic(flat2)
+    assert np.array_equal(part.top_nodes, flat2.top_nodes)
+
+
+def test_top_level_tree_of_geometrically_spaced_instances_stays_shallow():
+    """instances spaced geometrically along a line make a SAH split peel ONE box off per level -- a top-level tree as deep as the
+    instance count, which the device library refuses for its traversal stack (112 entries) although a balanced tree over the same boxes is
+    fine.  Lop-sided splits are only taken while the depth stays within ~2 log2(n)."""
+    v, f = scenes.icosphere(0)
+    mesh = H.Mesh((v * 0.4).astype(np.float32), f.astype(np.uint32), [L.material_diffuse((0.8, 0.8, 0.8))], builder=H.BVH_BINNED_SAH)
+    scene = H.Scene()
+    n = 600
+    for k in range(n):
+        s = 1.03 ** k
+        scene.add_node(mesh, location=(3.0 * s * s, 0.0, 0.0), scale=(s, s, s))
+    flat = scene.flatten()
+    top = flat.top_nodes
+    assert len(top) == 2 * n - 1
+    depth = np.zeros(len(top), np.int64)
+    for i in range(len(top) - 1, -1, -1):  # parents are stored after their children: one reverse sweep pushes depths down
+        if not top[i]["isLeaf"]:
+            depth[int(top[i]["a"])] = depth[int(top[i]["b"])] = depth[i] + 1
+    assert depth.max() <= 2 * (2 + 2 * int(np.log2(n))), depth.max()
+
+
 @pytest.mark.parametrize("n", [300, 3000])
 def test_top_level_build_for_many_instances(n):
     """More than kAgglomerativeMaxInstances (256) instances: top-down SAH over the instance boxes instead of the reference's O(n^2)

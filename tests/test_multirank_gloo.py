@@ -86,16 +86,34 @@ def test_planning_of_the_eight_rank_jobs():
     """What every rank of the driver's N = 8 runs computes before it touches its GPU (bench.main): config 4 and config 5, weak and strong."""
     sys.path.insert(0, ROOT)
     import bench
-    for (w, h), want_weak in (((1920, 1080), 2048), ((3840, 2160), 1024)):
+    for (w, h), want_weak in (((1920, 1080), 4096), ((3840, 2160), 1024)):
         owned = []
         for r in range(8):
             rects = bench.tile_rects(w, h, r, 8)
             owned.append(sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects))
         assert sum(owned) == w * h
-        plans = [bench.plan_in_flight(256, 8, o, bench.MAX_ENTRIES) for o in owned]  # (256 requested per rank: the budget is the default's, 512)
-        assert min(plans) <= want_weak and min(plans) >= want_weak * 0.95, (plans, want_weak)  # 4K: capped by the entries that fit in HBM
-        assert min(plans) * max(owned) <= bench.MAX_ENTRIES * 1.001
-        assert min(min(plans), 256 * 5) == min(min(plans), 1280)  # strong scaling: the job's 256 x 5 samples per pixel bound the batch
+        plans = [bench.plan_in_flight(bench.IN_FLIGHT, 8, o, bench.MAX_ENTRIES) for o in owned]  # the driver's default request
+        batch = min(plans)  # what the MIN all-reduce of bench.main agrees on
+        assert batch == want_weak, (plans, want_weak)  # 1080p: the library's 4 096 planes; 4K: capped by the entries that fit in HBM
+        assert batch % 256 == 0, "only multiples of 256 keep the samples of a pixel together in the queues (bundles, coherent first bounce)"
+        assert batch * max(owned) <= bench.MAX_ENTRIES * 1.016  # the budget's 1/64 of slack for the uneven shares
+        assert bench.resident_bytes(batch, max(owned)) < 230e9, "queues and planes of the largest share fit a 288 GB part beside the scene"
+        # strong scaling: the job is IN_FLIGHT x rounds samples per pixel whatever N is; a rank never keeps more of them in flight than the job holds
+        job = bench.IN_FLIGHT * 3
+        strong = min(batch, job)
+        assert strong == min(job, want_weak) and strong % 256 == 0  # 1080p: the whole 1 536-sample job in flight at once; 4K: 1 024 of them
+
+
+def test_in_flight_falls_back_to_what_the_device_has_free():
+    """bench.fit_in_flight: a card with another tenant / less HBM costs the line a percent or two, not the run."""
+    sys.path.insert(0, ROOT)
+    import bench
+    px = 1920 * 1080
+    assert bench.fit_in_flight(512, px, 280 << 30) == 512
+    n = bench.fit_in_flight(512, px, 150 << 30)
+    assert n == 256 and bench.resident_bytes(n, px) + (6 << 30) <= 150 << 30  # multiples of 256: 512 -> 256
+    assert bench.fit_in_flight(512, px, 60 << 30) == 128 and bench.fit_in_flight(512, px, 1 << 30) == 1
+    assert [bench.shrink_in_flight(x) for x in (4096, 768, 600, 256, 3, 1)] == [3840, 512, 512, 128, 1, 1]
 
 
 def test_bench_without_a_launcher_starts_its_ranks_as_child_processes():

@@ -29,7 +29,7 @@ import json; d=json.load(open('$out/frame_${step#vframe:}.json')); print('${step
     share2:*) # two ranks on this one GPU, persistent grids of <n> (per-ray) and <m> (packet) blocks per CU each: share2:n,m
       IFS=, read tb pb <<< "${step#share2:}"
       PTAMD_TRACE_BLOCKS_PER_CU=$tb PTAMD_PACKET_BLOCKS_PER_CU=$pb timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-gpu --backend gloo --no-cpu-baseline --no-frame --steps 3 --warmup 1 --rounds 2 --in-flight 128 > $out/share2_${tb}_${pb}.json 2> $out/share2_${tb}_${pb}.err; rc=$?; head -c 300 $out/share2_${tb}_${pb}.json; echo; tail -2 $out/share2_${tb}_${pb}.err ;;
-    sorttest) timeout -k 10 400 python tools/sort_test.py > $out/sort_test.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/sort_test.txt | tail -12 ;;
+    sorttest) timeout -k 10 400 python tools/sort_probe.py > $out/sort_test.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/sort_test.txt | tail -12 ;;
     py:*) timeout -k 10 400 python ${step#py:} > $out/py_$(basename ${step#py:} .py).txt 2>&1; rc=$?; grep -v amdgpu.ids $out/py_$(basename ${step#py:} .py).txt | tail -20 ;;
     final) timeout -k 10 1100 tools/final_profiles.sh > $out/final.log 2>&1; rc=$?; tail -5 $out/final.log | cut -c1-600 ;;
     stats:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#stats:}.so timeout -k 10 300 python tools/trace_stats.py > $out/trace_${step#stats:}.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/trace_${step#stats:}.txt | cut -c1-330 | tail -32 ;;
