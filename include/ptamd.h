@@ -153,6 +153,10 @@ typedef struct {
                                         origin together, packet by packet, ahead of the per-ray traversal (pt_descend.h; measured no faster on MI355X --
                                         DESIGN.md section 6 -- hence opt-in; the image differs at most in exact-t ties) */
 #define PT_FLAG_DESCENT_INTERSECT 2048u /* pt_intersect (test hook): packets of 64 consecutive rays take the shared descent, then the per-ray kernel */
+#define PT_FLAG_PARKED_INSTANCES 4096u /* every instance that is entered takes the general route (ray transformed into the instance's space, lane parked for entry and exit:
+                                         rounds 2-4).  Default since round 5: instances whose transform is a translation + uniform scale are walked by the per-ray
+                                         kernels without parking (entry nodes, the ray taken into the instance's space on the fly; csrc/pt_trace.h); rotated /
+                                         non-uniformly scaled ones keep the general route either way */
 #define PT_FLAG_INTEGRATOR_MIS 32u
 /* exactly the reference's COMPARE_SHADING build (kernel.cl:48-51,248-265; raytracer.cpp:464-495): neeMisShading for the pixels of
  * the left half of the image, neeIsShading for the right half, both halves showing the left half's view -- two estimators of one
@@ -183,7 +187,7 @@ typedef struct {
     uint64_t descent_launches; /* launches of the shared-descent kernel (rays that leave one pixel's footprint walk from the root to their origin together) */
     double ms_descend; /* its device ms in the last pt_render (already counted in ms_shadow / ms_intersect) */
     uint32_t stack_need; /* worst-case traversal stack entries of the active scene state (packet kernels need <= 64) */
-    uint32_t _pad;
+    uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk through an entry node (translation + uniform scale, not copied to world space) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

@@ -132,7 +132,7 @@ struct SceneDev {
     uint32_t numLights;
     uint32_t rootRef; // reference of the top-level root: a PairNode, or an instance when there is only one
     uint32_t numTriangles;
-    uint32_t _pad;
+    uint32_t firstWorldNode; // nodes below this index are object-space nodes of the mesh trees (reached through an instance); the top level, entry nodes and world-space copies come behind
 };
 
 // ---- queues ---------------------------------------------------------------------------------

@@ -34,6 +34,7 @@
 //    40.4: the near-first descent finds occluders sooner than fuller steps save.
 #pragma once
 #include "pt_shade.h"
+#include <type_traits>
 
 namespace ptd {
 
@@ -62,6 +63,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
+#ifndef PT_LDS_STACK_TL
+#define PT_LDS_STACK_TL 10 // ... in the instantiations that enter instances: their lanes keep an instance state in LDS too (16 B), and 7 waves per SIMD leave 5.7 KB per wave
+#endif
+constexpr int kLdsStackTL = PT_LDS_STACK_TL;
+constexpr int kTraversalStackMax = (kLdsStackTL < kLdsStack ? kLdsStackTL : kLdsStack) + 100; // what every instantiation can hold (LDS + spill, kSpillStack below)
 constexpr int kDescentStack = 3; // entries of a START stack (pt_descend.h: rays that leave one pixel's footprint take the way from the root to their origin together)
 static_assert(kDescentStack <= kLdsStack, "the hand-out copies a start stack into the LDS part of the lane's stack");
 constexpr int kSpillStack = 100; // further entries in global memory
@@ -163,8 +169,17 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false>
 __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
+    constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
     __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
+    // TWO_LEVEL, round 5: instances whose transform is a translation + uniform scale are traversed WITHOUT parking.  The lane keeps the world-space
+    // ray in its registers; while it walks object-space nodes / triangles (known from the reference alone: their indices lie below the
+    // first top-level node / below the first world-space triangle) the ray is taken into the instance's space on the fly,
+    //   o' = o * (1/s) + w,   1/d' = (1/d) * s,   d' = d * (1/s)        (t is shared between the spaces, scene.cl:118-121)
+    // from (1/s, w) kept per lane in LDS -- slot 64 of a wave holds the identity, which world-space steps read instead (o * 1 + 0 and
+    // d * 1 are exact): no branch, no parked step, seven more vector instructions per step.  The state arrives with the instance's ENTRY NODE
+    // (a one-child node in the top-level leaf's place that carries (1/s, w, instance) in its unused bytes: ptamd.hip, convertDynamic).
+    __shared__ float4 ldsInst[TWO_LEVEL ? kTraceBlock / 64 : 1][TWO_LEVEL ? 65 : 1];
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
@@ -177,6 +192,11 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
     const SceneDev& sc = a.sc;
     if (ANY_HIT && lane == 0)
         ldsDeposits[wave] = 0u;
+    if constexpr (TWO_LEVEL) {
+        ldsInst[wave][lane] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (lane == 0)
+            ldsInst[wave][64] = make_float4(1.f, 0.f, 0.f, 0.f);
+    }
 
     auto push = [&](int slot, uint32_t v) {
         if (slot < kLdsStack)
@@ -196,6 +216,10 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
 #ifdef PT_TRACE_STATS
     unsigned long long statAcc[24] = {};
     PT_TIC(tKernel);
+    // round 5, any-hit launches: does an occluded shadow ray die in the leaf that stopped the previous occluded ray of its lane / of its wave?
+    // [19] occluded rays, [20] ... in the leaf of the lane's previous occluded ray, [21] ... in the leaf that last stopped ANY ray of the wave (in an
+    // earlier iteration), [22] ... on the very triangle of the lane's previous one, [23] ... whose leaf is one of the wave's last FOUR occluder leaves
+    uint32_t statLaneLeaf = 0xFFFFFFFFu, statLaneTri = 0xFFFFFFFFu, statWaveLeaf[4] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
 #endif
     bool active = false;
     bool exhausted = false; // wave-uniform: queue has no more rays
@@ -410,6 +434,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         V3 to, td;
                         rayIntoInstance(in.r0, in.r1, in.r2, wo, wd, &to, &td);
                         setRay(to, td);
+                        ldsInst[wave][lane] = make_float4(1.f, 0.f, 0.f, 0.f); // the registers hold the instance-space ray: nothing to fold
                         curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
                         push(sp, kRefLeaveInstance);
                         sp++;
@@ -526,7 +551,8 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
                     const uint4 A = wp[0], B = wp[1];
-                    const uint2 C = *(const uint2*)&wp[2];
+                    typedef typename std::conditional<TWO_LEVEL, uint4, uint2>::type PlanesZ; // (TWO_LEVEL: the two spare words of the line carry an entry node's state)
+                    const PlanesZ C = *(const PlanesZ*)&wp[2];
                     const uint4 D = wp[3];
 #ifdef PT_EXTRA_LOADS // diagnostic: how sensitive is the kernel to vector-memory instruction count?
                     uint32_t extra = 0;
@@ -539,16 +565,28 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     if (extra == 0x12345u) // never true for real nodes; keeps the loads alive
                         tClosest = 0.f;
 #endif
+                    // the ray in the node's space (TWO_LEVEL: object-space nodes are seen through the lane's instance state, see the top)
+                    V3 no = co, nid = cid;
+                    if constexpr (TWO_LEVEL) {
+                        const float4 is = ldsInst[wave][refIndex(cur) < sc.firstWorldNode ? lane : 64u];
+                        const float scl = rcpFast(is.x);
+                        no = mk(fmaf(co.x, is.x, is.y), fmaf(co.y, is.x, is.z), fmaf(co.z, is.x, is.w));
+                        nid = mk(cid.x * scl, cid.y * scl, cid.z * scl);
+                        if (A.w >> 24) { // an entry node: from here on (until the walk comes back to world-space references) the lane is inside this instance
+                            ldsInst[wave][lane] = make_float4(asF(D.y), asF(D.z), asF(D.w), asF(C.z));
+                            curInst = (int)C.w;
+                        }
+                    }
                     // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
-                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
-                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    const float ax = asF((A.w & 0xFFu) << 23) * nid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * nid.y,
+                                az = asF(((A.w >> 16) & 0xFFu) << 23) * nid.z;
                     // (origin - o) / d from the live registers: keeping -o/d around as well would cost three VGPRs, and 72 is
                     // what 7 waves per SIMD allow
-                    const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
+                    const float bx = (asF(A.x) - no.x) * nid.x, by = (asF(A.y) - no.y) * nid.y, bz = (asF(A.z) - no.z) * nid.z;
                     // entry / exit planes chosen by the sign of the ray direction (whole dwords: 4 children at once)
                     // instead of min/max per plane pair; an empty slot is an inverted box (q 255..0) and can never
                     // satisfy exit >= entry -- and if round-off ever made it, its reference is a degenerate triangle
-                    const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
+                    const bool nx = nid.x < 0.f, ny = nid.y < 0.f, nz = nid.z < 0.f;
                     const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                     const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
@@ -639,37 +677,64 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                 PT_STAT(3, 1);
                 PT_STAT(6, nLeaf);
                 PT_TIC(tLeaf);
+#ifdef PT_TRACE_STATS
+                bool stOcc = false, stLane = false, stWave = false, stTri = false, stWave4 = false;
+#endif
                 if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
+                    V3 lo_ = co, ld_ = cd; // the ray in the triangles' space
+                    bool inObject = false;
+                    if constexpr (TWO_LEVEL) {
+                        inObject = first < sc.numTriangles + 1u; // the caller's (object-space) triangles; world-space copies come behind them
+                        const float4 is = ldsInst[wave][inObject ? lane : 64u];
+                        lo_ = mk(fmaf(co.x, is.x, is.y), fmaf(co.y, is.x, is.z), fmaf(co.z, is.x, is.w)); // rayIntoInstance's arithmetic for such a matrix, bit for bit
+                        ld_ = mk(cd.x * is.x, cd.y * is.x, cd.z * is.x);
+                    }
                     bool done = false;
+#ifdef PT_TRACE_STATS
+                    uint32_t statTri = 0xFFFFFFFFu;
+#endif
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
-                        const V3 P = cross(cd, e2);
+                        const V3 P = cross(ld_, e2);
                         const float det = dot(e1, P);
                         const float inv = rcpFast(det);
-                        const V3 T = co - v0;
+                        const V3 T = lo_ - v0;
                         const float u = dot(T, P) * inv;
                         const V3 Q = cross(T, e1);
-                        const float v = dot(cd, Q) * inv;
+                        const float v = dot(ld_, Q) * inv;
                         const float t = dot(e2, Q) * inv;
                         const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f
                             && t < tClosest;
                         if (hit) {
                             if (ANY_HIT) {
                                 done = true;
+#ifdef PT_TRACE_STATS
+                                statTri = first + k;
+#endif
                                 break;
                             }
                             tClosest = t;
                             hu = u;
                             hv = v;
                             hprim = (int)(first + k);
-                            hinst = curInst;
+                            hinst = TWO_LEVEL ? (inObject ? curInst : -1) : curInst;
                         }
                     }
+#ifdef PT_TRACE_STATS
+                    if (ANY_HIT && done) {
+                        stOcc = true;
+                        stLane = cur == statLaneLeaf;
+                        stWave = cur == statWaveLeaf[0];
+                        stTri = statTri == statLaneTri;
+                        stWave4 = cur == statWaveLeaf[0] || cur == statWaveLeaf[1] || cur == statWaveLeaf[2] || cur == statWaveLeaf[3];
+                        statLaneLeaf = cur, statLaneTri = statTri;
+                    }
+#endif
                     if (ANY_HIT && done) { // occluded: nothing to deposit
                         if (a.occluded)
                             a.occluded[rayIdx] = 1u;
@@ -680,6 +745,23 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         sp = max(sp - 1, 0);
                     }
                 }
+#ifdef PT_TRACE_STATS
+                if (ANY_HIT) { // the leaves that stopped rays in this step become the wave's most recent occluder leaves (up to four, newest first)
+                    PT_STAT(19, __popcll(__ballot(stOcc)));
+                    PT_STAT(20, __popcll(__ballot(stLane)));
+                    PT_STAT(21, __popcll(__ballot(stWave)));
+                    PT_STAT(22, __popcll(__ballot(stTri)));
+                    PT_STAT(23, __popcll(__ballot(stWave4)));
+                    unsigned long long stopped = __ballot(stOcc);
+                    for (int q = 0; q < 4 && stopped; q++) {
+                        const int src = __builtin_ctzll(stopped);
+                        stopped &= stopped - 1ull;
+                        const uint32_t leaf = (uint32_t)__shfl((int)statLaneLeaf, src);
+                        if (leaf != statWaveLeaf[0] && leaf != statWaveLeaf[1] && leaf != statWaveLeaf[2] && leaf != statWaveLeaf[3])
+                            statWaveLeaf[3] = statWaveLeaf[2], statWaveLeaf[2] = statWaveLeaf[1], statWaveLeaf[1] = statWaveLeaf[0], statWaveLeaf[0] = leaf;
+                    }
+                }
+#endif
                 PT_TOC(12, tLeaf);
             }
         }

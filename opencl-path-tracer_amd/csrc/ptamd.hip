@@ -102,6 +102,8 @@ struct pt_ctx {
         hipEvent_t stageRead = nullptr; // recorded on the copy stream after the copies out of `stage`
         bool stageBusy = false;
         uint32_t numLights = 0, rootRef = 0;
+        uint32_t foldedInstances = 0;
+        uint32_t rootRefFolded = 0; // the same top level for the per-ray kernels: entry nodes in place of the instances that are a translation + uniform scale (pt_trace.h)
         bool packetOk = false;
         uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
         bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
@@ -294,6 +296,7 @@ void refreshSceneView(pt_ctx* c)
     s.lights = d.lights.p;
     s.numLights = d.numLights;
     s.rootRef = d.rootRef;
+    s.firstWorldNode = (uint32_t)c->sg.wide.size();
     s.materialTex.texels = c->texMaterial.p;
     s.sky.texels = c->texSky.p;
     s.numTriangles = c->numTris;
@@ -350,7 +353,34 @@ struct WideKids {
     uint32_t src[4]; // where the box of child k comes from: (pair node << 1) | side -- what a refit re-reads (refitStaticGeom)
     bool empty[4];
 };
-std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
+// Leaf formation inside the collapse (round 5).  The reference's builders stop at <= 3 triangles per leaf with Ct 1.5 / Ci 1.0 tuned for a binary tree
+// (src/bvh/bvh_build.cpp:15-18); for THIS traversal a visit of a 4-wide node costs ~105 vector instructions and a triangle test ~35, and a leaf step runs
+// to the longest leaf among its lanes.  So the collapse may turn a whole subtree into ONE leaf where that is cheaper:
+//   asLeaf[n] = area(n) * (leaf0 + tri * (alpha * tris(n) + (1 - alpha) * cap))      (alpha 1: cost per triangle; alpha 0: every leaf visit costs the cap)
+//   asRoot[n] = area(n) * inner + cheapest distribution of its (up to four) slots
+// possible only where the subtree's triangle references are one contiguous run (the reference's builders emit leaves depth first: always) of <= cap.
+// cap 0 = the leaves are given (rounds 1-4).  PTAMD_LEAF_FORMATION="cap[,inner,leaf0,tri,alpha]" overrides at run time (sweeps).
+#ifndef PT_LEAF_CAP
+#define PT_LEAF_CAP 0
+#endif
+struct CollapseCosts {
+    uint32_t cap = PT_LEAF_CAP;
+    double inner = 105.0, leaf0 = 20.0, tri = 35.0, alpha = 1.0;
+    double leaf(uint32_t n) const { return leaf0 + tri * (alpha * (double)n + (1.0 - alpha) * (double)std::max(cap, 1u)); }
+};
+CollapseCosts collapseCostsFromEnv()
+{
+    CollapseCosts k;
+    if (const char* e = getenv("PTAMD_LEAF_FORMATION")) {
+        unsigned cap = k.cap;
+        const int got = sscanf(e, "%u,%lf,%lf,%lf,%lf", &cap, &k.inner, &k.leaf0, &k.tri, &k.alpha);
+        if (got >= 1)
+            k.cap = std::min(cap, kMaxLeafTris);
+    }
+    return k;
+}
+
+std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const CollapseCosts costs = CollapseCosts { 0u })
 {
     std::vector<WideKids> out(pair.size());
     struct Child {
@@ -389,6 +419,14 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
         double atMost[5]; // [1..4]
         uint8_t split[5]; // 0: the node itself, i: i slots to the left child
         uint8_t rootSplit, done;
+        uint8_t asLeaf; // as ONE child the subtree is a leaf of [leafFirst, leafFirst + leafCount)
+        uint32_t leafFirst, leafCount; // the subtree's triangle references, when they are one run of <= cap (leafCount 0: not)
+    };
+    const bool leafCosts = costs.cap > 0u; // the leaves are no longer given: they enter the cost
+    auto childArea = [&](const PairNode& n, int side) {
+        const Child c = childOf(n, side);
+        const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+        return dx >= 0.0 && dy >= 0.0 && dz >= 0.0 ? dx * dy + dy * dz + dz * dx : 0.0;
     };
     std::vector<Dp> dp(N);
     for (Dp& d : dp)
@@ -432,21 +470,47 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
                     continue;
                 }
                 // children are final (or n sits on a cycle, which upload validation has already excluded): combine
-                auto cost = [&](uint32_t r, int k) { return isInner(r) && dp[refIndex(r)].done == 2 ? dp[refIndex(r)].atMost[k] : 0.0; };
+                auto costSide = [&](int side, int k) {
+                    const uint32_t r = kids[side];
+                    if (isInner(r) && dp[refIndex(r)].done == 2)
+                        return dp[refIndex(r)].atMost[k];
+                    if (leafCosts && r != kRefNone && refCount(r) >= 1u && refCount(r) <= kMaxLeafTris) // a given leaf: what a visit of it costs
+                        return costs.leaf(refCount(r)) * childArea(pair[n], side);
+                    return 0.0;
+                };
                 Dp& d = dp[n];
+                // the subtree's triangle references as one run?
+                d.asLeaf = 0, d.leafFirst = 0, d.leafCount = 0;
+                if (leafCosts) {
+                    uint32_t first[2] = { 0, 0 }, cnt[2] = { 0, 0 };
+                    for (int side = 0; side < 2; side++) {
+                        const uint32_t r = kids[side];
+                        if (isInner(r) && dp[refIndex(r)].done == 2)
+                            first[side] = dp[refIndex(r)].leafFirst, cnt[side] = dp[refIndex(r)].leafCount;
+                        else if (r != kRefNone && refCount(r) >= 1u && refCount(r) <= kMaxLeafTris)
+                            first[side] = refIndex(r), cnt[side] = refCount(r);
+                    }
+                    if (cnt[0] && cnt[1] && cnt[0] + cnt[1] <= costs.cap && (first[0] + cnt[0] == first[1] || first[1] + cnt[1] == first[0]))
+                        d.leafFirst = std::min(first[0], first[1]), d.leafCount = cnt[0] + cnt[1];
+                }
                 double best = 1e300;
                 for (int i = 1; i <= 3; i++) {
-                    const double v = cost(kids[0], i) + cost(kids[1], 4 - i);
+                    const double v = costSide(0, i) + costSide(1, 4 - i);
                     if (v < best)
                         best = v, d.rootSplit = (uint8_t)i;
                 }
-                d.atMost[1] = nodeArea(n) + best;
+                d.atMost[1] = (leafCosts ? costs.inner : 1.0) * nodeArea(n) + best;
+                if (d.leafCount) {
+                    const double asLeaf = costs.leaf(d.leafCount) * nodeArea(n);
+                    if (asLeaf < d.atMost[1])
+                        d.atMost[1] = asLeaf, d.asLeaf = 1;
+                }
                 d.split[1] = 0;
                 for (int k = 2; k <= 4; k++) {
                     d.atMost[k] = d.atMost[1];
                     d.split[k] = 0;
                     for (int i = 1; i < k; i++) {
-                        const double v = cost(kids[0], i) + cost(kids[1], k - i);
+                        const double v = costSide(0, i) + costSide(1, k - i);
                         if (v < d.atMost[k])
                             d.atMost[k] = v, d.split[k] = (uint8_t)i;
                     }
@@ -476,7 +540,10 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair)
                 const uint32_t r = it.c.ref;
                 const int sp = isInner(r) && refIndex(r) != i ? dp[refIndex(r)].split[it.slots] : 0;
                 if (sp == 0) {
-                    kids[n++] = it.c;
+                    kids[n] = it.c;
+                    if (isInner(r) && refIndex(r) != i && dp[refIndex(r)].asLeaf) // the whole subtree as ONE leaf: same box, its run of triangles
+                        kids[n].ref = makeRef(dp[refIndex(r)].leafFirst, dp[refIndex(r)].leafCount);
+                    n++;
                     continue;
                 }
                 const PairNode& g = pair[refIndex(r)];
@@ -704,7 +771,7 @@ int buildStaticGeom(pt_ctx* c)
     pt_ctx::StaticGeom& g = c->sg;
     refreshHostGeometry(c);
     const uint32_t nN = c->numRefNodes, nT = c->numTris;
-    const std::vector<WideKids> kids = collapseKids(c->hostBottomNodes);
+    const std::vector<WideKids> kids = collapseKids(c->hostBottomNodes, collapseCostsFromEnv());
     const uint32_t emptyRef = makeRef(nT, 1u); // the all-zero triangle stored right after the caller's triangles (det == 0: never hit)
     std::vector<uint8_t> isChild(nN, 0);
     for (uint32_t i = 0; i < nN; i++) {
@@ -811,6 +878,23 @@ int buildStaticGeom(pt_ctx* c)
             }
             g.stackNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
         }
+    if (getenv("PTAMD_COLLAPSE_REPORT")) { // what the collapse made: packed nodes, leaves by size (tools / sweeps of PTAMD_LEAF_FORMATION)
+        uint64_t hist[kMaxLeafTris + 1] = {}, leaves = 0, refs = 0, used = 0;
+        for (const WideNode& w : g.wide)
+            for (uint32_t r : w.child)
+                if (r != emptyRef) {
+                    used++;
+                    if (refCount(r) >= 1u && refCount(r) <= kMaxLeafTris)
+                        hist[refCount(r)]++, leaves++, refs += refCount(r);
+                }
+        const CollapseCosts k = collapseCostsFromEnv();
+        fprintf(stderr, "[ptamd] collapse: cap %u costs %.0f/%.0f/%.0f alpha %.2f -> %zu wide nodes, %.2f used slots per node, %llu leaves, %.2f triangles per leaf; by size:", k.cap, k.inner,
+            k.leaf0, k.tri, k.alpha, g.wide.size(), g.wide.empty() ? 0.0 : (double)used / (double)g.wide.size(), (unsigned long long)leaves, leaves ? (double)refs / (double)leaves : 0.0);
+        for (uint32_t n = 1; n <= kMaxLeafTris; n++)
+            if (hist[n])
+                fprintf(stderr, " %u:%llu", n, (unsigned long long)hist[n]);
+        fprintf(stderr, "\n");
+    }
     buildFat(c);
     g.emptyRef = emptyRef;
     g.version++;
@@ -1035,10 +1119,13 @@ inline int sceneKind(const pt_ctx* c)
     return (c->dyn[c->active].hasInstances || forceTwoLevel) ? 1 : 0;
 }
 
-void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& a, hipStream_t stream = nullptr)
+void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stream = nullptr)
 {
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
+    TraceArgs a = args;
+    if (twoLevel) // the per-ray kernels walk the top level that holds entry nodes (the packet kernels and k_descend: the one with instance references)
+        a.sc.rootRef = c->dyn[c->active].rootRefFolded;
     const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
     if (!stream)
         stream = c->stream;
@@ -2013,7 +2100,8 @@ struct DynamicHost {
     std::vector<Light> lights;
     std::vector<BakeJob> jobs;
     std::vector<uint32_t> instanceTopNode;
-    uint32_t numLights = 0, rootRef = 0;
+    uint32_t numLights = 0, rootRef = 0, rootRefFolded = 0;
+    uint32_t foldedInstances = 0; // instances the per-ray kernels traverse through an entry node (no parked enter / leave)
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
     uint32_t bakedNodes = 0, bakedTris = 0;
     bool packetOk = false, hasInstances = false;
@@ -2078,7 +2166,10 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             numTopInner++;
         }
     }
-    out.topSlots = numTopInner;
+    // node slots of the top level: [the top level with instance references (<= numTopInner nodes) | one entry node per instance | the same top level
+    // with entry nodes for the per-ray kernels (<= numTopInner)]; the world-space copies start behind them
+    const uint32_t entryBase = staticNodes + numTopInner, foldedBase = entryBase + (uint32_t)hInst.size();
+    out.topSlots = 2u * numTopInner + (uint32_t)hInst.size();
     // ---- instances copied to world space --------------------------------------------------------------------
     // An instance costs every ray that enters it a transform in and a restore out on top of the traversal proper.  With 288 GB of
     // HBM the instanced geometry of scenes like the benchmark's (12 x 82 k triangles: ~110 MB of nodes and triangles) simply fits
@@ -2089,7 +2180,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     {
         const uint64_t budgetBytes = 2ull << 30;
         uint64_t usedBytes = 0;
-        uint32_t nextNode = staticNodes + numTopInner, nextTri = staticTris;
+        uint32_t nextNode = staticNodes + out.topSlots, nextTri = staticTris;
         auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
             const pt_ctx::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
             const bool single = refCount(root.ref) != 0u; // the mesh is one leaf
@@ -2123,7 +2214,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             for (uint32_t k = 0; k < hInst.size(); k++)
                 tryBake(k, true);
         }
-        out.bakedNodes = nextNode - (staticNodes + numTopInner);
+        out.bakedNodes = nextNode - (staticNodes + out.topSlots);
         out.bakedTris = nextTri - staticTris;
     }
     uint32_t topDepth = 0;
@@ -2143,9 +2234,9 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         }
     }
     // one pending entry per level of either tree + the leave-instance sentinel
-    if (topDepth + 1 + maxBottomDepth > (uint32_t)(kLdsStack + kSpillStack))
-        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kLdsStack + kSpillStack);
-    if ((uint64_t)staticNodes + numTopInner + out.bakedNodes > kRefIndexMask)
+    if (topDepth + 1 + maxBottomDepth > (uint32_t)kTraversalStackMax)
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kTraversalStackMax);
+    if ((uint64_t)staticNodes + out.topSlots + out.bakedNodes > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
     // ---- the top level: pair nodes -> 4-wide, packed breadth-first into the slots behind the static nodes -----------------
     std::vector<PairNode> topPairs(numTopInner);
@@ -2228,11 +2319,82 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         topNeed[q] = (n > 0 ? n - 1 : 0u) + deepest;
     }
     const uint32_t stackNeed = needOf(rootRef);
-    if (stackNeed > (uint32_t)(kLdsStack + kSpillStack))
-        return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kLdsStack + kSpillStack);
+    if (stackNeed > (uint32_t)kTraversalStackMax)
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH needs %u traversal stack entries, %d are available", stackNeed, kTraversalStackMax);
     // k_trace_packet keeps its stack in the 64 lanes of a register (instance references are entered there too, pt_packet.h)
     out.packetOk = stackNeed <= kPacketStack;
     out.stackNeed = stackNeed;
+    // ---- the top level once more, for the per-ray kernels: ENTRY NODES in place of the entered instances whose transform is a translation + uniform scale
+    // (the reference's own scenes, BASELINE configs 4 / 5).  An entry node is a one-child 4-wide node -- the instance's world-space box, the mesh root below it
+    // -- whose unused bytes carry (1 / s, w = -t / s) of the inverse transform and the instance index: a lane that walks over it takes its ray into
+    // the instance's space on the fly from then on (pt_trace.h) instead of parking twice per visit.  Same pairs, same boxes, hence the same collapse
+    // and the same worst-case stack (an entry node pushes nothing; the sentinel of a parked entry is the one entry more the bound above holds).
+    out.rootRefFolded = rootRef;
+    out.foldedInstances = 0;
+    {
+        static const bool envNoFold = getenv("PTAMD_NO_FOLDED_INSTANCES") != nullptr; // diagnostics: every entered instance takes the parked route (rounds 2-4)
+        const bool noFold = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u;
+        auto simple = [](const Instance& in) {
+            const float a = in.r0.x;
+            return a > 0.f && std::isfinite(a) && in.r1.y == a && in.r2.z == a && in.r0.y == 0.f && in.r0.z == 0.f && in.r1.x == 0.f && in.r1.z == 0.f && in.r2.x == 0.f
+                && in.r2.y == 0.f && std::isfinite(in.r0.w) && std::isfinite(in.r1.w) && std::isfinite(in.r2.w);
+        };
+        std::vector<uint8_t> folded(hInst.size(), 0);
+        for (size_t k = 0; k < hInst.size() && !noFold && !parityMode(c); k++) // (parity mode follows the reference to the letter)
+            if (refCount(topRef[hInst[k].topNode]) == kRefSpecial && simple(hInst[k]))
+                folded[k] = 1, out.foldedInstances++;
+        if (out.foldedInstances) {
+            auto foldRef = [&](uint32_t r) { return refCount(r) == kRefSpecial && refIndex(r) < hInst.size() && folded[refIndex(r)] ? makeRef(entryBase + refIndex(r), 0u) : r; };
+            std::vector<PairNode> pairsB = topPairs;
+            for (PairNode& pn : pairsB)
+                pn.left = foldRef(pn.left), pn.right = foldRef(pn.right);
+            const std::vector<WideKids> kidsB = collapseKids(pairsB);
+            std::vector<uint32_t> newB(numTopInner, kUnset), orderB;
+            uint32_t rootB = foldRef(topRef[topRoot]);
+            if (isTopInner(topRef[topRoot])) {
+                newB[local(topRef[topRoot])] = 0;
+                orderB.push_back(local(topRef[topRoot]));
+                for (size_t q = 0; q < orderB.size(); q++)
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r = kidsB[orderB[q]].ref[k];
+                        if (!kidsB[orderB[q]].empty[k] && isKept(r) && newB[refIndex(r)] == kUnset) {
+                            newB[refIndex(r)] = (uint32_t)orderB.size();
+                            orderB.push_back(refIndex(r));
+                        }
+                    }
+                rootB = makeRef(foldedBase, 0u);
+            }
+            out.topWide.resize((size_t)(foldedBase - staticNodes) + orderB.size()); // (the gap behind the first top level stays zero: never referenced)
+            for (size_t k = 0; k < hInst.size(); k++) {
+                if (!folded[k])
+                    continue;
+                const pt_top_bvh_node& leaf = topNodes[hInst[k].topNode];
+                float lo[4][3], hi[4][3];
+                const uint32_t refs[4] = { hInst[k].rootRef, sg.emptyRef, sg.emptyRef, sg.emptyRef };
+                const bool empty[4] = { false, true, true, true };
+                for (int a = 0; a < 3; a++) {
+                    lo[0][a] = leaf.min[a], hi[0][a] = leaf.max[a];
+                    for (int q = 1; q < 4; q++)
+                        lo[q][a] = 1.f, hi[q][a] = -1.f;
+                }
+                WideNode e;
+                quantiseWideNode(lo, hi, refs, empty, sg.emptyRef, &e);
+                auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+                e.exps |= 1u << 24; // "entry node": the words below are not references
+                e.child[1] = bits(hInst[k].r0.x), e.child[2] = bits(hInst[k].r0.w), e.child[3] = bits(hInst[k].r1.w);
+                e._pad0 = bits(hInst[k].r2.w), e._pad1 = (uint32_t)k;
+                out.topWide[(size_t)(entryBase - staticNodes) + k] = e;
+            }
+            for (size_t q = 0; q < orderB.size(); q++) {
+                const WideKids& wk = kidsB[orderB[q]];
+                uint32_t refs[4];
+                for (int k = 0; k < 4; k++)
+                    refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(foldedBase + newB[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[(size_t)(foldedBase - staticNodes) + q]);
+            }
+            out.rootRefFolded = rootB;
+        }
+    }
     std::vector<Light>& hLights = out.lights;
     hLights.resize(nL);
     for (uint32_t i = 0; i < nL; i++) {
@@ -2370,6 +2532,8 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     HIPCHK(c, hipEventRecord(d.uploaded, c->copyStream));
     d.numLights = h.numLights;
     d.rootRef = h.rootRef;
+    d.rootRefFolded = h.rootRefFolded;
+    d.foldedInstances = h.foldedInstances;
     d.packetOk = h.packetOk;
     d.stackNeed = h.stackNeed;
     d.hasInstances = h.hasInstances;
@@ -2710,6 +2874,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->descent_launches = c->descentLaunches;
     out->ms_descend = c->msDescend;
     out->stack_need = c->dyn[c->active].stackNeed;
+    out->folded_instances = c->dyn[c->active].foldedInstances;
     return PT_OK;
 }
 

@@ -12,7 +12,7 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "descent", "unbaked_descent"]
+MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "descent", "unbaked_descent", "two_level_parked", "unbaked_parked"]
 
 
 def _flags(gpu, mode):
@@ -23,15 +23,20 @@ def _flags(gpu, mode):
             "two_level_packet": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PACKET_INTERSECT, "unbaked": gpu.FLAG_NO_BAKED_INSTANCES,
             "unbaked_packet": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PACKET_INTERSECT,
             # *descent: packets of 64 consecutive rays walk from the root towards their origins together (pt_descend.h), then the per-ray kernel
-            "descent": gpu.FLAG_DESCENT_INTERSECT, "unbaked_descent": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_DESCENT_INTERSECT}[mode]
+            "descent": gpu.FLAG_DESCENT_INTERSECT, "unbaked_descent": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_DESCENT_INTERSECT,
+            # *parked: the general route into an instance for every instance (rounds 2-4); without it (round 5) the per-ray kernels walk instances that are a
+            # translation + uniform scale through entry nodes, the ray taken into the instance's space on the fly
+            "two_level_parked": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PARKED_INSTANCES, "unbaked_parked": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PARKED_INSTANCES}[mode]
 
 
 def _entered(mode):
     return mode.startswith(("two_level", "unbaked"))
 
 
-def _check_kernel_used(ctx, mode):
+def _check_kernel_used(ctx, mode, folded=None):
     assert (ctx.stats()["packet_launches"] > 0) == mode.endswith("packet"), "wrong traversal kernel ran"
+    if folded is not None:  # how many instances of the scene the per-ray kernels walk through entry nodes
+        assert ctx.stats()["folded_instances"] == folded, (ctx.stats()["folded_instances"], folded)
     assert (ctx.stats()["descent_launches"] > 0) == mode.endswith("descent"), "the shared descent did not run where it should (or ran where it should not)"
 
 
@@ -78,7 +83,11 @@ def test_random_rays_two_level(gpu, builder, mode, rotate):
     occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
     ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
     assert (occ != ref).sum() <= 3 + info["edge_flips"]
-    _check_kernel_used(ctx, mode)
+    # translated + uniformly scaled instances that are entered go through entry nodes (12 meshes; with nothing copied also the two quads); rotated ones
+    # and the *parked modes take the general route
+    quads = 2 if mode.startswith("unbaked") else 0  # the ground and the light: single-leaf meshes, copied to world space unless nothing is
+    want_folded = 0 if (mode.endswith("parked") or not two_level) else quads + (0 if rotate else 12)
+    _check_kernel_used(ctx, mode, want_folded)
     ctx.close()
 
 
@@ -271,8 +280,10 @@ def test_first_pass_with_a_ragged_tail_and_a_pixel_list(gpu, spp):
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles)
     n = owned * spp
     assert n % 256 != 0
-    first = U.make_ctx(gpu, b, W, Hh, samples_in_flight=spp)
-    queued = U.make_ctx(gpu, b, W, Hh, flags=gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=spp)
+    # (a context rounds its samples in flight down to a power of two -- what pt_render's batches are cut to --; the hook takes any batch up to that)
+    in_flight = 1 << (spp - 1).bit_length()
+    first = U.make_ctx(gpu, b, W, Hh, samples_in_flight=in_flight)
+    queued = U.make_ctx(gpu, b, W, Hh, flags=gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=in_flight)
     for ctx in (first, queued):
         ctx.set_tiles(tiles)
     o, d, pixel, got = first.primary_pass(3, spp, n)

@@ -53,7 +53,7 @@
 
 enum Kind {
     K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
-    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_FMAMIX_LO, K_FMAMIX_HI, K_PKFMA16, K_PKMAX16, K_PKMIN16, K_PKADD16, K_PKMUL16, K_CVT16, K_CVT16_SDWA, K_CVTUB_SDWA, K_PKRTZ, K_PKMAXI16, K_PKMADU16, K_CVTPKFP8, K_MED3, K_PKMOV, K_DOT2, K_COUNT
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_FMAMIX_LO, K_FMAMIX_HI, K_PKFMA16, K_PKMAX16, K_PKMIN16, K_PKADD16, K_PKMUL16, K_CVT16, K_CVT16_SDWA, K_CVTUB_SDWA, K_PKRTZ, K_PKMAXI16, K_PKMADU16, K_CVTPKFP8, K_MED3, K_PKMOV, K_DOT2, K_OR_SDWA_B1, K_OR_SDWA_B3, K_OR_SDWA_SGPR, K_AND_SDWA, K_MULU24_SDWA, K_ADDU_SDWA, K_MOV_SDWA, K_LSHL_SDWA, K_ALIGNBIT, K_ALIGNBYTE, K_OR_SDWA_FMA, K_CVTUB_FMA, K_COUNT
 };
 static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
     "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
@@ -66,7 +66,12 @@ static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v
     "compare-exchange by full-rate ops: v_sub_f32, v_ashrrev_i32, 2 x (v_xor, v_and, v_xor, v_xor) (per instruction)", "v_ashrrev_i32", "v_xor_b32", "v_bfi_b32",
     "compare-exchange of packed keys: v_min_u32 + v_max_u32 (per instruction)", "ds_write_b32 (own lane's slot)", "ds_read_b32 (own lane's slot)",
     "v_fma_mix_f32 (src0 = low f16 half)", "v_fma_mix_f32 (src0 = high f16 half)", "v_pk_fma_f16", "v_pk_max_f16", "v_pk_min_f16", "v_pk_add_f16", "v_pk_mul_f16", "v_cvt_f32_f16",
-    "v_cvt_f32_f16_sdwa src0_sel:WORD_1", "v_cvt_f32_u32_sdwa src0_sel:BYTE_1", "v_cvt_pkrtz_f16_f32", "v_pk_max_i16", "v_pk_mad_u16", "v_cvt_pk_f32_fp8", "v_med3_f32", "v_pk_mov_b32", "v_dot2_f32_f16" };
+    "v_cvt_f32_f16_sdwa src0_sel:WORD_1", "v_cvt_f32_u32_sdwa src0_sel:BYTE_1", "v_cvt_pkrtz_f16_f32", "v_pk_max_i16", "v_pk_mad_u16", "v_cvt_pk_f32_fp8", "v_med3_f32", "v_pk_mov_b32", "v_dot2_f32_f16",
+    "v_or_b32_sdwa src1_sel:BYTE_1 (VOP2 SDWA byte select: byte into a 0x4B000000 mantissa)", "v_or_b32_sdwa src1_sel:BYTE_3", "v_or_b32_sdwa with an SGPR src0, src1_sel:BYTE_2",
+    "v_and_b32_sdwa src1_sel:BYTE_1", "v_mul_u32_u24_sdwa src1_sel:BYTE_1", "v_add_u32_sdwa src1_sel:BYTE_1", "v_mov_b32_sdwa src0_sel:BYTE_1", "v_lshlrev_b32_sdwa src1_sel:BYTE_1",
+    "v_alignbit_b32", "v_alignbyte_b32",
+    "v_or_b32_sdwa BYTE_k + v_fma_f32 on its result (per instruction of the pair: the box test's byte -> plane distance)",
+    "v_cvt_f32_ubyteK + v_fma_f32 on its result (per instruction of the pair: today's form)" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
@@ -149,6 +154,24 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
         if (KIND == K_PKMADU16) asm volatile(REP32("v_pk_mad_u16 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
         if (KIND == K_MED3) asm volatile(REP32("v_med3_f32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
         if (KIND == K_DOT2) asm volatile(ACC32("v_dot2_f32_f16 ", ", %8, %9, ") : OPS : "v"(s), "v"(t));
+        // VOP2 SDWA byte selects (round 5): is a byte-select form of a full-rate VOP2 op still full rate?  (v_or into 0x4B000000 turns a byte into the float 2^23 + q)
+#define SDWA1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+        if (KIND == K_OR_SDWA_B1) asm volatile(REP32("v_or_b32_sdwa ", ", %8, %9" SDWA1) : OPS : "v"(s), "v"(t));
+        if (KIND == K_OR_SDWA_B3) asm volatile(REP32("v_or_b32_sdwa ", ", %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3") : OPS : "v"(s), "v"(t));
+        if (KIND == K_OR_SDWA_SGPR) asm volatile(REP32("v_or_b32_sdwa ", ", %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2") : OPS : "s"(0x4B000000), "v"(t));
+        if (KIND == K_AND_SDWA) asm volatile(REP32("v_and_b32_sdwa ", ", %8, %9" SDWA1) : OPS : "v"(s), "v"(t));
+        if (KIND == K_MULU24_SDWA) asm volatile(REP32("v_mul_u32_u24_sdwa ", ", %8, %9" SDWA1) : OPS : "v"(s), "v"(t));
+        if (KIND == K_ADDU_SDWA) asm volatile(REP32("v_add_u32_sdwa ", ", %8, %9" SDWA1) : OPS : "v"(s), "v"(t));
+        if (KIND == K_MOV_SDWA) asm volatile(REP32("v_mov_b32_sdwa ", ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") : OPS : "v"(s), "v"(t));
+        if (KIND == K_LSHL_SDWA) asm volatile(REP32("v_lshlrev_b32_sdwa ", ", %8, %9" SDWA1) : OPS : "v"(s), "v"(t));
+        if (KIND == K_ALIGNBIT) asm volatile(REP32("v_alignbit_b32 ", ", %8, %9, 8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_ALIGNBYTE) asm volatile(REP32("v_alignbyte_b32 ", ", %8, %9, 1") : OPS : "v"(s), "v"(t));
+        // the pair as the box test uses it: 16 x (byte k of t -> float in r, then r = r * s + s); bytes 0..3 in turn
+#define PAIR_OR(r, b) "v_or_b32_sdwa " r ", %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" b "\n\tv_fma_f32 " r ", " r ", %8, %8\n\t"
+#define PAIR_CVT(r, b) "v_cvt_f32_ubyte" b " " r ", %9\n\tv_fma_f32 " r ", " r ", %8, %8\n\t"
+#define PAIRS8(P) P("%0", "0") P("%1", "1") P("%2", "2") P("%3", "3") P("%4", "0") P("%5", "1") P("%6", "2") P("%7", "3")
+        if (KIND == K_OR_SDWA_FMA) asm volatile(PAIRS8(PAIR_OR) PAIRS8(PAIR_OR) : OPS : "v"(s), "v"(t));
+        if (KIND == K_CVTUB_FMA) asm volatile(PAIRS8(PAIR_CVT) PAIRS8(PAIR_CVT) : OPS : "v"(s), "v"(t));
 #undef OPS
         if (KIND == K_CVTPKFP8)
             asm volatile(REP32("v_cvt_pk_f32_fp8 ", ", %8")
@@ -244,6 +267,8 @@ int main(int argc, char** argv)
     RUN(K_MINMAX_SWAP) RUN(K_DSW) RUN(K_DSR)
     RUN(K_FMAMIX_LO) RUN(K_FMAMIX_HI) RUN(K_PKFMA16) RUN(K_PKMAX16) RUN(K_PKMIN16) RUN(K_PKADD16) RUN(K_PKMUL16) RUN(K_CVT16) RUN(K_CVT16_SDWA) RUN(K_CVTUB_SDWA)
     RUN(K_PKRTZ) RUN(K_PKMAXI16) RUN(K_PKMADU16) RUN(K_CVTPKFP8) RUN(K_MED3) RUN(K_PKMOV) RUN(K_DOT2)
+    RUN(K_OR_SDWA_B1) RUN(K_OR_SDWA_B3) RUN(K_OR_SDWA_SGPR) RUN(K_AND_SDWA) RUN(K_MULU24_SDWA) RUN(K_ADDU_SDWA) RUN(K_MOV_SDWA) RUN(K_LSHL_SDWA) RUN(K_ALIGNBIT) RUN(K_ALIGNBYTE)
+    RUN(K_OR_SDWA_FMA) RUN(K_CVTUB_FMA)
     CHECK(hipFree(dOut));
     return 0;
 }
