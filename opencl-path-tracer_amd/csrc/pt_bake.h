@@ -227,6 +227,87 @@ __global__ void __launch_bounds__(128) k_refit_nodes(RefitNodeArgs a)
     a.wide[q] = out;
 }
 
+// ---- refit on the device alone (pt_refit_vertices, round 5): what refitBVH does on the host (reference src/bvh/refit_bvh.cpp:6-34) --------------------
+// The caller hands over nothing but the vertices of the deformed mesh; every box of the packed trees is recomputed here, bottom-up: the box
+// of a leaf slot from the vertices of its triangles, the box of an inner slot as the union of that child's slots.  One thread per packed node
+// computes its leaf slots; a node whose slots are all final (its own thread and one arrival per inner child, counted by an atomic) is
+// quantised by whoever arrives last, which then carries the node's union up to the parent's slot and goes on there (Karras 2012's bottom-up
+// pass on a 4-wide tree).  min / max are exact, so the boxes -- and the quantised planes -- are the bits k_refit_nodes makes from the caller's
+// own refitBVH: a context refitted this way and a fresh one on the host-refitted arrays hold the same bytes.
+struct RefitTreeArgs {
+    const VertexIn* verts;
+    const TriShade* tri; // vertex indices of every triangle of the caller's numbering
+    WideNode* wide; // in place: references stay, planes are re-made
+    WideBoxes* boxes;
+    const uint32_t* parent; // [node]: (parent node << 2) | slot, ~0: the root of a run
+    const uint32_t* need; // [node]: arrivals that complete it = inner children + 1
+    uint32_t* arrived; // [node]: zero between refits (the last arrival resets it)
+    uint32_t emptyRef, n;
+};
+__global__ void __launch_bounds__(128) k_refit_tree(RefitTreeArgs a)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.n)
+        return;
+    {
+        const WideNode w = a.wide[q];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = w.child[k];
+            if (r == a.emptyRef) {
+                for (int ax = 0; ax < 3; ax++)
+                    a.boxes[q].lo[k][ax] = 1.f, a.boxes[q].hi[k][ax] = -1.f;
+                continue;
+            }
+            if (refCount(r) == 0u)
+                continue; // an inner child: its own last arrival writes this slot
+            float lo[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f }, hi[3] = { -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f };
+            for (uint32_t t = refIndex(r); t < refIndex(r) + refCount(r); t++) {
+                const TriShade ts = a.tri[t];
+                const uint32_t vi[3] = { ts.i0, ts.i1, ts.i2 };
+                for (int c = 0; c < 3; c++) {
+                    const float4 p = a.verts[vi[c]].pos;
+                    lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+                    hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+                }
+            }
+            for (int ax = 0; ax < 3; ax++)
+                a.boxes[q].lo[k][ax] = lo[ax], a.boxes[q].hi[k][ax] = hi[ax];
+        }
+    }
+    uint32_t node = q;
+    while (true) {
+        __threadfence(); // what this thread wrote is visible before it is counted ...
+        const uint32_t arrivals = atomicAdd(&a.arrived[node], 1u) + 1u;
+        if (arrivals < a.need[node])
+            return; // somebody else completes this node
+        __threadfence(); // ... and what the others wrote is visible to the one that counts last
+        a.arrived[node] = 0u;
+        const volatile WideBoxes* vb = (const volatile WideBoxes*)&a.boxes[node];
+        const volatile WideNode* vw = (const volatile WideNode*)&a.wide[node];
+        float lo[4][3], hi[4][3], ulo[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f }, uhi[3] = { -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f };
+        uint32_t refs[4];
+        bool empty[4];
+        for (int k = 0; k < 4; k++) {
+            refs[k] = vw->child[k];
+            empty[k] = refs[k] == a.emptyRef;
+            for (int ax = 0; ax < 3; ax++) {
+                lo[k][ax] = vb->lo[k][ax], hi[k][ax] = vb->hi[k][ax];
+                if (!empty[k])
+                    ulo[ax] = fminf(ulo[ax], lo[k][ax]), uhi[ax] = fmaxf(uhi[ax], hi[k][ax]);
+            }
+        }
+        WideNode out;
+        quantiseWideNode(lo, hi, refs, empty, a.emptyRef, &out);
+        a.wide[node] = out;
+        const uint32_t p = a.parent[node];
+        if (p == 0xFFFFFFFFu)
+            return;
+        for (int ax = 0; ax < 3; ax++)
+            a.boxes[p >> 2].lo[p & 3u][ax] = ulo[ax], a.boxes[p >> 2].hi[p & 3u][ax] = uhi[ax];
+        node = p >> 2;
+    }
+}
+
 // one thread per triangle: the intersection record (v0, e1, e2: the very subtractions pt_upload_static does on the host, so that a refitted
 // context and a fresh one hold the same bits) and the 128-byte shading record, from the new vertices
 __global__ void __launch_bounds__(256) k_refit_tris(RefitArgs a)

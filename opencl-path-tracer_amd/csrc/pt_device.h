@@ -132,7 +132,9 @@ struct SceneDev {
     uint32_t numLights;
     uint32_t rootRef; // reference of the top-level root: a PairNode, or an instance when there is only one
     uint32_t numTriangles;
-    uint32_t firstWorldNode; // nodes below this index are object-space nodes of the mesh trees (reached through an instance); the top level, entry nodes and world-space copies come behind
+    uint32_t firstWorldNode; // nodes below this index are object-space nodes of the mesh trees (reached through an instance); the top level and the world-space copies come behind ...
+    uint32_t instRootBase; // ... and behind those, as the last run of the array, one object-space copy of its mesh's root node per instance (k_trace<., true>: pt_trace.h)
+    uint32_t numInstRoots; // copies in that run (0: no instance is folded)
 };
 
 // ---- queues ---------------------------------------------------------------------------------

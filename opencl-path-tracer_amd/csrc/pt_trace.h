@@ -34,7 +34,6 @@
 //    40.4: the near-first descent finds occluders sooner than fuller steps save.
 #pragma once
 #include "pt_shade.h"
-#include <type_traits>
 
 namespace ptd {
 
@@ -64,10 +63,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 #ifndef PT_LDS_STACK_TL
-#define PT_LDS_STACK_TL 10 // ... in the instantiations that enter instances: their lanes keep an instance state in LDS too (16 B), and 7 waves per SIMD leave 5.7 KB per wave
+#define PT_LDS_STACK_TL PT_LDS_STACK // ... in the instantiations that enter instances
 #endif
 constexpr int kLdsStackTL = PT_LDS_STACK_TL;
 constexpr int kTraversalStackMax = (kLdsStackTL < kLdsStack ? kLdsStackTL : kLdsStack) + 100; // what every instantiation can hold (LDS + spill, kSpillStack below)
+constexpr uint32_t kInstFoldTable = 128; // entries of the per-workgroup table of folded instance transforms (entry 0: the identity): scenes of up to 127 instances
 constexpr int kDescentStack = 3; // entries of a START stack (pt_descend.h: rays that leave one pixel's footprint take the way from the root to their origin together)
 static_assert(kDescentStack <= kLdsStack, "the hand-out copies a start stack into the LDS part of the lane's stack");
 constexpr int kSpillStack = 100; // further entries in global memory
@@ -113,6 +113,10 @@ struct TraceArgs {
     uint32_t* spill; // kSpillStack * totalThreads dwords
     uint32_t totalThreads;
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
+    // k_trace<., true>: the table of folded instance transforms, entry 1 + k = (1/s, w) of instance k (the identity for instances that take the general
+    // route), entry 0 = the identity; instFoldCount 0: nothing is folded (more instances than the table holds, parity mode, PT_FLAG_PARKED_INSTANCES)
+    const float4* instFold;
+    uint32_t instFoldCount;
     // k_trace<., ., true>: the start state of every queue entry, made by k_descend (pt_descend.h): x = the reference to continue with,
     // y z w = up to three stacked entries in stack order (kRefNone: unused)
     const uint4* start;
@@ -172,14 +176,16 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
     constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
     __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
-    // TWO_LEVEL, round 5: instances whose transform is a translation + uniform scale are traversed WITHOUT parking.  The lane keeps the world-space
-    // ray in its registers; while it walks object-space nodes / triangles (known from the reference alone: their indices lie below the
-    // first top-level node / below the first world-space triangle) the ray is taken into the instance's space on the fly,
+    // TWO_LEVEL, round 5: instances whose transform is a translation + uniform scale are traversed WITHOUT parking and without an entry step.
+    // The lane keeps the WORLD-space ray in its registers; while it walks object-space nodes / triangles -- known from the reference alone:
+    // node indices below the first top-level node or in the run of per-instance root copies, triangle indices of the caller's numbering --
+    // the ray is taken into the instance's space on the fly,
     //   o' = o * (1/s) + w,   1/d' = (1/d) * s,   d' = d * (1/s)        (t is shared between the spaces, scene.cl:118-121)
-    // from (1/s, w) kept per lane in LDS -- slot 64 of a wave holds the identity, which world-space steps read instead (o * 1 + 0 and
-    // d * 1 are exact): no branch, no parked step, seven more vector instructions per step.  The state arrives with the instance's ENTRY NODE
-    // (a one-child node in the top-level leaf's place that carries (1/s, w, instance) in its unused bytes: ptamd.hip, convertDynamic).
-    __shared__ float4 ldsInst[TWO_LEVEL ? kTraceBlock / 64 : 1][TWO_LEVEL ? 65 : 1];
+    // with (1/s, w) read from a per-workgroup LDS table indexed by the lane's current instance (entry 0 = the identity, read by world-space
+    // steps and, through their own identity entries, by lanes inside a general instance, whose registers hold the instance-space ray): no
+    // branch, no parked step.  The top-level leaf of such an instance refers to the instance's own copy of its mesh's root node (object space;
+    // the copies form the last run of the node array, copy k = instance k): reaching it sets the lane's instance.  (ptamd.hip, convertDynamic.)
+    __shared__ float4 ldsInstFold[TWO_LEVEL ? kInstFoldTable : 1];
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
@@ -193,10 +199,11 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
     if (ANY_HIT && lane == 0)
         ldsDeposits[wave] = 0u;
     if constexpr (TWO_LEVEL) {
-        ldsInst[wave][lane] = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (lane == 0)
-            ldsInst[wave][64] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < kInstFoldTable)
+            ldsInstFold[threadIdx.x] = threadIdx.x < a.instFoldCount ? a.instFold[threadIdx.x] : make_float4(1.f, 0.f, 0.f, 0.f);
+        __syncthreads();
     }
+    const bool fold = TWO_LEVEL && a.instFoldCount != 0u; // wave-uniform
 
     auto push = [&](int slot, uint32_t v) {
         if (slot < kLdsStack)
@@ -434,7 +441,6 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         V3 to, td;
                         rayIntoInstance(in.r0, in.r1, in.r2, wo, wd, &to, &td);
                         setRay(to, td);
-                        ldsInst[wave][lane] = make_float4(1.f, 0.f, 0.f, 0.f); // the registers hold the instance-space ray: nothing to fold
                         curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
                         push(sp, kRefLeaveInstance);
                         sp++;
@@ -551,8 +557,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
                     const uint4 A = wp[0], B = wp[1];
-                    typedef typename std::conditional<TWO_LEVEL, uint4, uint2>::type PlanesZ; // (TWO_LEVEL: the two spare words of the line carry an entry node's state)
-                    const PlanesZ C = *(const PlanesZ*)&wp[2];
+                    const uint2 C = *(const uint2*)&wp[2];
                     const uint4 D = wp[3];
 #ifdef PT_EXTRA_LOADS // diagnostic: how sensitive is the kernel to vector-memory instruction count?
                     uint32_t extra = 0;
@@ -568,14 +573,14 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     // the ray in the node's space (TWO_LEVEL: object-space nodes are seen through the lane's instance state, see the top)
                     V3 no = co, nid = cid;
                     if constexpr (TWO_LEVEL) {
-                        const float4 is = ldsInst[wave][refIndex(cur) < sc.firstWorldNode ? lane : 64u];
+                        const uint32_t ni = refIndex(cur), rk = ni - sc.instRootBase;
+                        if (rk < sc.numInstRoots) // an instance's copy of its mesh root: from here on (until the walk is back at world-space references) the lane is inside instance rk
+                            curInst = (int)rk;
+                        const bool object = ni - sc.firstWorldNode >= sc.instRootBase - sc.firstWorldNode; // (unsigned: below the first world-space node, or behind the last)
+                        const float4 is = ldsInstFold[fold && object ? (uint32_t)curInst + 1u : 0u];
                         const float scl = rcpFast(is.x);
                         no = mk(fmaf(co.x, is.x, is.y), fmaf(co.y, is.x, is.z), fmaf(co.z, is.x, is.w));
                         nid = mk(cid.x * scl, cid.y * scl, cid.z * scl);
-                        if (A.w >> 24) { // an entry node: from here on (until the walk comes back to world-space references) the lane is inside this instance
-                            ldsInst[wave][lane] = make_float4(asF(D.y), asF(D.z), asF(D.w), asF(C.z));
-                            curInst = (int)C.w;
-                        }
                     }
                     // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
                     const float ax = asF((A.w & 0xFFu) << 23) * nid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * nid.y,
@@ -687,7 +692,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     bool inObject = false;
                     if constexpr (TWO_LEVEL) {
                         inObject = first < sc.numTriangles + 1u; // the caller's (object-space) triangles; world-space copies come behind them
-                        const float4 is = ldsInst[wave][inObject ? lane : 64u];
+                        const float4 is = ldsInstFold[fold && inObject ? (uint32_t)curInst + 1u : 0u];
                         lo_ = mk(fmaf(co.x, is.x, is.y), fmaf(co.y, is.x, is.z), fmaf(co.z, is.x, is.w)); // rayIntoInstance's arithmetic for such a matrix, bit for bit
                         ld_ = mk(cd.x * is.x, cd.y * is.x, cd.z * is.x);
                     }

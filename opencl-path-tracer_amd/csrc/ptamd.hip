@@ -102,7 +102,9 @@ struct pt_ctx {
         hipEvent_t stageRead = nullptr; // recorded on the copy stream after the copies out of `stage`
         bool stageBusy = false;
         uint32_t numLights = 0, rootRef = 0;
-        uint32_t foldedInstances = 0;
+        uint32_t foldedInstances = 0, instRootBase = 0, numInstRoots = 0;
+        DevBuf<float4> instFold; // the table of folded instance transforms (pt_trace.h)
+        uint32_t instFoldCount = 0;
         uint32_t rootRefFolded = 0; // the same top level for the per-ray kernels: entry nodes in place of the instances that are a translation + uniform scale (pt_trace.h)
         bool packetOk = false;
         uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
@@ -149,6 +151,11 @@ struct pt_ctx {
         DevBuf<pt_sub_bvh_node> dNodes; // the caller's nodes as last handed in
         DevBuf<uint32_t> dKidBoxNode;
         DevBuf<float> dExtra;
+        // refit on the device alone (pt_refit_vertices): who a packed node reports to and how many arrivals complete it (k_refit_tree, pt_bake.h)
+        DevBuf<uint32_t> dParent, dNeed, dArrived;
+        uint64_t refitTablesFor = 0; // topology the tables were made for (0: none)
+        bool refitTablesOk = false; // false: a node has two parents (roots that share a subtree): the caller refits on the host (pt_update_geometry)
+        uint64_t topology = 0; // bumped by every buildStaticGeom
         bool latestInStage = false; // the caller's latest vertices and nodes live in `stage` (vertices first), not in rawVerts / hostSubNodes
         void* stage = nullptr;
         size_t stageBytes = 0;
@@ -169,6 +176,7 @@ struct pt_ctx {
     bool mergePending = false;
     std::vector<VertexShade> hostVerts;
     std::vector<pt_vertex> rawVerts; // the caller's vertices as last handed in (pt_upload_static / pt_update_geometry)
+    bool hostNodeBoxesStale = false; // the boxes in hostSubNodes are older than rawVerts (pt_refit_vertices: the device refitted its own tree, nobody handed nodes in)
     bool hostGeomStale = false; // hostTris / hostVerts / hostBottomNodes' boxes / sg.wide / sg.boxes / sg.fat are older than the caller's latest arrays (a refit
                                 // re-makes the device's copies on the device only; the host's are refreshed if the whole conversion ever runs again)
     std::vector<uint32_t> denseOfNode; // caller's sub-BVH node -> pair node (0xFFFFFFFF: a leaf or a pad)
@@ -297,6 +305,8 @@ void refreshSceneView(pt_ctx* c)
     s.numLights = d.numLights;
     s.rootRef = d.rootRef;
     s.firstWorldNode = (uint32_t)c->sg.wide.size();
+    s.instRootBase = d.numInstRoots ? d.instRootBase : 0x7FFFFFFFu; // (nothing folded: no node lies behind the world-space ones)
+    s.numInstRoots = d.numInstRoots;
     s.materialTex.texels = c->texMaterial.p;
     s.sky.texels = c->texSky.p;
     s.numTriangles = c->numTris;
@@ -710,10 +720,45 @@ inline const pt_sub_bvh_node* latestNodes(const pt_ctx* c)
 
 // The host's mirrors from the caller's arrays as last handed in (a refit re-makes the device's records on the device and leaves these behind): pair-node
 // boxes, the packed nodes, hostTris / hostVerts.
+// the caller's node boxes recomputed from the latest vertices (what refitBVH leaves, reference src/bvh/refit_bvh.cpp:6-34): after a refit on
+// the device alone nobody handed refitted nodes in.  Children lie after their parent (validated at upload): one reverse sweep.
+void refitHostNodeBoxes(pt_ctx* c)
+{
+    const pt_vertex* verts = c->rawVerts.data();
+    std::vector<pt_sub_bvh_node>& nodes = c->hostSubNodes;
+    for (size_t i = nodes.size(); i-- > 0;) {
+        pt_sub_bvh_node& n = nodes[i];
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        if (n.triangleCount != 0) {
+            for (uint32_t t = n.leftChildOrFirstTriangle; t < n.leftChildOrFirstTriangle + n.triangleCount; t++) {
+                const TriShade& ts = c->hostTriShade[t];
+                for (uint32_t vi : { ts.i0, ts.i1, ts.i2 })
+                    for (int a = 0; a < 3; a++)
+                        lo[a] = fminf(lo[a], verts[vi].vertex[a]), hi[a] = fmaxf(hi[a], verts[vi].vertex[a]);
+            }
+        } else {
+            if (c->denseOfNode[i] == 0xFFFFFFFFu)
+                continue; // an unused pad
+            const pt_sub_bvh_node &L = nodes[n.leftChildOrFirstTriangle], &R = nodes[n.leftChildOrFirstTriangle + 1];
+            for (int a = 0; a < 3; a++)
+                lo[a] = fminf(L.min[a], R.min[a]), hi[a] = fmaxf(L.max[a], R.max[a]);
+        }
+        for (int a = 0; a < 3; a++)
+            n.min[a] = lo[a], n.max[a] = hi[a];
+    }
+    c->hostNodeBoxesStale = false;
+}
+
 void refreshHostGeometry(pt_ctx* c)
 {
     if (!c->hostGeomStale)
         return;
+    if (c->hostNodeBoxesStale) { // (rawVerts is current then: pt_refit_vertices keeps it so)
+        refitHostNodeBoxes(c);
+        refitPairBoxes(c, c->rawVerts.data(), c->hostSubNodes.data(), false);
+        if (c->sg.wide.size() == c->sg.kidEmpty.size() / 4)
+            refitWideOnHost(c);
+    }
     const pt_vertex* verts = latestVerts(c);
     if (c->sg.latestInStage) {
         refitPairBoxes(c, verts, latestNodes(c), false);
@@ -898,6 +943,7 @@ int buildStaticGeom(pt_ctx* c)
     buildFat(c);
     g.emptyRef = emptyRef;
     g.version++;
+    g.topology++;
     g.onDevice = false;
     return PT_OK;
 }
@@ -1124,8 +1170,10 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stre
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
     TraceArgs a = args;
-    if (twoLevel) // the per-ray kernels walk the top level that holds entry nodes (the packet kernels and k_descend: the one with instance references)
+    if (twoLevel) { // the per-ray kernels walk the top level in which folded instances are plain inner references (the packet kernels and k_descend: the one with instance references)
         a.sc.rootRef = c->dyn[c->active].rootRefFolded;
+        a.instFold = c->dyn[c->active].instFold.p, a.instFoldCount = c->dyn[c->active].instFoldCount;
+    }
     const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
     if (!stream)
         stream = c->stream;
@@ -1758,7 +1806,7 @@ void pt_destroy(pt_ctx* c)
     c->texMaterial.release(), c->texSky.release();
     c->nodes.release(), c->materials.release();
     for (auto& d : c->dyn) {
-        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release(), d.jobs.release();
+        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release(), d.jobs.release(), d.instFold.release();
         if (d.stage) (void)hipHostFree(d.stage);
         if (d.stageRead) (void)hipEventDestroy(d.stageRead);
         if (d.uploaded) (void)hipEventDestroy(d.uploaded);
@@ -1766,6 +1814,7 @@ void pt_destroy(pt_ctx* c)
     }
     c->sg.dWide.release(), c->sg.dBoxes.release(), c->sg.dLeafOfs.release(), c->sg.dRefTri.release(), c->sg.dTris.release(), c->sg.dFat.release();
     c->sg.dVerts.release(), c->triShade.release(), c->sg.dNodes.release(), c->sg.dKidBoxNode.release(), c->sg.dExtra.release();
+    c->sg.dParent.release(), c->sg.dNeed.release(), c->sg.dArrived.release();
     if (c->sg.stage) (void)hipHostFree(c->sg.stage);
     if (c->sg.stageRead) (void)hipEventDestroy(c->sg.stageRead);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
@@ -1870,18 +1919,44 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
             hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
         }
     };
-    // leaves larger than kMaxLeafTris become a small median-split subtree over their triangle range
+    // leaves larger than `maxLeaf` triangles become a small subtree over their triangle range (kMaxLeafTris: what a reference can address).
+    // PTAMD_MAX_LEAF=n (diagnostics, round 5): split the caller's leaves down to n triangles -- the reference's builders stop at <= 3
+    // (src/bvh/bvh_build.cpp:15), and a leaf step of this kernel runs to the longest leaf among its lanes.
+    uint32_t maxLeaf = kMaxLeafTris;
+    if (const char* e = getenv("PTAMD_MAX_LEAF"))
+        maxLeaf = std::max(1u, std::min((uint32_t)atoi(e), kMaxLeafTris));
     struct Range {
         uint32_t first, count;
     };
+    auto rangeBox = [&](Range r, V3& lo, V3& hi) {
+        lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
+        for (uint32_t t = 0; t < r.count; t++)
+            triBox(r.first + t, lo, hi);
+    };
+    auto halfArea = [](V3 lo, V3 hi) {
+        const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
     std::function<uint32_t(Range, V3&, V3&)> leafRef = [&](Range r, V3& lo, V3& hi) -> uint32_t {
         lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
-        if (r.count <= kMaxLeafTris) {
+        if (r.count <= maxLeaf) {
             for (uint32_t t = 0; t < r.count; t++)
                 triBox(r.first + t, lo, hi);
             return makeRef(r.first, r.count);
         }
-        const uint32_t half = r.count / 2;
+        // the range stays in the caller's order (a leaf is a run of it): cut where the two runs' surface-area cost is smallest
+        uint32_t half = r.count / 2;
+        if (r.count <= 8u) {
+            float best = FLT_MAX;
+            for (uint32_t cut = 1; cut < r.count; cut++) {
+                V3 alo, ahi, blo, bhi;
+                rangeBox({ r.first, cut }, alo, ahi);
+                rangeBox({ r.first + cut, r.count - cut }, blo, bhi);
+                const float cost = halfArea(alo, ahi) * (float)cut + halfArea(blo, bhi) * (float)(r.count - cut);
+                if (cost < best)
+                    best = cost, half = cut;
+            }
+        }
         V3 llo, lhi, rlo, rhi;
         const uint32_t l = leafRef({ r.first, half }, llo, lhi);
         const uint32_t rr = leafRef({ r.first + half, r.count - half }, rlo, rhi);
@@ -1899,7 +1974,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     c->nodeRef.assign(nN, kRefNone);
     for (uint32_t i = 0; i < nN; i++) {
         if (nodes[i].triangleCount != 0) {
-            if (nodes[i].triangleCount <= kMaxLeafTris) {
+            if (nodes[i].triangleCount <= maxLeaf) {
                 c->nodeRef[i] = makeRef(nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount);
             } else {
                 V3 lo, hi;
@@ -1930,7 +2005,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     for (uint32_t i = nN; i-- > 0;) {
         if (dense[i] == 0xFFFFFFFFu) {
             uint32_t extra = 0;
-            for (uint32_t cnt = nodes[i].triangleCount; cnt > kMaxLeafTris; cnt = (cnt + 1) / 2)
+            for (uint32_t cnt = nodes[i].triangleCount; cnt > maxLeaf; cnt = cnt > 8u ? (cnt + 1) / 2 : cnt - 1) // (the cost-driven cut of a short run may peel one triangle off per level)
                 extra++;
             c->subtreeDepth[i] = extra;
         } else {
@@ -2088,6 +2163,113 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
     });
 }
 
+// Who a packed node reports to in a bottom-up pass, and how many arrivals complete it (k_refit_tree).  Made once per topology.
+static int ensureRefitTables(pt_ctx* c)
+{
+    pt_ctx::StaticGeom& g = c->sg;
+    if (g.refitTablesFor == g.topology)
+        return PT_OK;
+    const size_t n = g.wide.size();
+    std::vector<uint32_t> parent(n, 0xFFFFFFFFu), need(n, 1u);
+    bool ok = true;
+    for (size_t q = 0; q < n; q++)
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = g.wide[q].child[k];
+            if (r == g.emptyRef || refCount(r) != 0u)
+                continue;
+            const uint32_t ch = refIndex(r);
+            if (ch >= n || ch == q || parent[ch] != 0xFFFFFFFFu) { // (two parents: roots that share a subtree -- the bottom-up pass would complete the child once and leave one parent waiting)
+                ok = false;
+                continue;
+            }
+            parent[ch] = ((uint32_t)q << 2) | (uint32_t)k;
+            need[q]++;
+        }
+    g.refitTablesOk = ok;
+    g.refitTablesFor = g.topology;
+    if (!ok)
+        return PT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->copyStream)); // (an earlier refit may still be walking the old tables)
+    int rc;
+    if ((rc = uploadVec(c, g.dParent, parent)) || (rc = uploadVec(c, g.dNeed, need)))
+        return rc;
+    HIPCHK(c, g.dArrived.alloc(std::max<size_t>(n, 1)));
+    HIPCHK(c, hipMemset(g.dArrived.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+    return PT_OK;
+}
+
+// A deformed frame of the same topology, refitted ON THE DEVICE: the caller hands over the vertices of the mesh that moved -- `nV` records that
+// replace [firstVertex, firstVertex + nV) of the vertex array pt_upload_static took -- and nothing else.  The device re-makes the triangles'
+// intersection and shading records (k_refit_tris) and recomputes every box of its packed trees bottom-up from the triangles (k_refit_tree:
+// what refitBVH does on the host in the reference, src/bvh/refit_bvh.cpp:6-34, and what pt_update_geometry expects the caller to have done),
+// on the copy stream, nothing synchronised.  Takes effect with the next pt_upload_dynamic(_async) + pt_frame_tick, like pt_update_geometry.
+// The host's share of a tick is one copy of the moved vertices into pinned memory.
+int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, uint32_t nV)
+{
+    return guarded(c, "pt_refit_vertices", [&]() -> int {
+        if (!c)
+            return PT_ERR_INVALID;
+        if (!c->haveStatic)
+            return fail(c, PT_ERR_STATE, "pt_refit_vertices: call pt_upload_static first");
+        if (!verts || nV == 0 || (uint64_t)firstVertex + nV > c->numVerts)
+            return fail(c, PT_ERR_INVALID, "pt_refit_vertices: [%u, %u + %u) is not a range of the %u uploaded vertices", firstVertex, firstVertex, nV, c->numVerts);
+        HIPCHK(c, hipSetDevice(c->device));
+        pt_ctx::StaticGeom& g = c->sg;
+        int rc;
+        if ((rc = uploadStaticGeom(c)) || (rc = ensureRefitTables(c))) // (the master copy reaches the device with the first dynamic upload at the latest)
+            return rc;
+        if (!g.refitTablesOk)
+            return fail(c, PT_ERR_UNSUPPORTED, "pt_refit_vertices: two roots of the sub-BVH array share a subtree: refit on the host and use pt_update_geometry");
+        // the host's copy of the caller's arrays: rawVerts takes the new vertices; the node boxes go stale (nobody refits them here) and are
+        // recomputed from the vertices only if the whole conversion ever runs again (refreshHostGeometry)
+        if (g.latestInStage) { // an earlier pt_update_geometry left the latest arrays in the staging memory: take them over first
+            if (g.stageBusy) {
+                HIPCHK(c, hipEventSynchronize(g.stageRead));
+                g.stageBusy = false;
+            }
+            const pt_vertex* sv = latestVerts(c);
+            const pt_sub_bvh_node* sn = latestNodes(c);
+            c->rawVerts.assign(sv, sv + c->numVerts);
+            c->hostSubNodes.assign(sn, sn + c->numRefNodes);
+            g.latestInStage = false;
+        }
+        std::memcpy(c->rawVerts.data() + firstVertex, verts, (size_t)nV * sizeof(pt_vertex));
+        c->hostNodeBoxesStale = true;
+        c->hostGeomStale = true;
+        const size_t bytesV = (size_t)nV * sizeof(pt_vertex);
+        if (!g.stageRead)
+            HIPCHK(c, hipEventCreateWithFlags(&g.stageRead, hipEventDisableTiming));
+        if (g.stageBusy) { // the previous refit's copy out of the staging memory (normally long done)
+            HIPCHK(c, hipEventSynchronize(g.stageRead));
+            g.stageBusy = false;
+        }
+        if (g.stageBytes < bytesV) {
+            if (g.stage)
+                (void)hipHostFree(g.stage);
+            g.stage = nullptr;
+            g.stageBytes = bytesV + bytesV / 8;
+            HIPCHK(c, hipHostMalloc(&g.stage, g.stageBytes, hipHostMallocDefault));
+        }
+        std::memcpy(g.stage, verts, bytesV);
+        g.version++;
+        HIPCHK(c, hipMemcpyAsync(g.dVerts.p + firstVertex, g.stage, bytesV, hipMemcpyHostToDevice, c->copyStream));
+        HIPCHK(c, hipEventRecord(g.stageRead, c->copyStream));
+        g.stageBusy = true;
+        static_assert(sizeof(VertexIn) == sizeof(pt_vertex), "the refit kernels read the caller's vertex records as they are");
+        if (!g.wide.empty()) {
+            RefitTreeArgs rt {};
+            rt.verts = (const VertexIn*)g.dVerts.p, rt.tri = c->triShade.p, rt.wide = g.dWide.p, rt.boxes = g.dBoxes.p;
+            rt.parent = g.dParent.p, rt.need = g.dNeed.p, rt.arrived = g.dArrived.p, rt.emptyRef = g.emptyRef, rt.n = (uint32_t)g.wide.size();
+            hipLaunchKernelGGL(k_refit_tree, dim3((rt.n + 127u) / 128u), dim3(128), 0, c->copyStream, rt);
+        }
+        RefitArgs ra {};
+        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->triShade.p, ra.mats = c->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->numTris;
+        hipLaunchKernelGGL(k_refit_tris, dim3((c->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
+        HIPCHK(c, hipGetLastError());
+        return PT_OK;
+    });
+}
+
 } // extern "C"
 
 namespace {
@@ -2101,7 +2283,10 @@ struct DynamicHost {
     std::vector<BakeJob> jobs;
     std::vector<uint32_t> instanceTopNode;
     uint32_t numLights = 0, rootRef = 0, rootRefFolded = 0;
-    uint32_t foldedInstances = 0; // instances the per-ray kernels traverse through an entry node (no parked enter / leave)
+    uint32_t foldedInstances = 0; // instances the per-ray kernels walk without parking (translation + uniform scale, pt_trace.h)
+    std::vector<WideNode> instRoots; // their copies of their meshes' root nodes (one slot per instance), stored at instRootBase: the last run of the node array
+    std::vector<float4> instFold; // entry 1 + k: (1 / s, w) of instance k; entry 0 and the instances on the general route: the identity
+    uint32_t instRootBase = 0;
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
     uint32_t bakedNodes = 0, bakedTris = 0;
     bool packetOk = false, hasInstances = false;
@@ -2166,10 +2351,11 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             numTopInner++;
         }
     }
-    // node slots of the top level: [the top level with instance references (<= numTopInner nodes) | one entry node per instance | the same top level
-    // with entry nodes for the per-ray kernels (<= numTopInner)]; the world-space copies start behind them
-    const uint32_t entryBase = staticNodes + numTopInner, foldedBase = entryBase + (uint32_t)hInst.size();
-    out.topSlots = 2u * numTopInner + (uint32_t)hInst.size();
+    // node slots of the top level: [the top level with instance references (<= numTopInner nodes) | the same top level for the per-ray kernels, which
+    // walk translated + uniformly scaled instances without parking (<= numTopInner)]; the world-space copies start behind them, the instances' root
+    // copies (one slot per instance) come last
+    const uint32_t foldedBase = staticNodes + numTopInner;
+    out.topSlots = 2u * numTopInner;
     // ---- instances copied to world space --------------------------------------------------------------------
     // An instance costs every ray that enters it a transform in and a restore out on top of the traversal proper.  With 288 GB of
     // HBM the instanced geometry of scenes like the benchmark's (12 x 82 k triangles: ~110 MB of nodes and triangles) simply fits
@@ -2236,7 +2422,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     // one pending entry per level of either tree + the leave-instance sentinel
     if (topDepth + 1 + maxBottomDepth > (uint32_t)kTraversalStackMax)
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth %u (top) + %u (bottom) exceeds the traversal stack (%d)", topDepth, maxBottomDepth, kTraversalStackMax);
-    if ((uint64_t)staticNodes + out.topSlots + out.bakedNodes > kRefIndexMask)
+    if ((uint64_t)staticNodes + out.topSlots + out.bakedNodes + hInst.size() > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
     // ---- the top level: pair nodes -> 4-wide, packed breadth-first into the slots behind the static nodes -----------------
     std::vector<PairNode> topPairs(numTopInner);
@@ -2324,27 +2510,32 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     // k_trace_packet keeps its stack in the 64 lanes of a register (instance references are entered there too, pt_packet.h)
     out.packetOk = stackNeed <= kPacketStack;
     out.stackNeed = stackNeed;
-    // ---- the top level once more, for the per-ray kernels: ENTRY NODES in place of the entered instances whose transform is a translation + uniform scale
-    // (the reference's own scenes, BASELINE configs 4 / 5).  An entry node is a one-child 4-wide node -- the instance's world-space box, the mesh root below it
-    // -- whose unused bytes carry (1 / s, w = -t / s) of the inverse transform and the instance index: a lane that walks over it takes its ray into
-    // the instance's space on the fly from then on (pt_trace.h) instead of parking twice per visit.  Same pairs, same boxes, hence the same collapse
-    // and the same worst-case stack (an entry node pushes nothing; the sentinel of a parked entry is the one entry more the bound above holds).
+    // ---- the top level once more, for the per-ray kernels: instances whose transform is a translation + uniform scale (the reference's own scenes,
+    // BASELINE configs 4 / 5) are walked WITHOUT parking (pt_trace.h).  In this copy of the top level such an instance is an ordinary inner reference
+    // -- to the instance's own copy of its mesh's ROOT node (object space, 64 bytes; the copies are the LAST run of the node array, copy k = instance
+    // k) -- and (1 / s, w = -t / s) of its inverse transform sits in a table the kernel keeps in LDS.  Same pairs, same boxes, hence the same
+    // collapse and a worst-case stack no larger than the one computed above (no sentinel).
     out.rootRefFolded = rootRef;
     out.foldedInstances = 0;
+    out.instRoots.clear();
+    out.instFold.clear();
+    out.instRootBase = staticNodes + out.topSlots + out.bakedNodes;
     {
         static const bool envNoFold = getenv("PTAMD_NO_FOLDED_INSTANCES") != nullptr; // diagnostics: every entered instance takes the parked route (rounds 2-4)
-        const bool noFold = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u;
+        const bool noFold = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u || parityMode(c) // (parity mode follows the reference to the letter)
+            || hInst.size() + 1 > kInstFoldTable;
         auto simple = [](const Instance& in) {
             const float a = in.r0.x;
             return a > 0.f && std::isfinite(a) && in.r1.y == a && in.r2.z == a && in.r0.y == 0.f && in.r0.z == 0.f && in.r1.x == 0.f && in.r1.z == 0.f && in.r2.x == 0.f
                 && in.r2.y == 0.f && std::isfinite(in.r0.w) && std::isfinite(in.r1.w) && std::isfinite(in.r2.w);
         };
         std::vector<uint8_t> folded(hInst.size(), 0);
-        for (size_t k = 0; k < hInst.size() && !noFold && !parityMode(c); k++) // (parity mode follows the reference to the letter)
+        for (size_t k = 0; k < hInst.size() && !noFold; k++)
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial && simple(hInst[k]))
                 folded[k] = 1, out.foldedInstances++;
         if (out.foldedInstances) {
-            auto foldRef = [&](uint32_t r) { return refCount(r) == kRefSpecial && refIndex(r) < hInst.size() && folded[refIndex(r)] ? makeRef(entryBase + refIndex(r), 0u) : r; };
+            const uint32_t instRootBase = out.instRootBase;
+            auto foldRef = [&](uint32_t r) { return refCount(r) == kRefSpecial && refIndex(r) < hInst.size() && folded[refIndex(r)] ? makeRef(instRootBase + refIndex(r), 0u) : r; };
             std::vector<PairNode> pairsB = topPairs;
             for (PairNode& pn : pairsB)
                 pn.left = foldRef(pn.left), pn.right = foldRef(pn.right);
@@ -2364,35 +2555,41 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
                     }
                 rootB = makeRef(foldedBase, 0u);
             }
-            out.topWide.resize((size_t)(foldedBase - staticNodes) + orderB.size()); // (the gap behind the first top level stays zero: never referenced)
-            for (size_t k = 0; k < hInst.size(); k++) {
-                if (!folded[k])
-                    continue;
-                const pt_top_bvh_node& leaf = topNodes[hInst[k].topNode];
-                float lo[4][3], hi[4][3];
-                const uint32_t refs[4] = { hInst[k].rootRef, sg.emptyRef, sg.emptyRef, sg.emptyRef };
-                const bool empty[4] = { false, true, true, true };
-                for (int a = 0; a < 3; a++) {
-                    lo[0][a] = leaf.min[a], hi[0][a] = leaf.max[a];
-                    for (int q = 1; q < 4; q++)
-                        lo[q][a] = 1.f, hi[q][a] = -1.f;
-                }
-                WideNode e;
-                quantiseWideNode(lo, hi, refs, empty, sg.emptyRef, &e);
-                auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-                e.exps |= 1u << 24; // "entry node": the words below are not references
-                e.child[1] = bits(hInst[k].r0.x), e.child[2] = bits(hInst[k].r0.w), e.child[3] = bits(hInst[k].r1.w);
-                e._pad0 = bits(hInst[k].r2.w), e._pad1 = (uint32_t)k;
-                out.topWide[(size_t)(entryBase - staticNodes) + k] = e;
-            }
+            out.topWide.resize((size_t)numTopInner + orderB.size()); // (the gap behind the first top level stays zero: never referenced)
             for (size_t q = 0; q < orderB.size(); q++) {
                 const WideKids& wk = kidsB[orderB[q]];
                 uint32_t refs[4];
                 for (int k = 0; k < 4; k++)
                     refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(foldedBase + newB[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
-                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[(size_t)(foldedBase - staticNodes) + q]);
+                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[(size_t)numTopInner + q]);
             }
             out.rootRefFolded = rootB;
+            // the instances' root copies and the table of their transforms (entry 0: the identity; instances on the general route: the identity too --
+            // their lanes hold the instance-space ray in registers)
+            out.instRoots.assign(hInst.size(), WideNode {});
+            out.instFold.assign(hInst.size() + 1, make_float4(1.f, 0.f, 0.f, 0.f));
+            for (size_t k = 0; k < hInst.size(); k++) {
+                if (!folded[k])
+                    continue;
+                const Instance& in = hInst[k];
+                out.instFold[k + 1] = make_float4(in.r0.x, in.r0.w, in.r1.w, in.r2.w);
+                if (refCount(in.rootRef) == 0u) {
+                    out.instRoots[k] = sg.wide[refIndex(in.rootRef)]; // the mesh's packed root node as it is: object space, children in the shared tree
+                } else { // the mesh is a single leaf: a one-child node around it -- the top-level leaf's box taken into object space, a few ulps outwards
+                    const pt_top_bvh_node& leaf = topNodes[in.topNode];
+                    float lo[4][3], hi[4][3];
+                    const uint32_t refs[4] = { in.rootRef, sg.emptyRef, sg.emptyRef, sg.emptyRef };
+                    const bool empty[4] = { false, true, true, true };
+                    const float w[3] = { in.r0.w, in.r1.w, in.r2.w };
+                    for (int a = 0; a < 3; a++) {
+                        const double l = (double)leaf.min[a] * in.r0.x + w[a], h = (double)leaf.max[a] * in.r0.x + w[a];
+                        lo[0][a] = nextafterf(nextafterf((float)l, -INFINITY), -INFINITY), hi[0][a] = nextafterf(nextafterf((float)h, INFINITY), INFINITY);
+                        for (int q = 1; q < 4; q++)
+                            lo[q][a] = 1.f, hi[q][a] = -1.f;
+                    }
+                    quantiseWideNode(lo, hi, refs, empty, sg.emptyRef, &out.instRoots[k]);
+                }
+            }
         }
     }
     std::vector<Light>& hLights = out.lights;
@@ -2460,12 +2657,13 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     if (d.used)
         HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
     const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->numTris + 1;
-    const size_t needWide = staticNodes + h.topSlots + h.bakedNodes, needTris = staticTris + h.bakedTris;
-    const size_t bytes[4] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
-        h.jobs.size() * sizeof(BakeJob) };
-    const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3];
+    const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size(), needTris = staticTris + h.bakedTris;
+    const size_t bytes[6] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
+        h.jobs.size() * sizeof(BakeJob), h.instRoots.size() * sizeof(WideNode), h.instFold.size() * sizeof(float4) };
+    const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4] + bytes[5];
     if (d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1)
-        || d.lights.n < std::max<size_t>(h.lights.size(), 1) || d.jobs.n < std::max<size_t>(h.jobs.size(), 1) || d.stageBytes < std::max<size_t>(total, 1)) {
+        || d.lights.n < std::max<size_t>(h.lights.size(), 1) || d.jobs.n < std::max<size_t>(h.jobs.size(), 1) || d.instFold.n < std::max<size_t>(h.instFold.size(), 1)
+        || d.stageBytes < std::max<size_t>(total, 1)) {
         // growing frees device memory, which the runtime only does once nothing uses it: wait for both streams (rare: the first
         // uploads, or a state with more world-space copies than any before)
         HIPCHK(c, hipStreamSynchronize(c->copyStream));
@@ -2473,7 +2671,8 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
             HIPCHK(c, hipEventSynchronize(d.lastUse));
         const bool regrown = d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size();
         if ((rc = growTo(c, d.wide, needWide)) || (rc = growTo(c, d.tris, needTris)) || (rc = growTo(c, d.fat, sg.fat.size()))
-            || (rc = growTo(c, d.instances, h.instances.size())) || (rc = growTo(c, d.lights, h.lights.size())) || (rc = growTo(c, d.jobs, h.jobs.size())))
+            || (rc = growTo(c, d.instances, h.instances.size())) || (rc = growTo(c, d.lights, h.lights.size())) || (rc = growTo(c, d.jobs, h.jobs.size()))
+            || (rc = growTo(c, d.instFold, h.instFold.size())))
             return rc;
         if (regrown)
             d.staticVersion = 0; // fresh buffers: the static arrays have to be put in again
@@ -2499,9 +2698,9 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         d.staticVersion = sg.version;
     }
     unsigned char* st = (unsigned char*)d.stage;
-    const void* src[4] = { h.topWide.data(), h.instances.data(), h.lights.data(), h.jobs.data() };
-    void* dst[4] = { d.wide.p + staticNodes, d.instances.p, d.lights.p, d.jobs.p };
-    for (int k = 0; k < 4; k++) {
+    const void* src[6] = { h.topWide.data(), h.instances.data(), h.lights.data(), h.jobs.data(), h.instRoots.data(), h.instFold.data() };
+    void* dst[6] = { d.wide.p + staticNodes, d.instances.p, d.lights.p, d.jobs.p, d.wide.p + h.instRootBase, d.instFold.p };
+    for (int k = 0; k < 6; k++) {
         if (bytes[k] == 0)
             continue;
         std::memcpy(st, src[k], bytes[k]);
@@ -2534,6 +2733,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     d.rootRef = h.rootRef;
     d.rootRefFolded = h.rootRefFolded;
     d.foldedInstances = h.foldedInstances;
+    d.instRootBase = h.instRootBase, d.numInstRoots = (uint32_t)h.instRoots.size(), d.instFoldCount = (uint32_t)h.instFold.size();
     d.packetOk = h.packetOk;
     d.stackNeed = h.stackNeed;
     d.hasInstances = h.hasInstances;

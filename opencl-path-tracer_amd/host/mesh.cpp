@@ -1,4 +1,5 @@
 #include "mesh.h"
+#include "parallel.h"
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -68,6 +69,7 @@ void Mesh::storeBvh(const std::string& fileName) const
     std::ofstream out(fileName, std::ios::out | std::ios::binary | std::ios::trunc);
     if (!out)
         throw std::runtime_error("cannot write " + fileName);
+    refittedBvh(); // (the boxes of a refitted mesh are made when asked for)
     const uint32_t root = m_bvh.rootNode, numNodes = (uint32_t)m_bvh.nodes.size(), numTriangles = (uint32_t)m_bvh.triangles.size();
     out.write((const char*)&BVH_FILE_FORMAT_VERSION, 4);
     out.write((const char*)&root, 4);
@@ -349,20 +351,52 @@ std::shared_ptr<Mesh> Mesh::fromOBJ(const std::string& path, const Material* ove
 
 void Mesh::generateSmoothNormals()
 {
-    // area-weighted smooth normals (cross product length = 2*area)
-    const size_t numVertices = m_vertices.size();
-    std::vector<vec3> acc(numVertices);
-    for (const auto& tri : m_inputTriangles) {
-        auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
-        vec3 n = cross(P(1) - P(0), P(2) - P(0));
-        for (int k = 0; k < 3; k++)
-            acc[tri.indices[k]] += n;
+    // area-weighted smooth normals (cross product length = 2*area): normal(v) = normalize(sum of the face normals of the triangles at v).
+    // Two passes, each over disjoint ranges on the library's worker threads: face normals, then per vertex the sum over its incident
+    // triangles in ascending triangle order -- the order a scatter over the triangles adds them in, so the result does not depend on
+    // the number of threads (and is what the single-threaded scatter of rounds 1-4 produced).
+    const size_t numVertices = m_vertices.size(), numTriangles = m_inputTriangles.size();
+    if (m_cornerStart.size() != numVertices + 1) { // the topology never changes: built once
+        m_cornerStart.assign(numVertices + 1, 0);
+        for (const auto& tri : m_inputTriangles)
+            for (int k = 0; k < 3; k++)
+                m_cornerStart[tri.indices[k] + 1]++;
+        for (size_t v = 0; v < numVertices; v++)
+            m_cornerStart[v + 1] += m_cornerStart[v];
+        m_cornerTri.resize(numTriangles * 3);
+        std::vector<uint32_t> fill(m_cornerStart.begin(), m_cornerStart.end() - 1);
+        for (size_t t = 0; t < numTriangles; t++)
+            for (int k = 0; k < 3; k++)
+                m_cornerTri[fill[m_inputTriangles[t].indices[k]]++] = (uint32_t)t;
     }
-    for (size_t i = 0; i < numVertices; i++) {
-        float len = length(acc[i]);
-        vec3 n = len > 0.0f ? acc[i] / len : vec3(0, 1, 0);
-        m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
+    m_faceNormal.resize(numTriangles);
+    WorkerPool& pool = WorkerPool::get();
+    pool.parallelFor(numTriangles, 4096, [&](size_t begin, size_t end) {
+        for (size_t t = begin; t < end; t++) {
+            const auto& tri = m_inputTriangles[t];
+            auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
+            m_faceNormal[t] = cross(P(1) - P(0), P(2) - P(0));
+        }
+    });
+    pool.parallelFor(numVertices, 4096, [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; i++) {
+            vec3 acc;
+            for (uint32_t c = m_cornerStart[i]; c < m_cornerStart[i + 1]; c++)
+                acc += m_faceNormal[m_cornerTri[c]];
+            const float len = length(acc);
+            const vec3 n = len > 0.0f ? acc / len : vec3(0, 1, 0);
+            m_vertices[i].normal[0] = n.x, m_vertices[i].normal[1] = n.y, m_vertices[i].normal[2] = n.z;
+        }
+    });
+}
+
+const BvhBuildResult& Mesh::refittedBvh() const
+{
+    if (m_boxesStale) {
+        refitBVH(m_bvh.nodes, m_bvh.rootNode, m_bvh.triangles, m_vertices);
+        m_boxesStale = false;
     }
+    return m_bvh;
 }
 
 // A deformed frame of the same mesh (MeshSequence with m_refitting, reference src/model/mesh_sequence.cpp:81-97): new positions
@@ -382,7 +416,7 @@ void Mesh::refit(const float* positions, const float* normals)
     }
     if (!normals)
         generateSmoothNormals();
-    refitBVH(m_bvh.nodes, m_bvh.rootNode, m_bvh.triangles, m_vertices);
+    m_boxesStale = true; // refitBVH runs when the nodes are asked for (refittedBvh); the device library refits its own copy (pt_refit_vertices)
     m_bvhFromCache = false;
     m_generation++;
 }

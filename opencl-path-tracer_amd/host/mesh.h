@@ -56,7 +56,7 @@ public:
     const std::vector<VertexSceneData>& getVertices() const override { return m_vertices; }
     const std::vector<TriangleSceneData>& getTriangles() const override { return m_bvh.triangles; }
     const std::vector<Material>& getMaterials() const override { return m_materials; }
-    const std::vector<SubBVHNode>& getBvhNodes() const override { return m_bvh.nodes; }
+    const std::vector<SubBVHNode>& getBvhNodes() const override { return refittedBvh().nodes; }
     const std::vector<uint32_t>& getEmissiveTriangles() const override { return m_emissive; }
     AABB getBounds() const override { return m_bounds; }
     bool isDynamic() const override { return false; }
@@ -76,21 +76,30 @@ public:
     bool loadBvh(const std::string& fileName);
     bool bvhFromCache() const { return m_bvhFromCache; }
 
-    // new positions (3 * numVertices floats) and normals (null: regenerated smooth) for the same topology: the BVH is refitted
+    // new positions (3 * numVertices floats) and normals (null: regenerated smooth) for the same topology: the BVH is refitted.
+    // The boxes are recomputed (refitBVH, bottom-up on one thread) only when somebody asks for the nodes: RayTracer::updateGeometry hands the
+    // device library the vertices alone and the device refits its own copy of the tree (pt_refit_vertices), so a frame loop never pays for them here.
     void refit(const float* positions, const float* normals);
+    bool boxesCurrent() const { return !m_boxesStale; }
 
-    const BvhBuildResult& getBvh() const { return m_bvh; }
+    const BvhBuildResult& getBvh() const { return refittedBvh(); }
     size_t numInputTriangles() const { return m_inputTriangles.size(); }
     BvhBuilder builder() const { return m_builder; }
     uint64_t generation() const override { return m_generation; }
 
 private:
     void generateSmoothNormals();
+    const BvhBuildResult& refittedBvh() const;
+    // vertex -> incident input triangles (once per corner, ascending): the smooth-normal pass gathers per vertex in the order the
+    // scatter over the triangles would have added (same sums, bit for bit), which lets it run on several threads
+    std::vector<uint32_t> m_cornerStart, m_cornerTri;
+    std::vector<vec3> m_faceNormal; // scratch of generateSmoothNormals
+    mutable bool m_boxesStale = false; // the nodes' boxes are older than the vertices (refit): recomputed by refittedBvh()
     std::vector<VertexSceneData> m_vertices;
     std::vector<TriangleSceneData> m_inputTriangles;
     std::vector<Material> m_materials;
     std::vector<uint32_t> m_emissive;
-    BvhBuildResult m_bvh;
+    mutable BvhBuildResult m_bvh;
     AABB m_bounds;
     BvhBuilder m_builder;
     bool m_bvhFromCache = false;

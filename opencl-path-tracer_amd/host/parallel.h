@@ -1,0 +1,97 @@
+// A few persistent worker threads for the host library's per-frame loops (Mesh::refit: smooth normals of ~40 k vertices per tick; the
+// reference does this work single-threaded inside Assimp / refit_bvh.cpp, and at 4-6 ms per frame never needed more).  Threads are started at
+// the first use and parked on a condition variable in between; parallelFor splits [0, count) into one contiguous range per thread, the
+// caller takes the first one itself.  Ranges are fixed by (count, thread count) alone: results never depend on timing.
+#pragma once
+#include <algorithm>
+#include <condition_variable>
+#include <cstddef>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace raytracer {
+
+class WorkerPool {
+public:
+    static WorkerPool& get()
+    {
+        static WorkerPool pool;
+        return pool;
+    }
+    // fn(begin, end) on disjoint ranges covering [0, count); below `minPerThread` items per thread the caller does it alone
+    void parallelFor(size_t count, size_t minPerThread, const std::function<void(size_t, size_t)>& fn)
+    {
+        const size_t parts = std::max<size_t>(1, std::min<size_t>(m_threads.size() + 1, count / std::max<size_t>(minPerThread, 1)));
+        if (parts <= 1) {
+            if (count)
+                fn(0, count);
+            return;
+        }
+        std::unique_lock<std::mutex> callers(m_callers); // one parallelFor at a time
+        const size_t chunk = (count + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> lock(m_mutex);
+            m_fn = &fn, m_count = count, m_chunk = chunk, m_parts = parts, m_pending = parts - 1, m_generation++;
+        }
+        m_wake.notify_all();
+        fn(0, std::min(chunk, count));
+        std::unique_lock<std::mutex> lock(m_mutex);
+        m_done.wait(lock, [&] { return m_pending == 0; });
+        m_fn = nullptr;
+    }
+    size_t threads() const { return m_threads.size() + 1; }
+
+private:
+    WorkerPool()
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned n = std::min(4u, hw) - 1u; // the caller is the first worker; more than four threads buy nothing on loops this small
+        for (unsigned i = 0; i < n; i++)
+            m_threads.emplace_back([this, i] { run(i + 1); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_mutex);
+            m_quit = true;
+        }
+        m_wake.notify_all();
+        for (std::thread& t : m_threads)
+            t.join();
+    }
+    void run(size_t part)
+    {
+        size_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t, size_t)>* fn;
+            size_t begin, end;
+            {
+                std::unique_lock<std::mutex> lock(m_mutex);
+                m_wake.wait(lock, [&] { return m_quit || m_generation != seen; });
+                if (m_quit)
+                    return;
+                seen = m_generation;
+                if (part >= m_parts)
+                    continue; // fewer parts than threads this time
+                fn = m_fn, begin = std::min(part * m_chunk, m_count), end = std::min(begin + m_chunk, m_count);
+            }
+            if (begin < end)
+                (*fn)(begin, end);
+            {
+                std::lock_guard<std::mutex> lock(m_mutex);
+                if (--m_pending == 0)
+                    m_done.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> m_threads;
+    std::mutex m_mutex, m_callers;
+    std::condition_variable m_wake, m_done;
+    const std::function<void(size_t, size_t)>* m_fn = nullptr;
+    size_t m_count = 0, m_chunk = 0, m_parts = 0, m_pending = 0, m_generation = 0;
+    bool m_quit = false;
+};
+
+} // namespace raytracer

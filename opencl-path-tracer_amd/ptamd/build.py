@@ -24,7 +24,7 @@ def build_host(force=False):
     out = os.path.join(HOST_DIR, "libptamd_host.so")
     deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
     if force or _newer(out, deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + HOST_SOURCES + ["-o", out, "-lz"],  # zlib: PNG inflate
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-pthread"] + HOST_SOURCES + ["-o", out, "-lz"],  # zlib: PNG inflate
                        cwd=HOST_DIR, check=True)
     return out
 
@@ -44,7 +44,7 @@ def build_sanitized(force=False):
     out = os.path.join(HOST_DIR, "libptamd_host_san.so")
     deps = _all_files(HOST_DIR, (".cpp", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))
     if force or _newer(out, deps):
-        subprocess.run(["g++", "-std=c++17", "-Wall", "-fPIC", "-shared"] + SANITIZE_FLAGS + HOST_SOURCES + ["-o", out, "-lz"], cwd=HOST_DIR, check=True)
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-fPIC", "-shared", "-pthread"] + SANITIZE_FLAGS + HOST_SOURCES + ["-o", out, "-lz"], cwd=HOST_DIR, check=True)
     odir = os.path.abspath(os.path.join(ROOT, "..", "oracle"))
     oout = os.path.join(odir, "liboracle_san.so")
     osrc = [f for f in os.listdir(odir) if f.endswith(".cpp")]

@@ -143,7 +143,9 @@ class Mesh:
         and triangles.  The BVH keeps topology and leaf order, its boxes are refitted (reference refitBVH,
         src/bvh/refit_bvh.cpp:6-34, as MeshSequence::buildBvh uses it, src/model/mesh_sequence.cpp:81-97)."""
         pos = _f32(positions, (-1, 3))
-        if len(pos) != self.stats()["num_vertices"]:
+        if getattr(self, "_num_vertices", None) is None:  # (stats() walks the whole tree -- the BvhTester invariants --: 1.8 ms per call at 82 k triangles)
+            self._num_vertices = self.stats()["num_vertices"]
+        if len(pos) != self._num_vertices:
             raise RuntimeError("Mesh.refit: the vertex count must stay the same")
         nrm = _f32(normals, (-1, 3))
         if lib().pth_mesh_refit(self._h, _ptr(pos), _ptr(nrm)):
