@@ -220,6 +220,13 @@ int pt_frame_tick(pt_ctx* ctx);
  * src/model/mesh_sequence.cpp:81-97): the caller's whole vertex and sub-BVH arrays after the refit.  Takes effect with the next
  * pt_upload_dynamic(_async) + pt_frame_tick. */
 int pt_update_geometry(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
+/* The same refit WITHOUT the caller's nodes (round 5): `n_verts` vertex records replace [first_vertex, first_vertex + n_verts) of the array
+ * pt_upload_static took -- the vertices of the mesh that moved -- and the device recomputes every box of its trees bottom-up from the
+ * triangles (what refitBVH does on the host in the reference, src/bvh/refit_bvh.cpp:6-34) and re-makes the triangle records, on the copy
+ * stream, nothing synchronised.  The host's share of a tick is one copy of the moved vertices.  The boxes are the bits pt_update_geometry
+ * makes from host-refitted nodes.  PT_ERR_UNSUPPORTED when two roots of the sub-BVH array share a subtree (use pt_update_geometry).
+ * Takes effect with the next pt_upload_dynamic(_async) + pt_frame_tick. */
+int pt_refit_vertices(pt_ctx* ctx, uint32_t first_vertex, const pt_vertex* verts, uint32_t n_verts);
 /* kind 0: material textures (CLTextureArray 1024x1024, CL_BGRA / CL_UNORM_INT8 in the reference, src/raytracer.cpp:284,
  * src/opencl/texture.cpp:112-131,148), kind 1: skydome (CL_RGBA / CL_FLOAT, src/raytracer.cpp:153-160, texture.cpp:96-110).
  * format: the two image formats the reference creates (texture.cpp:133-164) --

@@ -86,6 +86,13 @@ int pth_scene_flatten(pth_scene* s, pth_scene_counts* counts);
  * Fails (-1) when a node was added or a mesh of the scene was refitted (pth_mesh_refit) since that pth_scene_flatten: the static arrays
  * are then stale, and lights / top-level boxes made from the new mesh would not belong to them -- call pth_scene_flatten again. */
 int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts);
+/* The same without the check that the static arrays are current: for callers that hand deformed meshes to the device library themselves
+ * (pt_refit_vertices) and want nothing but the lights and the top level of the scene as it stands. */
+int pth_scene_flatten_dynamic_only(pth_scene* s, pth_scene_counts* counts);
+/* where mesh `m` lies in the arrays of the last pth_scene_flatten: its first vertex / sub-BVH node; -1 when the mesh is not part of the scene */
+int pth_scene_mesh_offsets(const pth_scene* s, const pth_mesh* m, uint32_t* firstVertex, uint32_t* firstNode);
+/* the mesh's vertex array in place (num_vertices records of 48 bytes; valid until the mesh is destroyed, contents change with pth_mesh_refit) */
+const pt_vertex* pth_mesh_vertices(const pth_mesh* m, uint32_t* count);
 int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top);
 
 int pth_camera_data(const pth_camera_params* p, pt_camera* out);

@@ -89,7 +89,8 @@ struct Instance {
     float4 r0, r1, r2; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major matrix
     uint32_t rootRef; // makeRef
     uint32_t topNode; // index of the top-level leaf (reported as `inst` in hit records)
-    uint32_t _p0, _p1;
+    uint32_t folded; // the per-ray kernels walk this instance without parking (translation + uniform scale: pt_trace.h); its table entry is not the identity
+    uint32_t _p1;
 };
 
 struct Material { // the reference's 48-byte record, read as 3 x float4

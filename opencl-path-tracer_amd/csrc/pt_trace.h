@@ -438,12 +438,18 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         // -------- enter instance refIndex(cur) (scene.cl:116-139); instances are only ever entered from world space
                         const uint32_t what = refIndex(cur);
                         const Instance in = sc.instances[what];
-                        V3 to, td;
-                        rayIntoInstance(in.r0, in.r1, in.r2, wo, wd, &to, &td);
-                        setRay(to, td);
                         curInst = (int)what; // instance index; pt_intersect reports the top-level leaf
-                        push(sp, kRefLeaveInstance);
-                        sp++;
+                        if (fold && in.folded) {
+                            // a folded instance reached through its instance reference (the start states of the shared descent come from the top level
+                            // that holds those): the lane keeps the world-space ray, the steps below take it into the instance's space on the fly
+                            setRay(wo, wd);
+                        } else {
+                            V3 to, td;
+                            rayIntoInstance(in.r0, in.r1, in.r2, wo, wd, &to, &td);
+                            setRay(to, td);
+                            push(sp, kRefLeaveInstance);
+                            sp++;
+                        }
                         cur = in.rootRef;
                     } else {
                         setRay(wo, wd); // back in world space, at a top-level node or leaf

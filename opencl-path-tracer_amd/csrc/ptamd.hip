@@ -2571,8 +2571,9 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             for (size_t k = 0; k < hInst.size(); k++) {
                 if (!folded[k])
                     continue;
-                const Instance& in = hInst[k];
+                Instance& in = hInst[k];
                 out.instFold[k + 1] = make_float4(in.r0.x, in.r0.w, in.r1.w, in.r2.w);
+                in.folded = 1u;
                 if (refCount(in.rootRef) == 0u) {
                     out.instRoots[k] = sg.wide[refIndex(in.rootRef)]; // the mesh's packed root node as it is: object space, children in the shared tree
                 } else { // the mesh is a single leaf: a one-child node around it -- the top-level leaf's box taken into object space, a few ulps outwards

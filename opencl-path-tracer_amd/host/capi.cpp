@@ -333,6 +333,49 @@ int pth_scene_flatten_dynamic(pth_scene* s, pth_scene_counts* counts)
     });
 }
 
+int pth_scene_flatten_dynamic_only(pth_scene* s, pth_scene_counts* counts)
+{
+    return guarded([&] {
+        SceneHandle& h = *(SceneHandle*)s;
+        if (!h.staticFlattened)
+            throw std::logic_error("pth_scene_flatten_dynamic_only: call pth_scene_flatten first (and again after adding nodes)");
+        flattenDynamic(h.scene, h.flat);
+        h.flattened = true; // (lights and top level are; the static arrays may be older than a refitted mesh: the caller said it does not want them)
+        *counts = pth_scene_counts {};
+        counts->num_lights = (uint32_t)h.flat.emissiveTriangles.size();
+        counts->num_top_nodes = (uint32_t)h.flat.topBvhNodes.size();
+        counts->top_root = h.flat.topBvhRoot;
+        counts->num_instances = (uint32_t)h.scene.numInstances();
+    });
+}
+
+int pth_scene_mesh_offsets(const pth_scene* s, const pth_mesh* m, uint32_t* firstVertex, uint32_t* firstNode)
+{
+    int found = -1;
+    guarded([&] {
+        const SceneHandle& h = *(const SceneHandle*)s;
+        if (!h.staticFlattened)
+            throw std::logic_error("pth_scene_mesh_offsets: call pth_scene_flatten first");
+        for (const MeshBvhPair& p : h.scene.getMeshes())
+            if (p.meshPtr.get() == ((const MeshHandle*)m)->mesh.get()) {
+                if (firstVertex) *firstVertex = p.vertexIndexOffset;
+                if (firstNode) *firstNode = p.bvhIndexOffset;
+                found = 0;
+            }
+    });
+    return found;
+}
+
+const pt_vertex* pth_mesh_vertices(const pth_mesh* m, uint32_t* count)
+{
+    if (!m)
+        return nullptr;
+    const auto& v = ((const MeshHandle*)m)->mesh->getVertices();
+    if (count)
+        *count = (uint32_t)v.size();
+    return v.data();
+}
+
 int pth_scene_copy(const pth_scene* s, pt_vertex* v, pt_triangle* t, pt_material* m, pt_sub_bvh_node* n, pt_emissive_triangle* l, pt_top_bvh_node* top)
 {
     return guarded([&] {

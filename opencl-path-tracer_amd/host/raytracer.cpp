@@ -34,6 +34,8 @@ void RayTracer::upload(const TextureArray& materialTextures, const TextureArray&
 {
     // static geometry once (reference: initBuffersAndTransferStaticData, src/raytracer.cpp:201-287) ...
     flattenStatic(*m_scene, m_flat);
+    for (MeshBvhPair& pair : m_scene->getMeshes())
+        pair.uploadedGeneration = pair.meshPtr->generation();
     check(pt_upload_static(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.triangles.data(), (uint32_t)m_flat.triangles.size(),
               m_flat.materials.data(), (uint32_t)m_flat.materials.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
         "pt_upload_static");
@@ -63,13 +65,33 @@ void RayTracer::frameTick()
     check(pt_frame_tick(m_ctx), "pt_frame_tick");
 }
 
-// Deformed meshes (Mesh::refit: same topology, refitted boxes -- the reference rewrites the dynamic tail of its vertex and
-// sub-BVH buffers in transferDynamicData, :510-568): re-flatten the geometry and hand it over; the following frameTick adopts it.
+// Deformed meshes (Mesh::refit: same topology, new vertices -- the reference rewrites the dynamic tail of its vertex and sub-BVH buffers in
+// transferDynamicData, :510-568, after refitting the boxes on the host, src/bvh/refit_bvh.cpp:6-34): every mesh that changed since the last
+// call hands its vertices to the device library, which refits its own copy of the trees (pt_refit_vertices) -- no node array travels, the
+// host never runs refitBVH in a frame loop (Mesh::refit leaves the boxes to whoever asks for them).  The following frameTick adopts it.
 void RayTracer::updateGeometry()
 {
-    flattenStatic(*m_scene, m_flat);
-    check(pt_update_geometry(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
-        "pt_update_geometry");
+    bool hostRoute = false;
+    for (MeshBvhPair& pair : m_scene->getMeshes()) {
+        const uint64_t gen = pair.meshPtr->generation();
+        if (gen == pair.uploadedGeneration)
+            continue;
+        const auto& verts = pair.meshPtr->getVertices();
+        const int rc = pt_refit_vertices(m_ctx, pair.vertexIndexOffset, verts.data(), (uint32_t)verts.size());
+        if (rc == PT_ERR_UNSUPPORTED) { // (roots of the sub-BVH array that share a subtree: the bottom-up pass on the device does not apply)
+            hostRoute = true;
+            break;
+        }
+        check(rc, "pt_refit_vertices");
+        pair.uploadedGeneration = gen;
+    }
+    if (hostRoute) { // the reference's way: boxes refitted on the host, the whole vertex and node arrays handed over
+        flattenStatic(*m_scene, m_flat);
+        check(pt_update_geometry(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
+            "pt_update_geometry");
+        for (MeshBvhPair& pair : m_scene->getMeshes())
+            pair.uploadedGeneration = pair.meshPtr->generation();
+    }
 }
 
 void RayTracer::rayTrace(const Camera& camera)

@@ -17,7 +17,7 @@ SceneNode& Scene::addNode(const std::shared_ptr<IMesh>& mesh, const Transform& t
         id = it->second;
     } else {
         id = (uint32_t)m_meshes.size();
-        m_meshes.push_back({ mesh, 0 });
+        m_meshes.push_back({ mesh, 0, 0, 0 });
         m_meshIds.emplace(mesh.get(), id);
     }
     auto node = std::make_unique<SceneNode>();
@@ -234,6 +234,7 @@ void flattenStatic(Scene& scene, FlattenedScene& out)
             out.subBvhNodes.push_back(n);
         }
         pair.bvhIndexOffset = n0;
+        pair.vertexIndexOffset = v0;
     }
 }
 

@@ -23,6 +23,8 @@ struct SceneNode {
 struct MeshBvhPair {
     std::shared_ptr<IMesh> meshPtr;
     uint32_t bvhIndexOffset; // offset of this mesh's nodes in the global sub-BVH array
+    uint32_t vertexIndexOffset = 0; // ... of its vertices in the global vertex array (what pt_refit_vertices addresses a deformed mesh by)
+    uint64_t uploadedGeneration = 0; // IMesh::generation() the device library last saw (RayTracer::updateGeometry)
 };
 
 class Scene {

@@ -63,7 +63,7 @@ class ShadeBatchIO(C.Structure):
 
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_upload_static", "pt_upload_dynamic",
-           "pt_upload_dynamic_async", "pt_frame_tick", "pt_update_geometry",
+           "pt_upload_dynamic_async", "pt_frame_tick", "pt_update_geometry", "pt_refit_vertices",
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
            "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
@@ -97,6 +97,7 @@ def lib():
         l.pt_upload_dynamic_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         l.pt_frame_tick.argtypes = [C.c_void_p]
         l.pt_update_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        l.pt_refit_vertices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         l.pt_upload_texture_array.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         l.pt_set_camera.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_set_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -190,6 +191,12 @@ class Context:
         """Refitted geometry (same topology): new vertices and sub-BVH boxes; follow with upload_dynamic(_async) / frame_tick."""
         self._chk(lib().pt_update_geometry(self._h, _p(flat.vertices), len(flat.vertices), _p(flat.sub_nodes), len(flat.sub_nodes)),
                   "pt_update_geometry")
+
+    def refit_vertices(self, first_vertex, vertices):
+        """A deformed mesh, refitted on the device: its vertex records (L.VERTEX) replace [first_vertex, ...) of the uploaded array; every box
+        of the device's trees is recomputed there.  Follow with upload_dynamic(_async) / frame_tick."""
+        v = np.ascontiguousarray(vertices, L.VERTEX)
+        self._chk(lib().pt_refit_vertices(self._h, first_vertex, _p(v), len(v)), "pt_refit_vertices")
 
     def upload_texture(self, kind, arr):
         """[layers][h][w][4]: float32 r g b a (PT_TEX_RGBA32F) or uint8 b g r a (PT_TEX_BGRA8_UNORM, the reference's material

@@ -71,6 +71,10 @@ def lib():
         _lib.pth_scene_flatten.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
         _lib.pth_scene_flatten_dynamic.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
         _lib.pth_scene_copy.argtypes = [C.c_void_p] * 7
+        _lib.pth_scene_flatten_dynamic_only.argtypes = [C.c_void_p, C.POINTER(SceneCounts)]
+        _lib.pth_scene_mesh_offsets.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _lib.pth_mesh_vertices.restype = C.c_void_p
+        _lib.pth_mesh_vertices.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         _lib.pth_camera_data.argtypes = [C.POINTER(CameraParams), C.c_void_p]
         _lib.pth_image_hdr_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib.pth_image_load_hdr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
@@ -150,6 +154,13 @@ class Mesh:
         nrm = _f32(normals, (-1, 3))
         if lib().pth_mesh_refit(self._h, _ptr(pos), _ptr(nrm)):
             _err("pth_mesh_refit")
+
+    def vertices_view(self):
+        """The mesh's vertex records IN PLACE (numpy view of the host library's array, no copy): what pt_refit_vertices takes after a refit."""
+        n = C.c_uint32(0)
+        ptr = lib().pth_mesh_vertices(self._h, C.byref(n))
+        buf = (C.c_char * (n.value * L.VERTEX.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=L.VERTEX, count=n.value)
 
     def geometry(self):
         """(vertices, materials) in the reference's device layouts."""
@@ -268,6 +279,28 @@ class Scene:
         if lib().pth_scene_copy(self._h, None, None, None, None, _ptr(l), _ptr(top)):
             _err("pth_scene_copy")
         return FlatScene(flat.vertices, flat.triangles, flat.materials, flat.sub_nodes, l, top, c.top_root, c.num_instances), dt
+
+    def flatten_dynamic_only(self):
+        """Lights and top-level BVH of the scene as it stands, nothing else (a FlatScene whose static arrays are None): for callers that hand
+        deformed meshes to the device themselves (Context.refit_vertices).  Returns (FlatScene, seconds inside the host library)."""
+        import time
+        c = SceneCounts()
+        t0 = time.perf_counter()
+        if lib().pth_scene_flatten_dynamic_only(self._h, C.byref(c)):
+            _err("pth_scene_flatten_dynamic_only")
+        dt = time.perf_counter() - t0
+        l = np.zeros(c.num_lights, L.EMISSIVE_TRIANGLE)
+        top = np.zeros(c.num_top_nodes, L.TOP_BVH_NODE)
+        if lib().pth_scene_copy(self._h, None, None, None, None, _ptr(l), _ptr(top)):
+            _err("pth_scene_copy")
+        return FlatScene(None, None, None, None, l, top, c.top_root, c.num_instances), dt
+
+    def mesh_offsets(self, mesh):
+        """(first vertex, first sub-BVH node) of `mesh` in the arrays of the last flatten()."""
+        v, n = C.c_uint32(0), C.c_uint32(0)
+        if lib().pth_scene_mesh_offsets(self._h, mesh._h, C.byref(v), C.byref(n)):
+            raise RuntimeError("mesh_offsets: the mesh is not part of the flattened scene")
+        return v.value, n.value
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

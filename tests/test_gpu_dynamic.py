@@ -85,11 +85,16 @@ def test_an_upload_that_is_never_adopted_changes_nothing_and_can_be_replaced(gpu
     fresh.close()
 
 
+@pytest.mark.parametrize("route", ["host_nodes", "device"])
 @pytest.mark.parametrize("builder", ["BVH_BINNED_SAH", "BVH_SPATIAL_SPLIT"])
-def test_deforming_mesh_through_refit(gpu, builder):
+def test_deforming_mesh_through_refit(gpu, builder, route):
     """Mesh.refit + pt_update_geometry + pt_upload_dynamic: a blob in the room twists and squashes over three frames, its BVH
     refitted, never rebuilt.  Every frame: closest hits equal the oracle's on the refitted arrays, the image equals the oracle's
-    path by path, and a context created from scratch with the same (refitted) arrays renders the same bits."""
+    path by path, and a context created from scratch with the same (refitted) arrays renders the same bits.
+    route "host_nodes": the reference's way -- boxes refitted on the host (refitBVH), the whole vertex and node arrays handed over
+    (pt_update_geometry); "device" (round 5): only the blob's vertices travel (pt_refit_vertices), the device recomputes every box of its
+    trees bottom-up -- and must end up with the very bytes the other route makes from the host-refitted nodes (the fresh context below is
+    given those)."""
     mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
     room = scenes.blob_room(W, Hh, level=3, builder=getattr(H, builder), material=mat)
     v, f = scenes.icosphere(3)
@@ -111,9 +116,16 @@ def test_deforming_mesh_through_refit(gpu, builder):
             p = np.stack([np.cos(ang) * p0[:, 0] - np.sin(ang) * p0[:, 2], (1 - 0.2 * frame) * p0[:, 1] + 0.05 * frame * np.sin(5 * p0[:, 0]),
                           np.sin(ang) * p0[:, 0] + np.cos(ang) * p0[:, 2]], 1)
             blob.refit(p)
-            flat = scene.flatten()
-            ctx.update_geometry(flat)
-            ctx.upload_dynamic(flat)
+            if route == "device":
+                first_vertex, _ = scene.mesh_offsets(blob)
+                ctx.refit_vertices(first_vertex, blob.vertices_view())
+                dyn, _ = scene.flatten_dynamic_only()
+                ctx.upload_dynamic(dyn)
+                flat = scene.flatten()  # (for the oracle and the fresh context: the host refits its boxes now, when they are asked for)
+            else:
+                flat = scene.flatten()
+                ctx.update_geometry(flat)
+                ctx.upload_dynamic(flat)
         ctx.clear()
         ctx.render(16)
         a, st = ctx.read_accum()[:, :3].copy(), ctx.stats()
@@ -220,7 +232,8 @@ def test_top_level_leaf_that_names_an_interior_node(gpu, flags_name):
     ctx.close()
 
 
-def test_refit_of_a_mesh_with_leaves_larger_than_a_device_leaf(gpu):
+@pytest.mark.parametrize("route", ["host_nodes", "device"])
+def test_refit_of_a_mesh_with_leaves_larger_than_a_device_leaf(gpu, route):
     """100 coincident triangles make one 100-triangle leaf, which pt_upload_static splits into a small subtree of its own (device leaves hold
     <= 30): those pair nodes mirror no node of the caller's, so a refit (pt_update_geometry) recomputes their boxes from the moved triangles.
     After the refit the context must see what a fresh context sees on the same arrays."""
@@ -241,7 +254,10 @@ def test_refit_of_a_mesh_with_leaves_larger_than_a_device_leaf(gpu):
     moved[:, 0] = pos[:, 0] * 0.5 + 2.0  # the stack of triangles shrinks and slides to x in [2, 2.5]
     mesh.refit(moved)
     flat2 = sc.flatten()
-    ctx.update_geometry(flat2)
+    if route == "device":  # the device refits the sub-leaves of the split leaf from their triangles like any other leaf
+        ctx.refit_vertices(sc.mesh_offsets(mesh)[0], mesh.vertices_view())
+    else:
+        ctx.update_geometry(flat2)
     ctx.upload_dynamic(flat2)
     got = ctx.intersect(o, d)
     fresh = gpu.Context(8, 8)
@@ -335,4 +351,57 @@ def test_refit_before_the_first_dynamic_upload_and_rebuild_after_a_refit(gpu):
     got_h = ctx.intersect(o, d)
     for k in ("t", "u", "v", "prim", "inst"):
         assert np.array_equal(got_h[k], want_h[k]), ("refit after the rebuild", k)
+    ctx.close()
+
+
+def test_device_refit_then_a_rebuild_of_the_static_part_and_partial_ranges(gpu):
+    """pt_refit_vertices leaves the host's mirrors behind twice over: the converted arrays AND the caller's node boxes (nobody hands nodes in).
+    (1) Two meshes in one scene, only the second one refitted -- a vertex RANGE, not the whole array; (2) then a state whose top-level leaf names
+    an interior node, which makes the whole conversion run again: from the latest vertices, with the node boxes recomputed on the host.  Either
+    way the context must hold what a fresh context holds that was given the final, host-refitted arrays; (3) a range that does not fit is refused."""
+    mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
+    v, f = scenes.icosphere(3)
+    p0 = (v * 0.5).astype(np.float32)
+    a_mesh = H.Mesh(p0 * 0.6, f.astype(np.uint32), [mat], builder=H.BVH_BINNED_SAH)
+    blob = H.Mesh(p0, f.astype(np.uint32), [mat], builder=H.BVH_SPATIAL_SPLIT)
+    scene = H.Scene()
+    mb = scenes._MeshBuilder()
+    mats = scenes._room_materials()
+    scenes._room(mb, mats)
+    scene.add_node(mb.build(mats, H.BVH_BINNED_SAH))
+    scene.add_node(a_mesh, location=(-0.5, 0.5, -0.3))
+    scene.add_node(blob, location=(0.2, 0.8, 0.1), scale=(1.1, 1.1, 1.1))
+    flat0 = scene.flatten()
+    cam = scenes.blob_room(W, Hh, level=3).camera
+    o, d = U.random_rays(20000, 4, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
+
+    def fresh_hits(flat):
+        c = U.make_ctx(gpu, flat, W, Hh, camera=cam, seed=8)
+        h = c.intersect(o, d)
+        c.close()
+        return h
+
+    ctx = U.make_ctx(gpu, flat0, W, Hh, camera=cam, seed=8)
+    first_vertex, first_node = scene.mesh_offsets(blob)
+    assert first_vertex > 0 and first_vertex + len(p0) == len(flat0.vertices)
+    with pytest.raises(gpu.PtError, match="not a range"):
+        ctx.refit_vertices(first_vertex + 1, blob.vertices_view())
+    for k in (1, 2):
+        blob.refit(_deformed(p0, k))
+        ctx.refit_vertices(first_vertex, blob.vertices_view())
+        ctx.upload_dynamic(scene.flatten_dynamic_only()[0])
+        flat = scene.flatten()
+        got, want = ctx.intersect(o, d), fresh_hits(flat)
+        for key in ("t", "u", "v", "prim", "inst"):
+            assert np.array_equal(got[key], want[key]), (k, key)
+    # (2) a new root below the blob's root: the whole conversion runs again, from the host's (stale, then refreshed) mirrors
+    import copy
+    part = copy.copy(flat)
+    part.top_nodes = flat.top_nodes.copy()
+    leaf = [int(l) for l in np.flatnonzero(part.top_nodes["isLeaf"] != 0) if int(part.top_nodes["a"][l]) == first_node][0]
+    part.top_nodes["a"][leaf] = int(flat.sub_nodes["left"][first_node]) + 1
+    ctx.upload_dynamic(part)
+    got, want = ctx.intersect(o, d), fresh_hits(part)
+    for key in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got[key], want[key]), ("rebuild after a device refit", key)
     ctx.close()
