@@ -481,8 +481,7 @@ def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
         cam = scenes.blob_room(W, Hh, level=2).camera
         ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=1)
         try:
-            build_ms, flatten_ms, upload_ms, total_ms = [], [], [], []
-            for k in range(6):
+            def new_scene(k):
                 p = (p0 * (1.0 + 0.1 * np.sin(k + 1.0 + 5.0 * p0[:, :1]))).astype(np.float32)
                 t0 = time.perf_counter()
                 mesh = H.Mesh(p, f, [mat], builder=H.BVH_BINNED_FAST)
@@ -491,20 +490,46 @@ def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
                 scene.add_node(room)
                 scene.add_node(mesh, location=(0.0, 0.8, 0.1), scale=(1.2, 1.2, 1.2))
                 flat = scene.flatten()
-                t2 = time.perf_counter()
+                return flat, t0, t1, time.perf_counter()
+
+            flat, _, _, _ = new_scene(0)
+            ctx.upload_scene(flat, sky=None)
+            ctx.set_camera(cam)
+            ctx.render(1)
+            # (a) round 5: pt_upload_static_async -- the rebuilt scene is converted and copied beside the one that renders, frames keep coming, the tick adopts it
+            build_ms, flatten_ms, upload_ms, total_ms, frames_between = [], [], [], [], []
+            for k in range(1, 9):
+                ctx.render(1, sync=False)  # a frame of the old scene is in flight while the host builds
+                flat, t0, t1, t2 = new_scene(k)
+                ctx.upload_static_async(flat)
+                ctx.upload_dynamic_async(flat)
+                t3 = time.perf_counter()
+                ctx.render(1, sync=False)  # ... and another one while the copies run
+                ctx.frame_tick()
+                ctx.render(1, sync=False)  # the first frame of the new scene
+                ctx.synchronize()
+                t4 = time.perf_counter()
+                if k >= 3:
+                    build_ms.append((t1 - t0) * 1e3), flatten_ms.append((t2 - t1) * 1e3), upload_ms.append((t3 - t2) * 1e3), total_ms.append((t4 - t0) * 1e3)
+            out["rebuild_20k"] = {"triangles": int(len(f)), "host_ms": {"mesh_build_fast_binned": round(float(np.median(build_ms)), 3), "flatten": round(float(np.median(flatten_ms)), 3),
+                                                                        "upload_static_async_and_dynamic_async": round(float(np.median(upload_ms)), 3)},
+                                  "ms_until_adopted": round(float(np.median(total_ms)), 3),
+                                  "what": "a rebuilt tree per frame: new Mesh (fast binned builder), flatten, pt_upload_static_async + pt_upload_dynamic_async, pt_frame_tick; "
+                                          "three 1-spp frames rendered meanwhile (two of the old scene, one of the new) and INCLUDED in ms_until_adopted; the render stream is "
+                                          "never synchronised by the upload; 20 480 triangles"}
+            # (b) rounds 3-4: pt_upload_static + pt_upload_dynamic (everything converted, the render stream synchronised, the dynamic state dropped)
+            upload_ms, total_ms = [], []
+            for k in range(9, 14):
+                flat, t0, t1, t2 = new_scene(k)
                 ctx.upload_scene(flat, sky=None)
                 t3 = time.perf_counter()
                 ctx.synchronize()
                 t4 = time.perf_counter()
-                if k == 0:
-                    ctx.set_camera(cam)
                 ctx.render(1)
-                if k >= 1:
-                    build_ms.append((t1 - t0) * 1e3), flatten_ms.append((t2 - t1) * 1e3), upload_ms.append((t3 - t2) * 1e3), total_ms.append((t4 - t0) * 1e3)
-            out["rebuild_20k"] = {"triangles": int(len(f)), "host_ms": {"mesh_build_fast_binned": round(float(np.median(build_ms)), 3), "flatten": round(float(np.median(flatten_ms)), 3),
-                                                                        "upload_static_and_dynamic": round(float(np.median(upload_ms)), 3)},
-                                  "ms_until_adopted": round(float(np.median(total_ms)), 3),
-                                  "what": "a rebuilt tree per frame: new Mesh (fast binned builder), flatten, pt_upload_static + pt_upload_dynamic, synchronise; 20 480 triangles"}
+                if k >= 10:
+                    upload_ms.append((t3 - t2) * 1e3), total_ms.append((t4 - t0) * 1e3)
+            out["rebuild_20k"]["synchronous_route"] = {"upload_static_and_dynamic_ms": round(float(np.median(upload_ms)), 3), "ms_until_adopted": round(float(np.median(total_ms)), 3),
+                                                       "what": "pt_upload_static + pt_upload_dynamic: what rounds 3-4 timed (no frame rendered meanwhile)"}
         finally:
             ctx.close()
     except Exception as e:

@@ -208,6 +208,13 @@ int pt_upload_static(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, cons
     const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 int pt_upload_dynamic(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
     const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
+/* A REBUILT scene as a frame-loop citizen -- the other branch of MeshSequence::buildBvh (src/model/mesh_sequence.cpp:89-96: a new tree per frame
+ * instead of a refit), whose arrays transferDynamicData re-uploads every tick (src/raytracer.cpp:510-568).  Same arguments as pt_upload_static;
+ * the scene is converted into the context's SECOND static set and copied to the device WITHOUT synchronising the render stream: frames enqueued
+ * so far, and any enqueued before the flip, keep rendering the old trees.  Follow with pt_upload_dynamic_async -- lights and top level of the
+ * NEW scene (its leaves name the new sub-BVH roots) -- and pt_frame_tick, which adopts both.  (Before anything renders it is pt_upload_static.) */
+int pt_upload_static_async(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, const pt_triangle* tris, uint32_t n_tris,
+    const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 /* transferDynamicData + frameTick as the reference runs them (src/raytracer.cpp:183-189,497-595): the dynamic part of the scene
  * is double-buffered on the device.  pt_upload_dynamic_async converts the next state on the host ("Lot of CPU work", :185) and
  * copies it into the INACTIVE buffers on a copy stream of its own -- the GPU keeps rendering the active state meanwhile, nothing

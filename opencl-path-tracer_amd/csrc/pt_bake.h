@@ -161,6 +161,16 @@ __global__ void __launch_bounds__(256) k_bake_tris(BakeArgs a)
     a.dstTris[j.dstTri + i] = b;
 }
 
+// The per-instance copies of mesh root nodes that folded instances are reached through (pt_trace.h, TWO_LEVEL): copy k = the packed root node of
+// instance k's mesh as the DEVICE holds it (after a refit the host's mirror of the packed nodes is stale).  src[k] = ~0: the slot was filled by the host
+// (a single-leaf mesh: a one-child node around the leaf) or is unused.
+__global__ void __launch_bounds__(64) k_inst_roots(const WideNode* wide, const uint32_t* src, WideNode* dst, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && src[k] != 0xFFFFFFFFu)
+        dst[k] = wide[src[k]];
+}
+
 // ---- refit (pt_update_geometry): a deformed frame of the SAME topology ------------------------------------------------------------------
 // The caller's vertex record (pt_vertex, include/ptamd.h: 48 bytes) as the device reads it
 struct VertexIn {

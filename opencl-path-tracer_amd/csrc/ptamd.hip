@@ -65,55 +65,10 @@ struct ShadowQueueBuf {
 
 } // namespace
 
-struct pt_ctx {
-    pt_config cfg {};
-    std::string error;
-    int device = 0;
-    int numCUs = 0;
-    hipStream_t stream = nullptr;
-    bool ownStream = false;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
-    std::vector<hipEvent_t> profEvents;
-    bool profile = false;
-
-    // scene (HBM)
-    DevBuf<PairNode> nodes;
-    DevBuf<WideNode> wide;
-    DevBuf<TriShade> triShade;
-    DevBuf<VertexShade> verts;
-    DevBuf<Material> materials;
-    // The dynamic part of the scene -- what pt_upload_dynamic(_async) produces: 4-wide nodes of both levels, intersection
-    // triangles (object space + world-space copies of instances), instances, lights -- exists TWICE, like the reference's
-    // double-buffered cl::Buffers (m_topBvhBuffers[2], m_emissiveTrianglesBuffers[2], ... src/raytracer.h:93-106): renders
-    // enqueued so far keep reading set `active` while the next state is converted on the host and copied into the other set on
-    // the copy stream; pt_frame_tick makes the render stream wait for that copy and flips (RayTracer::frameTick,
-    // src/raytracer.cpp:183-189; the barrier of :593).
-    struct DynamicSet {
-        DevBuf<WideNode> wide;
-        DevBuf<TriIsect> tris;
-        DevBuf<TriFat> fat; // shading records: they hold v0 / edges / normals, which a refitted mesh changes with the trees
-        DevBuf<Instance> instances;
-        DevBuf<Light> lights;
-        DevBuf<BakeJob> jobs; // world-space copies to make (pt_bake.h)
-        uint64_t staticVersion = 0; // version of the static arrays this set holds (0: none)
-        // pinned staging the asynchronous copies read from (grow-only, like the device buffers)
-        void* stage = nullptr;
-        size_t stageBytes = 0;
-        hipEvent_t stageRead = nullptr; // recorded on the copy stream after the copies out of `stage`
-        bool stageBusy = false;
-        uint32_t numLights = 0, rootRef = 0;
-        uint32_t foldedInstances = 0, instRootBase = 0, numInstRoots = 0;
-        DevBuf<float4> instFold; // the table of folded instance transforms (pt_trace.h)
-        uint32_t instFoldCount = 0;
-        uint32_t rootRefFolded = 0; // the same top level for the per-ray kernels: entry nodes in place of the instances that are a translation + uniform scale (pt_trace.h)
-        bool packetOk = false;
-        uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
-        bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
-        std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
-        hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
-        hipEvent_t lastUse = nullptr; // recorded on the render stream when the set stopped being the active one
-        bool used = false;
-    } dyn[2];
+// Everything pt_upload_static derives from the caller's static arrays -- the host's mirrors and the device's master copies.  A context holds TWO
+// (like the dynamic sets, like the reference's double-buffered cl::Buffers): renders and refits work on the current one while
+// pt_upload_static_async converts a rebuilt scene into the other; pt_frame_tick adopts it together with the dynamic state built on it.
+struct StaticScene {
     // The static part: the bottom-level trees as packed 4-wide nodes, object-space triangles and shading records.  Converted on the
     // host once per pt_upload_static / pt_update_geometry (buildStaticGeom); one master copy on the device, from which a dynamic
     // set refreshes its own copy (device to device) when its version is stale.
@@ -162,6 +117,83 @@ struct pt_ctx {
         hipEvent_t stageRead = nullptr;
         bool stageBusy = false;
     } sg;
+    DevBuf<TriShade> triShade;
+    DevBuf<Material> materials;
+    std::vector<VertexShade> hostVerts;
+    std::vector<pt_vertex> rawVerts; // the caller's vertices as last handed in (pt_upload_static / pt_update_geometry)
+    std::vector<uint32_t> denseOfNode; // caller's sub-BVH node -> pair node (0xFFFFFFFF: a leaf or a pad)
+    uint32_t numDensePairs = 0; // pair nodes [0, numDensePairs) mirror the caller's inner nodes; the rest split leaves of more than kMaxLeafTris
+    std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
+    std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
+    std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
+    std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
+    std::vector<TriShade> hostTriShade; // vertex indices + material of every triangle (kept for pt_update_geometry)
+    std::vector<pt_material> hostMaterials;
+    std::vector<pt_sub_bvh_node> hostSubNodes; // the caller's sub-BVH as uploaded (topology; boxes are replaced by pt_update_geometry)
+    uint32_t numVerts = 0;
+    uint32_t numRefNodes = 0, numTris = 0;
+    bool hostNodeBoxesStale = false; // the boxes in hostSubNodes are older than rawVerts (pt_refit_vertices: the device refitted its own tree, nobody handed nodes in)
+    bool hostGeomStale = false; // hostTris / hostVerts / hostBottomNodes' boxes / sg.wide / sg.boxes / sg.fat are older than the caller's latest arrays (a refit
+                                // re-makes the device's copies on the device only; the host's are refreshed if the whole conversion ever runs again)
+    bool materialBins = false; // the surfaces are of more than one material type: k_shade shades its tiles in material order
+    bool have = false; // holds a converted scene
+};
+
+struct pt_ctx {
+    pt_config cfg {};
+    std::string error;
+    int device = 0;
+    int numCUs = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    std::vector<hipEvent_t> profEvents;
+    bool profile = false;
+
+    // scene (HBM)
+    DevBuf<PairNode> nodes;
+    DevBuf<WideNode> wide;
+    DevBuf<VertexShade> verts;
+    // The dynamic part of the scene -- what pt_upload_dynamic(_async) produces: 4-wide nodes of both levels, intersection
+    // triangles (object space + world-space copies of instances), instances, lights -- exists TWICE, like the reference's
+    // double-buffered cl::Buffers (m_topBvhBuffers[2], m_emissiveTrianglesBuffers[2], ... src/raytracer.h:93-106): renders
+    // enqueued so far keep reading set `active` while the next state is converted on the host and copied into the other set on
+    // the copy stream; pt_frame_tick makes the render stream wait for that copy and flips (RayTracer::frameTick,
+    // src/raytracer.cpp:183-189; the barrier of :593).
+    struct DynamicSet {
+        DevBuf<WideNode> wide;
+        DevBuf<TriIsect> tris;
+        DevBuf<TriFat> fat; // shading records: they hold v0 / edges / normals, which a refitted mesh changes with the trees
+        DevBuf<Instance> instances;
+        DevBuf<Light> lights;
+        DevBuf<BakeJob> jobs; // world-space copies to make (pt_bake.h)
+        uint64_t staticVersion = 0; // version of the static arrays this set holds (0: none)
+        int staticIndex = 0; // which of the context's two static scenes this state was built on
+        uint32_t numTris = 0, firstWorldNode = 0; // of that scene, as the kernels need them (SceneDev)
+        // pinned staging the asynchronous copies read from (grow-only, like the device buffers)
+        void* stage = nullptr;
+        size_t stageBytes = 0;
+        hipEvent_t stageRead = nullptr; // recorded on the copy stream after the copies out of `stage`
+        bool stageBusy = false;
+        uint32_t numLights = 0, rootRef = 0;
+        uint32_t foldedInstances = 0, instRootBase = 0, numInstRoots = 0;
+        DevBuf<float4> instFold; // the table of folded instance transforms (pt_trace.h)
+        DevBuf<uint32_t> instRootSrc;
+        uint32_t instFoldCount = 0;
+        uint32_t rootRefFolded = 0; // the same top level for the per-ray kernels: entry nodes in place of the instances that are a translation + uniform scale (pt_trace.h)
+        bool packetOk = false;
+        uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
+        bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
+        std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
+        hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
+        hipEvent_t lastUse = nullptr; // recorded on the render stream when the set stopped being the active one
+        bool used = false;
+    } dyn[2];
+    StaticScene stat[2];
+    StaticScene* st = &stat[0]; // the static scene the entry points work on: the current one, except while pt_upload_static_async converts the other
+    int statCur = 0; // static scene of the active dynamic set
+    int statPending = -1; // converted by pt_upload_static_async, waiting for a dynamic state and pt_frame_tick
+    uint64_t staticVersions = 0; // versions of the static arrays are drawn from one counter (a dynamic set compares the one it holds with the scene's)
     int active = 0; // set the render kernels read
     int pending = -1; // set with an upload in flight / finished that pt_frame_tick will switch to
     hipStream_t copyStream = nullptr;
@@ -174,24 +206,8 @@ struct pt_ctx {
     DevBuf<float4> accumShadow;
     ShadowQueueBuf shadowQ[kMaxPasses];
     bool mergePending = false;
-    std::vector<VertexShade> hostVerts;
-    std::vector<pt_vertex> rawVerts; // the caller's vertices as last handed in (pt_upload_static / pt_update_geometry)
-    bool hostNodeBoxesStale = false; // the boxes in hostSubNodes are older than rawVerts (pt_refit_vertices: the device refitted its own tree, nobody handed nodes in)
-    bool hostGeomStale = false; // hostTris / hostVerts / hostBottomNodes' boxes / sg.wide / sg.boxes / sg.fat are older than the caller's latest arrays (a refit
-                                // re-makes the device's copies on the device only; the host's are refreshed if the whole conversion ever runs again)
-    std::vector<uint32_t> denseOfNode; // caller's sub-BVH node -> pair node (0xFFFFFFFF: a leaf or a pad)
-    uint32_t numDensePairs = 0; // pair nodes [0, numDensePairs) mirror the caller's inner nodes; the rest split leaves of more than kMaxLeafTris
     DevBuf<uint8_t> texMaterial, texSky; // float4 or BGRA8 texels (Texture::format)
     SceneDev scene {};
-    std::vector<TriIsect> hostTris; // object-space intersection triangles (world-space copies of tiny instances are appended per pt_upload_dynamic)
-    std::vector<PairNode> hostBottomNodes; // bottom-level pair nodes (the top level is appended per pt_upload_dynamic)
-    std::vector<uint32_t> nodeRef; // reference sub-BVH node index -> device child reference
-    std::vector<uint32_t> subtreeDepth; // per reference node (roots queried)
-    std::vector<TriShade> hostTriShade; // vertex indices + material of every triangle (kept for pt_update_geometry)
-    std::vector<pt_material> hostMaterials;
-    std::vector<pt_sub_bvh_node> hostSubNodes; // the caller's sub-BVH as uploaded (topology; boxes are replaced by pt_update_geometry)
-    uint32_t numVerts = 0;
-    uint32_t numRefNodes = 0, numTris = 0;
     bool haveStatic = false, haveDynamic = false, haveCamera = false;
 
     // frame state
@@ -214,7 +230,6 @@ struct pt_ctx {
     uint32_t passCountsEntries = 0; // entries of the batch the hint comes from (0: no hint yet)
     uint32_t passCountsPending = 0; // entries of the batch whose copy is in flight
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
-    bool materialBins = false; // the surfaces are of more than one material type: k_shade shades its tiles in material order
     uint32_t packetUse = 0; // bit 0: primary rays, bit 1: their shadow rays, bit 2: the pt_intersect test hook
     uint64_t packetLaunches = 0, genLaunches = 0, bundleLaunches = 0;
     float4* accum = nullptr;
@@ -299,23 +314,26 @@ void refreshSceneView(pt_ctx* c)
     s.wide = d.wide.p;
     s.tris = d.tris.p;
     s.triFat = d.fat.p;
-    s.materials = c->materials.p;
+    s.materials = c->st->materials.p;
     s.instances = d.instances.p;
     s.lights = d.lights.p;
     s.numLights = d.numLights;
     s.rootRef = d.rootRef;
-    s.firstWorldNode = (uint32_t)c->sg.wide.size();
+    s.firstWorldNode = d.firstWorldNode; // (of the static scene the active dynamic set was built on)
     s.instRootBase = d.numInstRoots ? d.instRootBase : 0x7FFFFFFFu; // (nothing folded: no node lies behind the world-space ones)
     s.numInstRoots = d.numInstRoots;
     s.materialTex.texels = c->texMaterial.p;
     s.sky.texels = c->texSky.p;
-    s.numTriangles = c->numTris;
+    s.numTriangles = c->haveDynamic ? d.numTris : c->st->numTris;
 }
 
 template <typename T>
 int uploadVec(pt_ctx* c, DevBuf<T>& buf, const std::vector<T>& host)
 {
-    HIPCHK(c, buf.alloc(std::max<size_t>(host.size(), 1)));
+    // grow-only: a rebuilt scene of about the old size reuses the old buffers (hipFree waits for the whole device -- a frame loop that rebuilds a
+    // tree per frame, pt_upload_static_async, must not)
+    if (!buf.p || buf.n < std::max<size_t>(host.size(), 1))
+        HIPCHK(c, buf.alloc(std::max<size_t>(host.size() + host.size() / 8, 1)));
     if (!host.empty())
         HIPCHK(c, hipMemcpy(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     return PT_OK;
@@ -638,10 +656,10 @@ bool invertTransform(const float* m, double w[4][8])
 // split a leaf of more than kMaxLeafTris triangles (appended children first), the bounds of their triangles
 void refitPairBoxes(pt_ctx* c, const pt_vertex* verts, const pt_sub_bvh_node* nodes, bool onlyExtra)
 {
-    std::vector<PairNode>& pair = c->hostBottomNodes;
+    std::vector<PairNode>& pair = c->st->hostBottomNodes;
     if (!onlyExtra)
-        for (uint32_t i = 0; i < c->numRefNodes; i++) {
-            const uint32_t d = c->denseOfNode[i];
+        for (uint32_t i = 0; i < c->st->numRefNodes; i++) {
+            const uint32_t d = c->st->denseOfNode[i];
             if (d == 0xFFFFFFFFu)
                 continue;
             const uint32_t l = nodes[i].leftChildOrFirstTriangle;
@@ -650,13 +668,13 @@ void refitPairBoxes(pt_ctx* c, const pt_vertex* verts, const pt_sub_bvh_node* no
             pair[d].by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
             pair[d].bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
         }
-    if (pair.size() <= c->numDensePairs)
+    if (pair.size() <= c->st->numDensePairs)
         return;
     auto boxOf = [&](uint32_t ref, V3& lo, V3& hi) {
         lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
         if (refCount(ref) != 0u) {
             for (uint32_t t = refIndex(ref); t < refIndex(ref) + refCount(ref); t++) {
-                const TriShade& ts = c->hostTriShade[t];
+                const TriShade& ts = c->st->hostTriShade[t];
                 for (uint32_t vi : { ts.i0, ts.i1, ts.i2 }) {
                     const V3 p = mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]);
                     lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
@@ -669,7 +687,7 @@ void refitPairBoxes(pt_ctx* c, const pt_vertex* verts, const pt_sub_bvh_node* no
             hi = mk(fmaxf(n.bx.y, n.bx.w), fmaxf(n.by.y, n.by.w), fmaxf(n.bz.y, n.bz.w));
         }
     };
-    for (size_t j = c->numDensePairs; j < pair.size(); j++) {
+    for (size_t j = c->st->numDensePairs; j < pair.size(); j++) {
         V3 llo, lhi, rlo, rhi;
         boxOf(pair[j].left, llo, lhi);
         boxOf(pair[j].right, rlo, rhi);
@@ -682,8 +700,8 @@ void refitPairBoxes(pt_ctx* c, const pt_vertex* verts, const pt_sub_bvh_node* no
 // the packed 4-wide nodes of a refit on the host: same children in the same slots, new boxes (what k_refit_nodes does on the device)
 void refitWideOnHost(pt_ctx* c)
 {
-    pt_ctx::StaticGeom& g = c->sg;
-    const std::vector<PairNode>& pair = c->hostBottomNodes;
+    StaticScene::StaticGeom& g = c->st->sg;
+    const std::vector<PairNode>& pair = c->st->hostBottomNodes;
     for (size_t q = 0; q < g.wide.size(); q++) {
         float lo[4][3], hi[4][3];
         uint32_t refs[4];
@@ -712,10 +730,10 @@ void refitWideOnHost(pt_ctx* c)
 }
 
 // the caller's latest vertices / nodes: in the pinned staging memory after a device-side refit, in the host vectors otherwise
-inline const pt_vertex* latestVerts(const pt_ctx* c) { return c->sg.latestInStage ? (const pt_vertex*)c->sg.stage : c->rawVerts.data(); }
+inline const pt_vertex* latestVerts(const pt_ctx* c) { return c->st->sg.latestInStage ? (const pt_vertex*)c->st->sg.stage : c->st->rawVerts.data(); }
 inline const pt_sub_bvh_node* latestNodes(const pt_ctx* c)
 {
-    return c->sg.latestInStage ? (const pt_sub_bvh_node*)((const unsigned char*)c->sg.stage + (size_t)c->numVerts * sizeof(pt_vertex)) : c->hostSubNodes.data();
+    return c->st->sg.latestInStage ? (const pt_sub_bvh_node*)((const unsigned char*)c->st->sg.stage + (size_t)c->st->numVerts * sizeof(pt_vertex)) : c->st->hostSubNodes.data();
 }
 
 // The host's mirrors from the caller's arrays as last handed in (a refit re-makes the device's records on the device and leaves these behind): pair-node
@@ -724,20 +742,20 @@ inline const pt_sub_bvh_node* latestNodes(const pt_ctx* c)
 // the device alone nobody handed refitted nodes in.  Children lie after their parent (validated at upload): one reverse sweep.
 void refitHostNodeBoxes(pt_ctx* c)
 {
-    const pt_vertex* verts = c->rawVerts.data();
-    std::vector<pt_sub_bvh_node>& nodes = c->hostSubNodes;
+    const pt_vertex* verts = c->st->rawVerts.data();
+    std::vector<pt_sub_bvh_node>& nodes = c->st->hostSubNodes;
     for (size_t i = nodes.size(); i-- > 0;) {
         pt_sub_bvh_node& n = nodes[i];
         float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         if (n.triangleCount != 0) {
             for (uint32_t t = n.leftChildOrFirstTriangle; t < n.leftChildOrFirstTriangle + n.triangleCount; t++) {
-                const TriShade& ts = c->hostTriShade[t];
+                const TriShade& ts = c->st->hostTriShade[t];
                 for (uint32_t vi : { ts.i0, ts.i1, ts.i2 })
                     for (int a = 0; a < 3; a++)
                         lo[a] = fminf(lo[a], verts[vi].vertex[a]), hi[a] = fmaxf(hi[a], verts[vi].vertex[a]);
             }
         } else {
-            if (c->denseOfNode[i] == 0xFFFFFFFFu)
+            if (c->st->denseOfNode[i] == 0xFFFFFFFFu)
                 continue; // an unused pad
             const pt_sub_bvh_node &L = nodes[n.leftChildOrFirstTriangle], &R = nodes[n.leftChildOrFirstTriangle + 1];
             for (int a = 0; a < 3; a++)
@@ -746,56 +764,56 @@ void refitHostNodeBoxes(pt_ctx* c)
         for (int a = 0; a < 3; a++)
             n.min[a] = lo[a], n.max[a] = hi[a];
     }
-    c->hostNodeBoxesStale = false;
+    c->st->hostNodeBoxesStale = false;
 }
 
 void refreshHostGeometry(pt_ctx* c)
 {
-    if (!c->hostGeomStale)
+    if (!c->st->hostGeomStale)
         return;
-    if (c->hostNodeBoxesStale) { // (rawVerts is current then: pt_refit_vertices keeps it so)
+    if (c->st->hostNodeBoxesStale) { // (rawVerts is current then: pt_refit_vertices keeps it so)
         refitHostNodeBoxes(c);
-        refitPairBoxes(c, c->rawVerts.data(), c->hostSubNodes.data(), false);
-        if (c->sg.wide.size() == c->sg.kidEmpty.size() / 4)
+        refitPairBoxes(c, c->st->rawVerts.data(), c->st->hostSubNodes.data(), false);
+        if (c->st->sg.wide.size() == c->st->sg.kidEmpty.size() / 4)
             refitWideOnHost(c);
     }
     const pt_vertex* verts = latestVerts(c);
-    if (c->sg.latestInStage) {
+    if (c->st->sg.latestInStage) {
         refitPairBoxes(c, verts, latestNodes(c), false);
-        if (c->sg.wide.size() == c->sg.kidEmpty.size() / 4)
+        if (c->st->sg.wide.size() == c->st->sg.kidEmpty.size() / 4)
             refitWideOnHost(c);
     }
     auto P = [&](uint32_t vi) { return mk(verts[vi].vertex[0], verts[vi].vertex[1], verts[vi].vertex[2]); };
-    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
-        const TriShade& ts = c->hostTriShade[t];
+    for (size_t t = 0; t < c->st->hostTriShade.size(); t++) {
+        const TriShade& ts = c->st->hostTriShade[t];
         const V3 v0 = P(ts.i0);
         const V3 e1 = P(ts.i1) - v0, e2 = P(ts.i2) - v0; // shapes.cl:37-38
-        c->hostTris[t].a = make_float4(v0.x, v0.y, v0.z, e1.x);
-        c->hostTris[t].b = make_float4(e1.y, e1.z, e2.x, e2.y);
-        c->hostTris[t].c = make_float4(e2.z, 0.f, 0.f, 0.f);
+        c->st->hostTris[t].a = make_float4(v0.x, v0.y, v0.z, e1.x);
+        c->st->hostTris[t].b = make_float4(e1.y, e1.z, e2.x, e2.y);
+        c->st->hostTris[t].c = make_float4(e2.z, 0.f, 0.f, 0.f);
     }
-    for (size_t v = 0; v < c->numVerts; v++) {
-        c->hostVerts[v].n_u = make_float4(verts[v].normal[0], verts[v].normal[1], verts[v].normal[2], verts[v].texCoord[0]);
-        c->hostVerts[v].v_pad = make_float4(verts[v].texCoord[1], 0.f, 0.f, 0.f);
+    for (size_t v = 0; v < c->st->numVerts; v++) {
+        c->st->hostVerts[v].n_u = make_float4(verts[v].normal[0], verts[v].normal[1], verts[v].normal[2], verts[v].texCoord[0]);
+        c->st->hostVerts[v].v_pad = make_float4(verts[v].texCoord[1], 0.f, 0.f, 0.f);
     }
-    if (c->sg.latestInStage) { // the host vectors take the latest arrays over (the staging memory is rewritten by the next refit)
-        c->rawVerts.assign(verts, verts + c->numVerts);
+    if (c->st->sg.latestInStage) { // the host vectors take the latest arrays over (the staging memory is rewritten by the next refit)
+        c->st->rawVerts.assign(verts, verts + c->st->numVerts);
         const pt_sub_bvh_node* nodes = latestNodes(c);
-        c->hostSubNodes.assign(nodes, nodes + c->numRefNodes);
-        c->sg.latestInStage = false;
+        c->st->hostSubNodes.assign(nodes, nodes + c->st->numRefNodes);
+        c->st->sg.latestInStage = false;
     }
-    c->hostGeomStale = false;
+    c->st->hostGeomStale = false;
 }
 
 // shading records of the caller's triangles: one 128-byte line per triangle (TriFat, pt_device.h)
 void buildFat(pt_ctx* c)
 {
-    pt_ctx::StaticGeom& g = c->sg;
-    g.fat.resize(c->hostTriShade.size());
-    for (size_t t = 0; t < c->hostTriShade.size(); t++) {
-        const TriShade& ts = c->hostTriShade[t];
-        const VertexShade &a0 = c->hostVerts[ts.i0], &a1 = c->hostVerts[ts.i1], &a2 = c->hostVerts[ts.i2];
-        const TriIsect& ti = c->hostTris[t];
+    StaticScene::StaticGeom& g = c->st->sg;
+    g.fat.resize(c->st->hostTriShade.size());
+    for (size_t t = 0; t < c->st->hostTriShade.size(); t++) {
+        const TriShade& ts = c->st->hostTriShade[t];
+        const VertexShade &a0 = c->st->hostVerts[ts.i0], &a1 = c->st->hostVerts[ts.i1], &a2 = c->st->hostVerts[ts.i2];
+        const TriIsect& ti = c->st->hostTris[t];
         TriFat f {};
         f.n0u = a0.n_u, f.n1u = a1.n_u, f.n2u = a2.n_u;
         float mbits;
@@ -804,7 +822,7 @@ void buildFat(pt_ctx* c)
         f.e1e = make_float4(ti.a.w, ti.b.x, ti.b.y, ti.b.z); // edge1.xyz, edge2.x
         f.e2v = make_float4(ti.b.w, ti.c.x, ti.a.x, ti.a.y); // edge2.yz, v0.xy
         float m[12]; // the caller's 48-byte material record: colour (16 B), parameters (16 B), type (+ padding)
-        std::memcpy(m, &c->hostMaterials[ts.material], sizeof m);
+        std::memcpy(m, &c->st->hostMaterials[ts.material], sizeof m);
         f.v0c = make_float4(ti.a.z, m[0], m[1], m[2]);
         f.mat = make_float4(m[4], m[5], m[6], m[8]);
         g.fat[t] = f;
@@ -813,34 +831,34 @@ void buildFat(pt_ctx* c)
 
 int buildStaticGeom(pt_ctx* c)
 {
-    pt_ctx::StaticGeom& g = c->sg;
+    StaticScene::StaticGeom& g = c->st->sg;
     refreshHostGeometry(c);
-    const uint32_t nN = c->numRefNodes, nT = c->numTris;
-    const std::vector<WideKids> kids = collapseKids(c->hostBottomNodes, collapseCostsFromEnv());
+    const uint32_t nN = c->st->numRefNodes, nT = c->st->numTris;
+    const std::vector<WideKids> kids = collapseKids(c->st->hostBottomNodes, collapseCostsFromEnv());
     const uint32_t emptyRef = makeRef(nT, 1u); // the all-zero triangle stored right after the caller's triangles (det == 0: never hit)
     std::vector<uint8_t> isChild(nN, 0);
     for (uint32_t i = 0; i < nN; i++) {
-        const pt_sub_bvh_node& n = c->hostSubNodes[i];
+        const pt_sub_bvh_node& n = c->st->hostSubNodes[i];
         const uint32_t l = n.leftChildOrFirstTriangle;
-        if (n.triangleCount == 0 && c->nodeRef[i] != kRefNone && (uint64_t)l + 1 < nN)
+        if (n.triangleCount == 0 && c->st->nodeRef[i] != kRefNone && (uint64_t)l + 1 < nN)
             isChild[l] = isChild[l + 1] = 1;
     }
     std::vector<uint32_t> rootNodes;
     for (uint32_t i = 0; i < nN; i++)
-        if (c->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
+        if (c->st->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
             rootNodes.push_back(i);
     g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear(), g.kidBoxNode.clear();
-    std::vector<uint32_t> pairLeft(c->numDensePairs, 0u); // pair node -> the caller's node that is its left child
+    std::vector<uint32_t> pairLeft(c->st->numDensePairs, 0u); // pair node -> the caller's node that is its left child
     for (uint32_t i = 0; i < nN; i++)
-        if (c->denseOfNode[i] != 0xFFFFFFFFu)
-            pairLeft[c->denseOfNode[i]] = c->hostSubNodes[i].leftChildOrFirstTriangle;
+        if (c->st->denseOfNode[i] != 0xFFFFFFFFu)
+            pairLeft[c->st->denseOfNode[i]] = c->st->hostSubNodes[i].leftChildOrFirstTriangle;
     g.rootOfNode.assign(nN, -1);
     constexpr uint32_t kUnset = 0xFFFFFFFFu;
     std::vector<uint32_t> newIndex(kids.size(), kUnset), order;
     auto isInner = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < kids.size(); };
     for (uint32_t rn : rootNodes) {
-        pt_ctx::StaticGeom::Root root {};
-        const uint32_t rref = c->nodeRef[rn];
+        StaticScene::StaticGeom::Root root {};
+        const uint32_t rref = c->st->nodeRef[rn];
         root.nodeBase = (uint32_t)order.size();
         root.refBase = (uint32_t)g.refTri.size();
         root.bakeable = true;
@@ -886,7 +904,7 @@ int buildStaticGeom(pt_ctx* c)
                 g.kidSrc[q * 4 + k] = wk.src[k], g.kidEmpty[q * 4 + k] = wk.empty[k] ? 1u : 0u;
                 if (!wk.empty[k]) { // the caller's node whose box this slot takes: the left / right child of the node its pair mirrors
                     const uint32_t pr = wk.src[k] >> 1, side = wk.src[k] & 1u;
-                    g.kidBoxNode[q * 4 + k] = pr < c->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->numDensePairs) * 2u + side));
+                    g.kidBoxNode[q * 4 + k] = pr < c->st->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->st->numDensePairs) * 2u + side));
                 }
                 refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
                 if (!wk.empty[k] && !isInner(wk.ref[k])) {
@@ -909,7 +927,7 @@ int buildStaticGeom(pt_ctx* c)
     // earlier root had packed already) lies in an earlier one.  So: run by run in ascending order, each run in reverse -- every child
     // is final when its parent is reached.  (One reverse sweep over everything took 0 for the shared children: too small a bound.)
     g.stackNeed.assign(g.wide.size(), 0u);
-    for (const pt_ctx::StaticGeom::Root& root : g.roots)
+    for (const StaticScene::StaticGeom::Root& root : g.roots)
         for (size_t q = (size_t)root.nodeBase + root.numNodes; q-- > root.nodeBase;) {
             if (refCount(root.ref) != 0u || refIndex(root.ref) != root.nodeBase)
                 break; // no run of its own (a single leaf, or the root sits inside an earlier run)
@@ -942,8 +960,8 @@ int buildStaticGeom(pt_ctx* c)
     }
     buildFat(c);
     g.emptyRef = emptyRef;
-    g.version++;
-    g.topology++;
+    g.version = ++c->staticVersions;
+    g.topology = g.version;
     g.onDevice = false;
     return PT_OK;
 }
@@ -951,22 +969,22 @@ int buildStaticGeom(pt_ctx* c)
 // the static arrays' master copy in device memory (the two dynamic sets take theirs from it, device to device)
 int uploadStaticGeom(pt_ctx* c)
 {
-    pt_ctx::StaticGeom& g = c->sg;
+    StaticScene::StaticGeom& g = c->st->sg;
     if (g.onDevice)
         return PT_OK;
     // the copy stream may still be reading the old master (a set being refreshed from it)
     HIPCHK(c, hipStreamSynchronize(c->copyStream));
-    if (c->hostGeomStale) { // refitted before the master copy ever reached the device
+    if (c->st->hostGeomStale) { // refitted before the master copy ever reached the device
         refreshHostGeometry(c);
         buildFat(c);
     }
-    std::vector<TriIsect> tris = c->hostTris;
+    std::vector<TriIsect> tris = c->st->hostTris;
     tris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) }); // what an unused child slot refers to
     int rc;
     if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dBoxes, g.boxes)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs))
         || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat))
-        || (rc = uploadVec(c, g.dVerts, c->rawVerts)) || (rc = uploadVec(c, c->triShade, c->hostTriShade))
-        || (rc = uploadVec(c, g.dNodes, c->hostSubNodes)) || (rc = uploadVec(c, g.dKidBoxNode, g.kidBoxNode)))
+        || (rc = uploadVec(c, g.dVerts, c->st->rawVerts)) || (rc = uploadVec(c, c->st->triShade, c->st->hostTriShade))
+        || (rc = uploadVec(c, g.dNodes, c->st->hostSubNodes)) || (rc = uploadVec(c, g.dKidBoxNode, g.kidBoxNode)))
         return rc;
     g.onDevice = true;
     return PT_OK;
@@ -1446,7 +1464,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
         }
         if (generalShading(c))
             hipLaunchKernelGGL((k_shade<false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
-        else if (c->materialBins)
+        else if (c->st->materialBins)
             hipLaunchKernelGGL((k_shade<false, false, false, true>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
         else
             hipLaunchKernelGGL((k_shade<false, false>), dim3(head), dim3(kShadeBlock), 0, c->stream, a);
@@ -1804,19 +1822,22 @@ void pt_destroy(pt_ctx* c)
     for (auto* b : f4)
         b->release();
     c->texMaterial.release(), c->texSky.release();
-    c->nodes.release(), c->materials.release();
+    c->nodes.release();
+    for (StaticScene& sc : c->stat) {
+        StaticScene::StaticGeom& g = sc.sg;
+        sc.materials.release(), sc.triShade.release();
+        g.dWide.release(), g.dBoxes.release(), g.dLeafOfs.release(), g.dRefTri.release(), g.dTris.release(), g.dFat.release();
+        g.dVerts.release(), g.dNodes.release(), g.dKidBoxNode.release(), g.dExtra.release(), g.dParent.release(), g.dNeed.release(), g.dArrived.release();
+        if (g.stage) (void)hipHostFree(g.stage);
+        if (g.stageRead) (void)hipEventDestroy(g.stageRead);
+    }
     for (auto& d : c->dyn) {
-        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release(), d.jobs.release(), d.instFold.release();
+        d.wide.release(), d.tris.release(), d.fat.release(), d.instances.release(), d.lights.release(), d.jobs.release(), d.instFold.release(), d.instRootSrc.release();
         if (d.stage) (void)hipHostFree(d.stage);
         if (d.stageRead) (void)hipEventDestroy(d.stageRead);
         if (d.uploaded) (void)hipEventDestroy(d.uploaded);
         if (d.lastUse) (void)hipEventDestroy(d.lastUse);
     }
-    c->sg.dWide.release(), c->sg.dBoxes.release(), c->sg.dLeafOfs.release(), c->sg.dRefTri.release(), c->sg.dTris.release(), c->sg.dFat.release();
-    c->sg.dVerts.release(), c->triShade.release(), c->sg.dNodes.release(), c->sg.dKidBoxNode.release(), c->sg.dExtra.release();
-    c->sg.dParent.release(), c->sg.dNeed.release(), c->sg.dArrived.release();
-    if (c->sg.stage) (void)hipHostFree(c->sg.stage);
-    if (c->sg.stageRead) (void)hipEventDestroy(c->sg.stageRead);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     c->pixelList.release(), c->hitInst.release();
     c->accumPlanes.release(), c->pixelOrdinal.release(), c->resolveTmp.release(), c->activeFlag.release(), c->streams.release(), c->control.release(), c->totals.release(), c->spill.release();
@@ -1854,8 +1875,9 @@ int pt_set_stream(pt_ctx* c, void* hip_stream)
     return PT_OK;
 }
 
+// `async`: into c->st without touching the render stream or the dynamic state (pt_upload_static_async: c->st is the scene that is not current)
 static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
-    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN, bool async = false)
 {
     {
     if (!c)
@@ -1971,17 +1993,17 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
         hNodes.push_back(pn);
         return makeRef((uint32_t)hNodes.size() - 1, 0);
     };
-    c->nodeRef.assign(nN, kRefNone);
+    c->st->nodeRef.assign(nN, kRefNone);
     for (uint32_t i = 0; i < nN; i++) {
         if (nodes[i].triangleCount != 0) {
             if (nodes[i].triangleCount <= maxLeaf) {
-                c->nodeRef[i] = makeRef(nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount);
+                c->st->nodeRef[i] = makeRef(nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount);
             } else {
                 V3 lo, hi;
-                c->nodeRef[i] = leafRef({ nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount }, lo, hi);
+                c->st->nodeRef[i] = leafRef({ nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount }, lo, hi);
             }
         } else if (dense[i] != 0xFFFFFFFFu) {
-            c->nodeRef[i] = makeRef(dense[i], 0);
+            c->st->nodeRef[i] = makeRef(dense[i], 0);
         }
     }
     for (uint32_t i = 0; i < nN; i++) {
@@ -1994,49 +2016,55 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
         pn.bx = make_float4(L.min[0], L.max[0], R.min[0], R.max[0]);
         pn.by = make_float4(L.min[1], L.max[1], R.min[1], R.max[1]);
         pn.bz = make_float4(L.min[2], L.max[2], R.min[2], R.max[2]);
-        pn.left = c->nodeRef[l];
-        pn.right = c->nodeRef[l + 1];
+        pn.left = c->st->nodeRef[l];
+        pn.right = c->st->nodeRef[l + 1];
         if (pn.left == kRefNone || pn.right == kRefNone)
             return fail(c, PT_ERR_INVALID, "sub-BVH node %u: child is an unused pad node", i);
         hNodes[dense[i]] = pn;
     }
     // depth of every subtree (children have larger indices: one reverse sweep), for the stack bound
-    c->subtreeDepth.assign(nN, 0);
+    c->st->subtreeDepth.assign(nN, 0);
     for (uint32_t i = nN; i-- > 0;) {
         if (dense[i] == 0xFFFFFFFFu) {
             uint32_t extra = 0;
             for (uint32_t cnt = nodes[i].triangleCount; cnt > maxLeaf; cnt = cnt > 8u ? (cnt + 1) / 2 : cnt - 1) // (the cost-driven cut of a short run may peel one triangle off per level)
                 extra++;
-            c->subtreeDepth[i] = extra;
+            c->st->subtreeDepth[i] = extra;
         } else {
             const uint32_t l = nodes[i].leftChildOrFirstTriangle;
-            c->subtreeDepth[i] = 1 + std::max(c->subtreeDepth[l], c->subtreeDepth[l + 1]);
+            c->st->subtreeDepth[i] = 1 + std::max(c->st->subtreeDepth[l], c->st->subtreeDepth[l + 1]);
         }
     }
     if (hNodes.size() > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
 
     int rc;
-    c->hostTris = hTris;
-    c->hostBottomNodes = std::move(hNodes);
-    c->rawVerts.assign(verts, verts + nV);
-    c->hostGeomStale = false;
-    c->sg.latestInStage = false;
-    c->denseOfNode = dense;
-    c->numDensePairs = numInner;
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
-    if ((rc = uploadVec(c, c->materials, hMats)))
+    c->st->hostTris = hTris;
+    c->st->hostBottomNodes = std::move(hNodes);
+    c->st->rawVerts.assign(verts, verts + nV);
+    c->st->hostGeomStale = false;
+    c->st->sg.latestInStage = false;
+    c->st->denseOfNode = dense;
+    c->st->numDensePairs = numInner;
+    if (!async)
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
+    if ((rc = uploadVec(c, c->st->materials, hMats)))
         return rc;
-    c->hostTriShade = std::move(hShade);
-    c->hostMaterials.assign(mats, mats + nM);
-    c->hostSubNodes.assign(nodes, nodes + nN);
-    c->hostVerts = std::move(hVerts);
-    c->numVerts = nV;
-    c->numRefNodes = nN;
-    c->numTris = nT;
-    c->haveStatic = true;
-    c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
-    c->pending = -1;
+    c->st->hostTriShade = std::move(hShade);
+    c->st->hostMaterials.assign(mats, mats + nM);
+    c->st->hostSubNodes.assign(nodes, nodes + nN);
+    c->st->hostVerts = std::move(hVerts);
+    c->st->numVerts = nV;
+    c->st->numRefNodes = nN;
+    c->st->numTris = nT;
+    c->st->have = true;
+    c->st->hostNodeBoxesStale = false;
+    if (!async) {
+        c->haveStatic = true;
+        c->haveDynamic = false; // top-level leaves reference sub-BVH roots: must be re-uploaded
+        c->pending = -1;
+        c->statPending = -1; // (a rebuilt scene that was waiting for its frame tick is dropped with the dynamic state)
+    }
     {   // material types in use (emissive surfaces end a path in a few instructions: they do not count)
         uint32_t types = 0;
         for (uint32_t t = 0; t < nT; t++) {
@@ -2045,14 +2073,50 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
             types |= 1u << std::min(ty, 31u);
         }
         types &= ~(1u << MAT_EMISSIVE);
-        c->materialBins = (types & (types - 1u)) != 0u && (c->cfg.flags & PT_FLAG_MATERIAL_BINS) != 0u; // opt-in: measured slower (pt_shade.h)
+        c->st->materialBins = (types & (types - 1u)) != 0u && (c->cfg.flags & PT_FLAG_MATERIAL_BINS) != 0u; // opt-in: measured slower (pt_shade.h)
     }
-    c->sg.extraRoots.clear();
+    c->st->sg.extraRoots.clear();
     if ((rc = buildStaticGeom(c)))
         return rc;
-    refreshSceneView(c);
+    if (!async)
+        refreshSceneView(c);
     return PT_OK;
     }
+}
+
+// A REBUILT scene per frame as a frame-loop citizen (the other branch of MeshSequence::buildBvh, reference src/model/mesh_sequence.cpp:89-96, whose
+// result transferDynamicData uploads every tick, src/raytracer.cpp:510-568): the same arrays as pt_upload_static, converted into the context's
+// SECOND static scene and copied to the device without touching the render stream -- the frames enqueued so far, and any enqueued before the flip,
+// keep rendering the old trees.  Follow with pt_upload_dynamic_async (lights and top level OF THE NEW SCENE: its leaves name the new sub-BVH roots)
+// and pt_frame_tick, which adopts both.  pt_update_geometry / pt_refit_vertices keep addressing the current scene until then.
+int pt_upload_static_async(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
+    uint32_t nM, const pt_sub_bvh_node* nodes, uint32_t nN)
+{
+    return guarded(c, "pt_upload_static_async", [&]() -> int {
+        if (!c)
+            return PT_ERR_INVALID;
+        if (!c->haveStatic || !c->haveDynamic) // nothing is rendering yet: the plain upload does
+            return uploadStaticImpl(c, verts, nV, tris, nT, mats, nM, nodes, nN);
+        HIPCHK(c, hipSetDevice(c->device));
+        // the other scene's master copies may still be read by copies the copy stream has queued (a dynamic set refreshing itself from them,
+        // world-space copy kernels): that stream only -- the render stream is never waited for
+        HIPCHK(c, hipStreamSynchronize(c->copyStream));
+        const int target = 1 - c->statCur;
+        if (c->pending >= 0 && c->dyn[c->pending].staticIndex == target)
+            c->pending = -1; // a dynamic state built on the scene that is about to be replaced: never adopted
+        c->statPending = -1;
+        StaticScene* const cur = c->st;
+        c->st = &c->stat[target];
+        int rc = uploadStaticImpl(c, verts, nV, tris, nT, mats, nM, nodes, nN, true);
+        if (rc == PT_OK)
+            rc = uploadStaticGeom(c);
+        if (rc != PT_OK)
+            c->st->have = false;
+        c->st = cur;
+        if (rc == PT_OK)
+            c->statPending = target;
+        return rc;
+    });
 }
 
 int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_triangle* tris, uint32_t nT, const pt_material* mats,
@@ -2068,7 +2132,7 @@ int pt_upload_static(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_tr
 //
 // A refit cannot change what the conversion of pt_upload_static decided -- which descendants of a binary node became the children of
 // its 4-wide node (the collapse's split choices), the breadth-first packing, the leaves' triangle references, the stack bound -- so all
-// of that is kept (pt_ctx::StaticGeom::kidSrc / kidBoxNode / kidEmpty / leafOfs / refTri / stackNeed) and only what moves is re-made, ON THE
+// of that is kept (StaticScene::StaticGeom::kidSrc / kidBoxNode / kidEmpty / leafOfs / refTri / stackNeed) and only what moves is re-made, ON THE
 // DEVICE: the caller's vertex and node arrays travel as they are through pinned staging on the copy stream (an event of its own guards
 // the staging memory: no stream is synchronised), k_refit_nodes gathers every packed node's child boxes from the caller's nodes and
 // re-quantises it (quantiseWideNode: the host's routine), k_refit_tris re-makes the triangles' intersection and shading records.  The
@@ -2083,23 +2147,23 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
             return PT_ERR_INVALID;
         if (!c->haveStatic)
             return fail(c, PT_ERR_STATE, "pt_update_geometry: call pt_upload_static first");
-        if (!verts || !nodes || nV != c->numVerts || nN != c->numRefNodes)
-            return fail(c, PT_ERR_INVALID, "pt_update_geometry: the vertex and node counts must be the uploaded ones (%u, %u)", c->numVerts, c->numRefNodes);
+        if (!verts || !nodes || nV != c->st->numVerts || nN != c->st->numRefNodes)
+            return fail(c, PT_ERR_INVALID, "pt_update_geometry: the vertex and node counts must be the uploaded ones (%u, %u)", c->st->numVerts, c->st->numRefNodes);
         for (uint32_t i = 0; i < nN; i++)
-            if (nodes[i].leftChildOrFirstTriangle != c->hostSubNodes[i].leftChildOrFirstTriangle || nodes[i].triangleCount != c->hostSubNodes[i].triangleCount)
+            if (nodes[i].leftChildOrFirstTriangle != c->st->hostSubNodes[i].leftChildOrFirstTriangle || nodes[i].triangleCount != c->st->hostSubNodes[i].triangleCount)
                 return fail(c, PT_ERR_INVALID, "pt_update_geometry: node %u changed its links: a refit keeps the topology (use pt_upload_static for a rebuilt tree)", i);
         HIPCHK(c, hipSetDevice(c->device));
-        pt_ctx::StaticGeom& g = c->sg;
+        StaticScene::StaticGeom& g = c->st->sg;
         if (!g.onDevice) {
             // nothing of the old geometry is on the device yet: everything on the host, the first upload takes it from the host arrays
             refreshHostGeometry(c); // (an earlier device-side refit may have left the host mirrors behind)
             refitPairBoxes(c, verts, nodes, false);
             refitWideOnHost(c);
-            c->rawVerts.assign(verts, verts + nV);
-            c->hostSubNodes.assign(nodes, nodes + nN);
+            c->st->rawVerts.assign(verts, verts + nV);
+            c->st->hostSubNodes.assign(nodes, nodes + nN);
             g.latestInStage = false;
-            c->hostGeomStale = true; // hostTris / hostVerts / sg.fat follow at the upload
-            g.version++;
+            c->st->hostGeomStale = true; // hostTris / hostVerts / sg.fat follow at the upload
+            g.version = ++c->staticVersions;
             return PT_OK;
         }
         // ---- the device's master copy: the caller's vertices and nodes AS THEY ARE through pinned staging on the copy stream; the packed nodes
@@ -2108,10 +2172,10 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
         static_assert(sizeof(VertexIn) == sizeof(pt_vertex), "k_refit_tris reads the caller's vertex records as they are");
         static_assert(sizeof(SubNodeIn) == sizeof(pt_sub_bvh_node), "k_refit_nodes reads the caller's node records as they are");
         std::vector<float> extra; // boxes of the pair nodes that split an oversized leaf (rare): recomputed here
-        if (c->hostBottomNodes.size() > c->numDensePairs) {
+        if (c->st->hostBottomNodes.size() > c->st->numDensePairs) {
             refitPairBoxes(c, verts, nodes, true);
-            for (size_t j = c->numDensePairs; j < c->hostBottomNodes.size(); j++) {
-                const PairNode& n = c->hostBottomNodes[j];
+            for (size_t j = c->st->numDensePairs; j < c->st->hostBottomNodes.size(); j++) {
+                const PairNode& n = c->st->hostBottomNodes[j];
                 const float b[12] = { n.bx.x, n.by.x, n.bz.x, n.bx.y, n.by.y, n.bz.y, n.bx.z, n.by.z, n.bz.z, n.bx.w, n.by.w, n.bz.w };
                 extra.insert(extra.end(), b, b + 12);
             }
@@ -2137,8 +2201,8 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
         std::memcpy(st, verts, bytesV);
         std::memcpy(st + bytesV, nodes, bytesN);
         g.latestInStage = true;
-        c->hostGeomStale = true;
-        g.version++;
+        c->st->hostGeomStale = true;
+        g.version = ++c->staticVersions;
         HIPCHK(c, hipMemcpyAsync(g.dVerts.p, st, bytesV, hipMemcpyHostToDevice, c->copyStream));
         HIPCHK(c, hipMemcpyAsync(g.dNodes.p, st + bytesV, bytesN, hipMemcpyHostToDevice, c->copyStream));
         if (bytesE) {
@@ -2156,8 +2220,8 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
             hipLaunchKernelGGL(k_refit_nodes, dim3((rn.n + 127u) / 128u), dim3(128), 0, c->copyStream, rn);
         }
         RefitArgs ra {};
-        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->triShade.p, ra.mats = c->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->numTris;
-        hipLaunchKernelGGL(k_refit_tris, dim3((c->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
+        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->st->triShade.p, ra.mats = c->st->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->st->numTris;
+        hipLaunchKernelGGL(k_refit_tris, dim3((c->st->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
         HIPCHK(c, hipGetLastError());
         return PT_OK;
     });
@@ -2166,7 +2230,7 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
 // Who a packed node reports to in a bottom-up pass, and how many arrivals complete it (k_refit_tree).  Made once per topology.
 static int ensureRefitTables(pt_ctx* c)
 {
-    pt_ctx::StaticGeom& g = c->sg;
+    StaticScene::StaticGeom& g = c->st->sg;
     if (g.refitTablesFor == g.topology)
         return PT_OK;
     const size_t n = g.wide.size();
@@ -2193,8 +2257,9 @@ static int ensureRefitTables(pt_ctx* c)
     int rc;
     if ((rc = uploadVec(c, g.dParent, parent)) || (rc = uploadVec(c, g.dNeed, need)))
         return rc;
-    HIPCHK(c, g.dArrived.alloc(std::max<size_t>(n, 1)));
-    HIPCHK(c, hipMemset(g.dArrived.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+    if (!g.dArrived.p || g.dArrived.n < std::max<size_t>(n, 1))
+        HIPCHK(c, g.dArrived.alloc(std::max<size_t>(n + n / 8, 1)));
+    HIPCHK(c, hipMemset(g.dArrived.p, 0, g.dArrived.n * sizeof(uint32_t)));
     return PT_OK;
 }
 
@@ -2211,10 +2276,10 @@ int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, u
             return PT_ERR_INVALID;
         if (!c->haveStatic)
             return fail(c, PT_ERR_STATE, "pt_refit_vertices: call pt_upload_static first");
-        if (!verts || nV == 0 || (uint64_t)firstVertex + nV > c->numVerts)
-            return fail(c, PT_ERR_INVALID, "pt_refit_vertices: [%u, %u + %u) is not a range of the %u uploaded vertices", firstVertex, firstVertex, nV, c->numVerts);
+        if (!verts || nV == 0 || (uint64_t)firstVertex + nV > c->st->numVerts)
+            return fail(c, PT_ERR_INVALID, "pt_refit_vertices: [%u, %u + %u) is not a range of the %u uploaded vertices", firstVertex, firstVertex, nV, c->st->numVerts);
         HIPCHK(c, hipSetDevice(c->device));
-        pt_ctx::StaticGeom& g = c->sg;
+        StaticScene::StaticGeom& g = c->st->sg;
         int rc;
         if ((rc = uploadStaticGeom(c)) || (rc = ensureRefitTables(c))) // (the master copy reaches the device with the first dynamic upload at the latest)
             return rc;
@@ -2229,13 +2294,13 @@ int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, u
             }
             const pt_vertex* sv = latestVerts(c);
             const pt_sub_bvh_node* sn = latestNodes(c);
-            c->rawVerts.assign(sv, sv + c->numVerts);
-            c->hostSubNodes.assign(sn, sn + c->numRefNodes);
+            c->st->rawVerts.assign(sv, sv + c->st->numVerts);
+            c->st->hostSubNodes.assign(sn, sn + c->st->numRefNodes);
             g.latestInStage = false;
         }
-        std::memcpy(c->rawVerts.data() + firstVertex, verts, (size_t)nV * sizeof(pt_vertex));
-        c->hostNodeBoxesStale = true;
-        c->hostGeomStale = true;
+        std::memcpy(c->st->rawVerts.data() + firstVertex, verts, (size_t)nV * sizeof(pt_vertex));
+        c->st->hostNodeBoxesStale = true;
+        c->st->hostGeomStale = true;
         const size_t bytesV = (size_t)nV * sizeof(pt_vertex);
         if (!g.stageRead)
             HIPCHK(c, hipEventCreateWithFlags(&g.stageRead, hipEventDisableTiming));
@@ -2251,20 +2316,20 @@ int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, u
             HIPCHK(c, hipHostMalloc(&g.stage, g.stageBytes, hipHostMallocDefault));
         }
         std::memcpy(g.stage, verts, bytesV);
-        g.version++;
+        g.version = ++c->staticVersions;
         HIPCHK(c, hipMemcpyAsync(g.dVerts.p + firstVertex, g.stage, bytesV, hipMemcpyHostToDevice, c->copyStream));
         HIPCHK(c, hipEventRecord(g.stageRead, c->copyStream));
         g.stageBusy = true;
         static_assert(sizeof(VertexIn) == sizeof(pt_vertex), "the refit kernels read the caller's vertex records as they are");
         if (!g.wide.empty()) {
             RefitTreeArgs rt {};
-            rt.verts = (const VertexIn*)g.dVerts.p, rt.tri = c->triShade.p, rt.wide = g.dWide.p, rt.boxes = g.dBoxes.p;
+            rt.verts = (const VertexIn*)g.dVerts.p, rt.tri = c->st->triShade.p, rt.wide = g.dWide.p, rt.boxes = g.dBoxes.p;
             rt.parent = g.dParent.p, rt.need = g.dNeed.p, rt.arrived = g.dArrived.p, rt.emptyRef = g.emptyRef, rt.n = (uint32_t)g.wide.size();
             hipLaunchKernelGGL(k_refit_tree, dim3((rt.n + 127u) / 128u), dim3(128), 0, c->copyStream, rt);
         }
         RefitArgs ra {};
-        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->triShade.p, ra.mats = c->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->numTris;
-        hipLaunchKernelGGL(k_refit_tris, dim3((c->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
+        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->st->triShade.p, ra.mats = c->st->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = c->st->numTris;
+        hipLaunchKernelGGL(k_refit_tris, dim3((c->st->numTris + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
         HIPCHK(c, hipGetLastError());
         return PT_OK;
     });
@@ -2275,7 +2340,7 @@ int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, u
 namespace {
 
 // What the host-side conversion of one dynamic state produces (no device call in it): the top level, the instance table, the lights,
-// and the list of world-space copies the device is to make.  Everything below the top level is static (pt_ctx::StaticGeom).
+// and the list of world-space copies the device is to make.  Everything below the top level is static (StaticScene::StaticGeom).
 struct DynamicHost {
     std::vector<WideNode> topWide; // goes to wide[staticNodes ...]
     std::vector<Instance> instances;
@@ -2285,6 +2350,7 @@ struct DynamicHost {
     uint32_t numLights = 0, rootRef = 0, rootRefFolded = 0;
     uint32_t foldedInstances = 0; // instances the per-ray kernels walk without parking (translation + uniform scale, pt_trace.h)
     std::vector<WideNode> instRoots; // their copies of their meshes' root nodes (one slot per instance), stored at instRootBase: the last run of the node array
+    std::vector<uint32_t> instRootSrc; // per instance: the packed node its root copy is made from ON THE DEVICE (k_inst_roots), ~0: instRoots[k] holds it already
     std::vector<float4> instFold; // entry 1 + k: (1 / s, w) of instance k; entry 0 and the instances on the general route: the identity
     uint32_t instRootBase = 0;
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
@@ -2295,7 +2361,7 @@ struct DynamicHost {
 
 int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
 {
-    pt_ctx::StaticGeom& sg = c->sg;
+    StaticScene::StaticGeom& sg = c->st->sg;
     // a top-level leaf may name any node of the caller's sub-BVH array; the ones that are not mesh roots become roots of their own
     {
         bool grown = false;
@@ -2303,7 +2369,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             const pt_top_bvh_node& n = topNodes[i];
             if (!n.isLeaf)
                 continue;
-            if (n.a >= c->numRefNodes || c->nodeRef[n.a] == kRefNone)
+            if (n.a >= c->st->numRefNodes || c->st->nodeRef[n.a] == kRefNone)
                 return fail(c, PT_ERR_INVALID, "top-level leaf %u: sub-BVH root %u is not a valid node", i, n.a);
             if (sg.rootOfNode[n.a] < 0 && std::find(sg.extraRoots.begin(), sg.extraRoots.end(), n.a) == sg.extraRoots.end()) {
                 sg.extraRoots.push_back(n.a);
@@ -2317,7 +2383,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         }
     }
     const uint32_t staticNodes = (uint32_t)sg.wide.size();
-    const uint32_t staticTris = c->numTris + 1u; // the caller's triangles + the all-zero one
+    const uint32_t staticTris = c->st->numTris + 1u; // the caller's triangles + the all-zero one
     // ---- instances (one per top-level leaf) and top-level pair nodes (one per top-level inner node)
     std::vector<Instance>& hInst = out.instances;
     hInst.clear();
@@ -2329,8 +2395,8 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     for (uint32_t i = 0; i < nTop; i++) {
         const pt_top_bvh_node& n = topNodes[i];
         if (n.isLeaf) {
-            maxBottomDepth = std::max(maxBottomDepth, c->subtreeDepth[n.a] + 1);
-            const pt_ctx::StaticGeom::Root& root = sg.roots[sg.rootOfNode[n.a]];
+            maxBottomDepth = std::max(maxBottomDepth, c->st->subtreeDepth[n.a] + 1);
+            const StaticScene::StaticGeom::Root& root = sg.roots[sg.rootOfNode[n.a]];
             Instance in {};
             const float* m = n.invTransform; // column-major
             in.r0 = make_float4(m[0], m[4], m[8], m[12]);
@@ -2368,7 +2434,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         uint64_t usedBytes = 0;
         uint32_t nextNode = staticNodes + out.topSlots, nextTri = staticTris;
         auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
-            const pt_ctx::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
+            const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
             const bool single = refCount(root.ref) != 0u; // the mesh is one leaf
             if (single != !wholeTrees)
                 return;
@@ -2518,6 +2584,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     out.rootRefFolded = rootRef;
     out.foldedInstances = 0;
     out.instRoots.clear();
+    out.instRootSrc.clear();
     out.instFold.clear();
     out.instRootBase = staticNodes + out.topSlots + out.bakedNodes;
     {
@@ -2567,6 +2634,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             // the instances' root copies and the table of their transforms (entry 0: the identity; instances on the general route: the identity too --
             // their lanes hold the instance-space ray in registers)
             out.instRoots.assign(hInst.size(), WideNode {});
+            out.instRootSrc.assign(hInst.size(), 0xFFFFFFFFu);
             out.instFold.assign(hInst.size() + 1, make_float4(1.f, 0.f, 0.f, 0.f));
             for (size_t k = 0; k < hInst.size(); k++) {
                 if (!folded[k])
@@ -2575,7 +2643,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
                 out.instFold[k + 1] = make_float4(in.r0.x, in.r0.w, in.r1.w, in.r2.w);
                 in.folded = 1u;
                 if (refCount(in.rootRef) == 0u) {
-                    out.instRoots[k] = sg.wide[refIndex(in.rootRef)]; // the mesh's packed root node as it is: object space, children in the shared tree
+                    out.instRootSrc[k] = refIndex(in.rootRef); // the mesh's packed root node as the device holds it (the host's mirror goes stale with a refit): object space, children in the shared tree
                 } else { // the mesh is a single leaf: a one-child node around it -- the top-level leaf's box taken into object space, a few ulps outwards
                     const pt_top_bvh_node& leaf = topNodes[in.topNode];
                     float lo[4][3], hi[4][3];
@@ -2646,25 +2714,33 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     if (nL > 0 && !lights)
         return fail(c, PT_ERR_INVALID, "pt_upload_dynamic: null light array");
     HIPCHK(c, hipSetDevice(c->device));
+    // a rebuilt scene is waiting (pt_upload_static_async): this state is built on IT -- its top-level leaves name the new sub-BVH roots
+    struct UseScene {
+        pt_ctx* c;
+        StaticScene* saved;
+        ~UseScene() { c->st = saved; }
+    } useScene { c, c->st };
+    if (c->statPending >= 0)
+        c->st = &c->stat[c->statPending];
     DynamicHost h;
     int rc = convertDynamic(c, lights, nL, topNodes, nTop, topRoot, h);
     if (rc || (rc = uploadStaticGeom(c)))
         return rc;
-    pt_ctx::StaticGeom& sg = c->sg;
+    StaticScene::StaticGeom& sg = c->st->sg;
     const int target = c->haveDynamic ? 1 - c->active : c->active; // nothing active yet: fill the active set itself
     pt_ctx::DynamicSet& d = c->dyn[target];
     // the copies may not start before the renders that still read this set are done (it was the active set until the last tick),
     // nor before an earlier, never-adopted upload into it has finished (same stream: ordered)
     if (d.used)
         HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
-    const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->numTris + 1;
+    const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->st->numTris + 1;
     const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size(), needTris = staticTris + h.bakedTris;
-    const size_t bytes[6] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
-        h.jobs.size() * sizeof(BakeJob), h.instRoots.size() * sizeof(WideNode), h.instFold.size() * sizeof(float4) };
-    const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4] + bytes[5];
+    const size_t bytes[7] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
+        h.jobs.size() * sizeof(BakeJob), h.instRoots.size() * sizeof(WideNode), h.instFold.size() * sizeof(float4), h.instRootSrc.size() * sizeof(uint32_t) };
+    const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4] + bytes[5] + bytes[6];
     if (d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size() || d.instances.n < std::max<size_t>(h.instances.size(), 1)
         || d.lights.n < std::max<size_t>(h.lights.size(), 1) || d.jobs.n < std::max<size_t>(h.jobs.size(), 1) || d.instFold.n < std::max<size_t>(h.instFold.size(), 1)
-        || d.stageBytes < std::max<size_t>(total, 1)) {
+        || d.instRootSrc.n < std::max<size_t>(h.instRootSrc.size(), 1) || d.stageBytes < std::max<size_t>(total, 1)) {
         // growing frees device memory, which the runtime only does once nothing uses it: wait for both streams (rare: the first
         // uploads, or a state with more world-space copies than any before)
         HIPCHK(c, hipStreamSynchronize(c->copyStream));
@@ -2673,7 +2749,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         const bool regrown = d.wide.n < needWide || d.tris.n < needTris || d.fat.n < sg.fat.size();
         if ((rc = growTo(c, d.wide, needWide)) || (rc = growTo(c, d.tris, needTris)) || (rc = growTo(c, d.fat, sg.fat.size()))
             || (rc = growTo(c, d.instances, h.instances.size())) || (rc = growTo(c, d.lights, h.lights.size())) || (rc = growTo(c, d.jobs, h.jobs.size()))
-            || (rc = growTo(c, d.instFold, h.instFold.size())))
+            || (rc = growTo(c, d.instFold, h.instFold.size())) || (rc = growTo(c, d.instRootSrc, h.instRootSrc.size())))
             return rc;
         if (regrown)
             d.staticVersion = 0; // fresh buffers: the static arrays have to be put in again
@@ -2699,9 +2775,9 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         d.staticVersion = sg.version;
     }
     unsigned char* st = (unsigned char*)d.stage;
-    const void* src[6] = { h.topWide.data(), h.instances.data(), h.lights.data(), h.jobs.data(), h.instRoots.data(), h.instFold.data() };
-    void* dst[6] = { d.wide.p + staticNodes, d.instances.p, d.lights.p, d.jobs.p, d.wide.p + h.instRootBase, d.instFold.p };
-    for (int k = 0; k < 6; k++) {
+    const void* src[7] = { h.topWide.data(), h.instances.data(), h.lights.data(), h.jobs.data(), h.instRoots.data(), h.instFold.data(), h.instRootSrc.data() };
+    void* dst[7] = { d.wide.p + staticNodes, d.instances.p, d.lights.p, d.jobs.p, d.wide.p + h.instRootBase, d.instFold.p, d.instRootSrc.p };
+    for (int k = 0; k < 7; k++) {
         if (bytes[k] == 0)
             continue;
         std::memcpy(st, src[k], bytes[k]);
@@ -2711,6 +2787,10 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     if (total) {
         HIPCHK(c, hipEventRecord(d.stageRead, c->copyStream));
         d.stageBusy = true;
+    }
+    if (!h.instRootSrc.empty()) { // the folded instances' copies of their meshes' root nodes, from the set's own (just refreshed) copy of the static nodes
+        const uint32_t n = (uint32_t)h.instRootSrc.size();
+        hipLaunchKernelGGL(k_inst_roots, dim3((n + 63u) / 64u), dim3(64), 0, c->copyStream, d.wide.p, d.instRootSrc.p, d.wide.p + h.instRootBase, n);
     }
     if (!h.jobs.empty()) { // the world-space copies: one thread per (copy, node) and per (copy, triangle reference)
         BakeArgs ba {};
@@ -2732,6 +2812,8 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     HIPCHK(c, hipEventRecord(d.uploaded, c->copyStream));
     d.numLights = h.numLights;
     d.rootRef = h.rootRef;
+    d.staticIndex = (int)(c->st - c->stat);
+    d.numTris = c->st->numTris, d.firstWorldNode = (uint32_t)sg.wide.size();
     d.rootRefFolded = h.rootRefFolded;
     d.foldedInstances = h.foldedInstances;
     d.instRootBase = h.instRootBase, d.numInstRoots = (uint32_t)h.instRoots.size(), d.instFoldCount = (uint32_t)h.instFold.size();
@@ -2765,6 +2847,12 @@ int pt_frame_tick(pt_ctx* c)
     c->active = c->pending;
     c->pending = -1;
     c->haveDynamic = true;
+    if (next.staticIndex != c->statCur) { // the state was built on a rebuilt scene (pt_upload_static_async): that scene is the current one from here on
+        c->statCur = next.staticIndex;
+        c->st = &c->stat[c->statCur];
+    }
+    if (c->statPending == c->statCur)
+        c->statPending = -1;
     refreshSceneView(c);
     return PT_OK;
 }
@@ -3362,7 +3450,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         hH[i] = make_float4(prim >= 0 ? io->t[i] : INFINITY, io->u[i], io->v[i], fprim);
         int32_t ti = io->inst[i];
         hI[i] = (ti >= 0 && (size_t)ti < topToInst.size()) ? topToInst[ti] : -1;
-        if (prim >= 0 && (hI[i] < 0 || (uint32_t)prim >= c->numTris))
+        if (prim >= 0 && (hI[i] < 0 || (uint32_t)prim >= c->st->numTris))
             return fail(c, PT_ERR_INVALID, "pt_shade_batch: entry %u has an invalid prim/inst", i);
     }
     RayQueueBuf in, out, stagedDummy;

@@ -94,6 +94,19 @@ void RayTracer::updateGeometry()
     }
 }
 
+// A rebuilt scene (meshes replaced, topology changed -- the else branch of MeshSequence::buildBvh, reference src/model/mesh_sequence.cpp:89-96):
+// everything static is flattened again and handed to the device library's second static set on the copy stream; frames keep rendering the old scene
+// until the next frameTick, which uploads the new scene's lights and top level and adopts both.
+void RayTracer::rebuildGeometry()
+{
+    flattenStatic(*m_scene, m_flat);
+    for (MeshBvhPair& pair : m_scene->getMeshes())
+        pair.uploadedGeneration = pair.meshPtr->generation();
+    check(pt_upload_static_async(m_ctx, m_flat.vertices.data(), (uint32_t)m_flat.vertices.size(), m_flat.triangles.data(), (uint32_t)m_flat.triangles.size(),
+              m_flat.materials.data(), (uint32_t)m_flat.materials.size(), m_flat.subBvhNodes.data(), (uint32_t)m_flat.subBvhNodes.size()),
+        "pt_upload_static_async");
+}
+
 void RayTracer::rayTrace(const Camera& camera)
 {
     const CameraData cam = camera.get_camera_data();

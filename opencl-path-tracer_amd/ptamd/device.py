@@ -62,7 +62,7 @@ class ShadeBatchIO(C.Structure):
                                              "soz", "sdx", "sdy", "sdz", "slen", "sc_r", "sc_g", "sc_b")])
 
 
-EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_upload_static", "pt_upload_dynamic",
+EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_upload_static", "pt_upload_static_async", "pt_upload_dynamic",
            "pt_upload_dynamic_async", "pt_frame_tick", "pt_update_geometry", "pt_refit_vertices",
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
            "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
@@ -93,6 +93,7 @@ def lib():
         l.pt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         l.pt_upload_static.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                        C.c_uint32, C.c_void_p, C.c_uint32]
+        l.pt_upload_static_async.argtypes = l.pt_upload_static.argtypes
         l.pt_upload_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         l.pt_upload_dynamic_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         l.pt_frame_tick.argtypes = [C.c_void_p]
@@ -174,6 +175,12 @@ class Context:
             self.upload_texture(1, sky)
         if material_textures is not None:
             self.upload_texture(0, material_textures)
+
+    def upload_static_async(self, flat):
+        """A rebuilt scene, converted and copied beside the one that is rendering (the render stream is not synchronised); follow with
+        upload_dynamic_async(flat) and frame_tick(), which adopts both."""
+        self._chk(lib().pt_upload_static_async(self._h, _p(flat.vertices), len(flat.vertices), _p(flat.triangles), len(flat.triangles),
+                                               _p(flat.materials), len(flat.materials), _p(flat.sub_nodes), len(flat.sub_nodes)), "pt_upload_static_async")
 
     def upload_dynamic(self, flat):
         self._chk(lib().pt_upload_dynamic(self._h, _p(flat.lights), len(flat.lights), _p(flat.top_nodes),

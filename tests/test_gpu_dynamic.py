@@ -405,3 +405,78 @@ def test_device_refit_then_a_rebuild_of_the_static_part_and_partial_ranges(gpu):
     for key in ("t", "u", "v", "prim", "inst"):
         assert np.array_equal(got[key], want[key]), ("rebuild after a device refit", key)
     ctx.close()
+
+
+def test_a_rebuilt_tree_per_frame_is_adopted_at_the_tick_while_the_old_one_renders(gpu):
+    """pt_upload_static_async (round 5; the other branch of MeshSequence::buildBvh, reference src/model/mesh_sequence.cpp:89-96: a NEW tree per frame):
+    a rebuilt scene is converted and copied beside the one that renders; frames enqueued before the tick still show the old scene (bit for bit what a
+    context that only ever saw it renders), frames after it the new one; closest hits equal the oracle's on the rebuilt arrays.  Three rebuilds in a
+    row use both static sets in turn; a refit (device route) of the adopted scene and an async rebuild that is replaced before its tick work too."""
+    mat = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
+    mb = scenes._MeshBuilder()
+    mats = scenes._room_materials()
+    scenes._room(mb, mats)
+    room = mb.build(mats, H.BVH_BINNED_SAH)
+    cam = scenes.blob_room(W, Hh, level=3).camera
+    o, d = U.random_rays(20000, 4, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
+
+    def scene_of(level, k):
+        v, f = scenes.icosphere(level)
+        p = (v * (0.35 + 0.05 * k) * (1.0 + 0.15 * np.sin(3.0 * k + 5.0 * v[:, :1]))).astype(np.float32)
+        mesh = H.Mesh(p, f.astype(np.uint32), [mat], builder=H.BVH_BINNED_FAST)
+        sc = H.Scene()
+        sc.add_node(room)
+        sc.add_node(mesh, location=(0.05 * k, 0.8, 0.1), scale=(1.2, 1.2, 1.2))
+        return sc, mesh, sc.flatten()
+
+    def fresh(flat):
+        c = U.make_ctx(gpu, flat, W, Hh, camera=cam, seed=8, samples_in_flight=1)
+        h = c.intersect(o, d)
+        c.render(8)
+        a = c.read_accum().copy()
+        c.close()
+        return h, a
+
+    sc0, _, flat0 = scene_of(3, 0)
+    ctx = U.make_ctx(gpu, flat0, W, Hh, camera=cam, seed=8, samples_in_flight=1)
+    _, a_prev = fresh(flat0)
+    for k, level in ((1, 3), (2, 2), (3, 3)):  # different triangle counts: the sets' buffers grow and are reused
+        sck, meshk, flatk = scene_of(level, k)
+        ctx.upload_static_async(flatk)
+        ctx.upload_dynamic_async(flatk)
+        ctx.clear()
+        ctx.render(8, sync=False)  # enqueued BEFORE the tick: the old scene
+        old = ctx.read_accum().copy()
+        assert np.array_equal(old, a_prev), f"rebuild {k}: a frame before the tick must show the old scene"
+        ctx.frame_tick()
+        ctx.clear()
+        ctx.render(8)
+        want_h, want_a = fresh(flatk)
+        assert np.array_equal(ctx.read_accum(), want_a), f"rebuild {k}: frames after the tick != a fresh context on the rebuilt arrays"
+        got_h = ctx.intersect(o, d)
+        for key in ("t", "u", "v", "prim", "inst"):
+            assert np.array_equal(got_h[key], want_h[key]), (k, key)
+        info = U.compare_hits(flatk, got_h, O.intersect_batch(O.BoundScene(flatk), o, d, threads=8), edge_flip_frac=5e-4)
+        assert info["n"] > 5000
+        a_prev = want_a
+    # the adopted scene deforms: the device-route refit addresses it
+    verts = meshk.geometry()[0]["vertex"][:, :3]
+    meshk.refit((verts * np.float32(0.9)).astype(np.float32))
+    ctx.refit_vertices(sck.mesh_offsets(meshk)[0], meshk.vertices_view())
+    ctx.upload_dynamic(sck.flatten_dynamic_only()[0])
+    flat_r = sck.flatten()
+    got_h, (want_h, _) = ctx.intersect(o, d), fresh(flat_r)
+    for key in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got_h[key], want_h[key]), ("refit of the adopted scene", key)
+    # a rebuild that is replaced by another one before its tick: only the last one is adopted
+    _, _, flat_a = scene_of(3, 7)
+    _, _, flat_b = scene_of(2, 8)
+    ctx.upload_static_async(flat_a)
+    ctx.upload_dynamic_async(flat_a)
+    ctx.upload_static_async(flat_b)
+    ctx.upload_dynamic_async(flat_b)
+    ctx.frame_tick()
+    ctx.clear()
+    ctx.render(8)
+    assert np.array_equal(ctx.read_accum(), fresh(flat_b)[1])
+    ctx.close()
