@@ -90,7 +90,7 @@ struct Instance {
     uint32_t rootRef; // makeRef
     uint32_t topNode; // index of the top-level leaf (reported as `inst` in hit records)
     uint32_t folded; // the per-ray kernels walk this instance without parking (translation + uniform scale: pt_trace.h); its table entry is not the identity
-    uint32_t _p1;
+    uint32_t simple; // the transform is a translation + uniform scale: a bundle of camera rays enters by scaling its beam (pt_packet_multi.h)
 };
 
 struct Material { // the reference's 48-byte record, read as 3 x float4

@@ -225,21 +225,36 @@ __global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_mult
                         const u4v_t m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
                         const float4 r0 = make_float4(asF(m0.x), asF(m0.y), asF(m0.z), asF(m0.w)), r1 = make_float4(asF(m1.x), asF(m1.y), asF(m1.z), asF(m1.w)),
                                      r2 = make_float4(asF(m2.x), asF(m2.y), asF(m2.z), asF(m2.w));
-                        V3 to = co, td[R];
+                        if (uni(mrow[3].w) != 0u) {
+                            // a translation + uniform scale (Instance::simple; the reference's own scenes, BASELINE configs 4 / 5): x' = x / s + w maps the
+                            // beam onto itself -- same octant, the origin moved, every |1 / direction| times s -- so nothing is reduced over the wave
+                            // again: one FMA per origin component, one product per direction component (rayIntoInstance's results for such a matrix, bit
+                            // for bit, minus its zero-component nudges, as in the per-ray kernels' folded route), two products for the role's multipliers
+                            // (1 ulp each against the 2^-18 of slack they carry)
+                            co = mk(fmaf(r0.x, co.x, r0.w), fmaf(r1.y, co.y, r1.w), fmaf(r2.z, co.z, r2.w));
 #pragma unroll
-                        for (int r = 0; r < R; r++)
-                            rayIntoInstance(r0, r1, r2, co, cd[r], &to, &td[r]); // (the origin is the same R times: folded by the compiler)
-                        V3 tLo, tHi;
-                        bool tnx, tny, tnz;
-                        if (!bundleOctant<R>(td, tLo, tHi, tnx, tny, tnz)) {
-                            whole = false; // the bundle no longer points into one octant: start over, sub-packet by sub-packet
-                            break;
+                            for (int r = 0; r < R; r++)
+                                cd[r] = mk(r0.x * cd[r].x, r1.y * cd[r].y, r2.z * cd[r].z);
+                            const float scl = rcpFast(r0.x);
+                            negSO = -(S * (axis == 0u ? co.x : (axis == 1u ? co.y : co.z)));
+                            mulPos *= scl, mulNeg *= scl;
+                        } else {
+                            V3 to = co, td[R];
+#pragma unroll
+                            for (int r = 0; r < R; r++)
+                                rayIntoInstance(r0, r1, r2, co, cd[r], &to, &td[r]); // (the origin is the same R times: folded by the compiler)
+                            V3 tLo, tHi;
+                            bool tnx, tny, tnz;
+                            if (!bundleOctant<R>(td, tLo, tHi, tnx, tny, tnz)) {
+                                whole = false; // the bundle no longer points into one octant: start over, sub-packet by sub-packet
+                                break;
+                            }
+                            co = to;
+#pragma unroll
+                            for (int r = 0; r < R; r++)
+                                cd[r] = td[r];
+                            bundleBeam(co, tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
                         }
-                        co = to;
-#pragma unroll
-                        for (int r = 0; r < R; r++)
-                            cd[r] = td[r];
-                        bundleBeam(co, tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
                         curInst = (int)refIndex(cur);
                         stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
                         sp++;

@@ -1941,10 +1941,17 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
             hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
         }
     };
-    // leaves larger than `maxLeaf` triangles become a small subtree over their triangle range (kMaxLeafTris: what a reference can address).
-    // PTAMD_MAX_LEAF=n (diagnostics, round 5): split the caller's leaves down to n triangles -- the reference's builders stop at <= 3
-    // (src/bvh/bvh_build.cpp:15), and a leaf step of this kernel runs to the longest leaf among its lanes.
-    uint32_t maxLeaf = kMaxLeafTris;
+    // Leaves larger than `maxLeaf` triangles become a small subtree over their triangle range.  Round 5: maxLeaf = 2, not the 30 a reference can
+    // address -- the reference's builders stop at <= 3 triangles (src/bvh/bvh_build.cpp:15: 60 % of the benchmark meshes' leaves hold two, 39 % three),
+    // and a leaf step of the traversal kernels runs to the LONGEST leaf among its lanes: with the three-triangle leaves cut into 1 + 2 at the cheaper
+    // of the two places (the pieces go into free slots of the 4-wide nodes where there are any: 27 k -> 37 k nodes for 82 k triangles) every leaf step
+    // is two trips at most.  Measured on the benchmark (one box, A / B / A): 10 868 -> 11 012 -> 10 832 Mrays/s (+1.5 %; leaves of ONE triangle: -0.7 %;
+    // merging subtrees into leaves of up to 4 / 6 / 8 instead: -1.0 / -3.3 / -3.4 %, profiles/round5/r5_tree_shape.txt).  Parity mode keeps the caller's
+    // leaves (its order of triangle tests is the reference's).  PTAMD_MAX_LEAF=n overrides (diagnostics).
+#ifndef PT_MAX_LEAF
+#define PT_MAX_LEAF 2
+#endif
+    uint32_t maxLeaf = parityMode(c) ? kMaxLeafTris : std::min<uint32_t>(PT_MAX_LEAF, kMaxLeafTris);
     if (const char* e = getenv("PTAMD_MAX_LEAF"))
         maxLeaf = std::max(1u, std::min((uint32_t)atoi(e), kMaxLeafTris));
     struct Range {
@@ -2404,6 +2411,13 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             in.r2 = make_float4(m[2], m[6], m[10], m[14]);
             in.rootRef = root.ref;
             in.topNode = i;
+            {   // a translation + uniform scale?  (parity mode follows the reference's route to the letter)
+                const float a = in.r0.x;
+                in.simple = (!parityMode(c) && !(c->cfg.flags & PT_FLAG_PARKED_INSTANCES) && a > 0.f && std::isfinite(a) && in.r1.y == a && in.r2.z == a && in.r0.y == 0.f
+                                && in.r0.z == 0.f && in.r1.x == 0.f && in.r1.z == 0.f && in.r2.x == 0.f && in.r2.y == 0.f && std::isfinite(in.r0.w) && std::isfinite(in.r1.w)
+                                && std::isfinite(in.r2.w))
+                    ? 1u : 0u;
+            }
             if (hInst.size() >= kSpecialLeaveInstance)
                 return fail(c, PT_ERR_UNSUPPORTED, "too many instances");
             topRef[i] = makeRef((uint32_t)hInst.size(), kRefSpecial);
@@ -2591,11 +2605,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         static const bool envNoFold = getenv("PTAMD_NO_FOLDED_INSTANCES") != nullptr; // diagnostics: every entered instance takes the parked route (rounds 2-4)
         const bool noFold = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u || parityMode(c) // (parity mode follows the reference to the letter)
             || hInst.size() + 1 > kInstFoldTable;
-        auto simple = [](const Instance& in) {
-            const float a = in.r0.x;
-            return a > 0.f && std::isfinite(a) && in.r1.y == a && in.r2.z == a && in.r0.y == 0.f && in.r0.z == 0.f && in.r1.x == 0.f && in.r1.z == 0.f && in.r2.x == 0.f
-                && in.r2.y == 0.f && std::isfinite(in.r0.w) && std::isfinite(in.r1.w) && std::isfinite(in.r2.w);
-        };
+        auto simple = [](const Instance& in) { return in.simple != 0u; };
         std::vector<uint8_t> folded(hInst.size(), 0);
         for (size_t k = 0; k < hInst.size() && !noFold; k++)
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial && simple(hInst[k]))
