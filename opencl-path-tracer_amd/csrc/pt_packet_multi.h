@@ -105,7 +105,10 @@ __device__ inline void bundleBeam(const V3 co, V3 mLo, V3 mHi, bool nx, bool ny,
 // is kept in LDS too (written when a hit is accepted -- a few times per ray -- instead of R more registers).  A transform that turns the
 // bundle into more than one octant ends the beam walk: the bundle starts over, sub-packet by sub-packet.
 template <int R, bool TWO_LEVEL>
-__global__ void __launch_bounds__(kPacketBlock, PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
+#ifndef PT_MULTI_MIN_WAVES_TL
+#define PT_MULTI_MIN_WAVES_TL PT_MULTI_MIN_WAVES // the instantiation that enters instances (round 5: 16 spilled registers at 5 waves per SIMD -- 44 more vector loads per bundle, all scratch)
+#endif
+__global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
 {
     constexpr int kSaveRay = 0, kSaveBeam = 3 + 3 * R, kSaveInst = kSaveBeam + 5, kSave = kSaveInst + R;
     __shared__ uint32_t ldsSave[TWO_LEVEL ? kPacketBlock / 64 : 1][TWO_LEVEL ? kSave : 1][64];

@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
     // branch, no parked step.  The top-level leaf of such an instance refers to the instance's own copy of its mesh's root node (object space;
     // the copies form the last run of the node array, copy k = instance k): reaching it sets the lane's instance.  (ptamd.hip, convertDynamic.)
     __shared__ float4 ldsInstFold[TWO_LEVEL ? kInstFoldTable : 1];
+    __shared__ float ldsInstScale[TWO_LEVEL ? kInstFoldTable : 1]; // s of the same entries (1 / x is a quarter-rate instruction; an LDS read is none of the vector ALU's)
     // unoccluded shadow rays of each wave so far (any-hit): kept in LDS, not in a register -- the kernel sits at the 72
     // VGPRs / ~96 SGPRs that 7 waves per SIMD allow -- and added to the device counter once, when the wave retires
     __shared__ uint32_t ldsDeposits[kTraceBlock / 64];
@@ -199,8 +200,11 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
     if (ANY_HIT && lane == 0)
         ldsDeposits[wave] = 0u;
     if constexpr (TWO_LEVEL) {
-        if (threadIdx.x < kInstFoldTable)
-            ldsInstFold[threadIdx.x] = threadIdx.x < a.instFoldCount ? a.instFold[threadIdx.x] : make_float4(1.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < kInstFoldTable) {
+            const float4 e = threadIdx.x < a.instFoldCount ? a.instFold[threadIdx.x] : make_float4(1.f, 0.f, 0.f, 0.f);
+            ldsInstFold[threadIdx.x] = e;
+            ldsInstScale[threadIdx.x] = e.x == 1.f ? 1.f : 1.0f / e.x;
+        }
         __syncthreads();
     }
     const bool fold = TWO_LEVEL && a.instFoldCount != 0u; // wave-uniform
@@ -561,6 +565,18 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
 #endif
                 if (wantInner) {
                     // -------- inner step at either level: one 64-byte fetch, FOUR quantised child boxes ----------
+                    // TWO_LEVEL: the lane's instance and its table entry, ahead of the node fetch (the LDS read hides under it)
+                    float4 foldIs = make_float4(1.f, 0.f, 0.f, 0.f);
+                    float foldScale = 1.f;
+                    if constexpr (TWO_LEVEL) {
+                        const uint32_t ni = refIndex(cur), rk = ni - sc.instRootBase;
+                        if (rk < sc.numInstRoots) // an instance's copy of its mesh root: from here on (until the walk is back at world-space references) the lane is inside instance rk
+                            curInst = (int)rk;
+                        const bool object = ni - sc.firstWorldNode >= sc.instRootBase - sc.firstWorldNode; // (unsigned: below the first world-space node, or behind the last)
+                        const uint32_t slot = fold && object ? (uint32_t)curInst + 1u : 0u;
+                        foldIs = ldsInstFold[slot];
+                        foldScale = ldsInstScale[slot];
+                    }
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
                     const uint4 A = wp[0], B = wp[1];
                     const uint2 C = *(const uint2*)&wp[2];
@@ -576,17 +592,11 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     if (extra == 0x12345u) // never true for real nodes; keeps the loads alive
                         tClosest = 0.f;
 #endif
-                    // the ray in the node's space (TWO_LEVEL: object-space nodes are seen through the lane's instance state, see the top)
+                    // the ray in the node's space (TWO_LEVEL: object-space nodes are seen through the lane's instance, see the top)
                     V3 no = co, nid = cid;
                     if constexpr (TWO_LEVEL) {
-                        const uint32_t ni = refIndex(cur), rk = ni - sc.instRootBase;
-                        if (rk < sc.numInstRoots) // an instance's copy of its mesh root: from here on (until the walk is back at world-space references) the lane is inside instance rk
-                            curInst = (int)rk;
-                        const bool object = ni - sc.firstWorldNode >= sc.instRootBase - sc.firstWorldNode; // (unsigned: below the first world-space node, or behind the last)
-                        const float4 is = ldsInstFold[fold && object ? (uint32_t)curInst + 1u : 0u];
-                        const float scl = rcpFast(is.x);
-                        no = mk(fmaf(co.x, is.x, is.y), fmaf(co.y, is.x, is.z), fmaf(co.z, is.x, is.w));
-                        nid = mk(cid.x * scl, cid.y * scl, cid.z * scl);
+                        no = mk(fmaf(co.x, foldIs.x, foldIs.y), fmaf(co.y, foldIs.x, foldIs.z), fmaf(co.z, foldIs.x, foldIs.w));
+                        nid = mk(cid.x * foldScale, cid.y * foldScale, cid.z * foldScale);
                     }
                     // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
                     const float ax = asF((A.w & 0xFFu) << 23) * nid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * nid.y,
