@@ -106,7 +106,9 @@ __device__ inline void bundleBeam(const V3 co, V3 mLo, V3 mHi, bool nx, bool ny,
 // bundle into more than one octant ends the beam walk: the bundle starts over, sub-packet by sub-packet.
 template <int R, bool TWO_LEVEL>
 #ifndef PT_MULTI_MIN_WAVES_TL
-#define PT_MULTI_MIN_WAVES_TL PT_MULTI_MIN_WAVES // the instantiation that enters instances (round 5: 16 spilled registers at 5 waves per SIMD -- 44 more vector loads per bundle, all scratch)
+#define PT_MULTI_MIN_WAVES_TL (PT_MULTI_MIN_WAVES > 4 ? 4 : PT_MULTI_MIN_WAVES) // the instantiation that enters instances: at 5 waves per SIMD (96 VGPRs) it spilled 16 registers
+    // inside the node loop -- 44 more vector loads per bundle, all scratch (SQ_INSTS_VMEM_RD +78 % for +9 % vector instructions: profiles/round5/) -- and took
+    // 25.4 instead of 17.7 ms per batch; at 4 waves (113 VGPRs, nothing spilled) 20.5
 #endif
 __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
 {

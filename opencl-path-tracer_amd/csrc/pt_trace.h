@@ -67,7 +67,9 @@ constexpr int kLdsStack = PT_LDS_STACK; // stack entries kept in LDS per lane
 #endif
 constexpr int kLdsStackTL = PT_LDS_STACK_TL;
 constexpr int kTraversalStackMax = (kLdsStackTL < kLdsStack ? kLdsStackTL : kLdsStack) + 100; // what every instantiation can hold (LDS + spill, kSpillStack below)
-constexpr uint32_t kInstFoldTable = 128; // entries of the per-workgroup table of folded instance transforms (entry 0: the identity): scenes of up to 127 instances
+constexpr uint32_t kInstFoldTable = 96; // entries of the per-workgroup table of folded instance transforms (entry 0: the identity): scenes of up to 95 instances.  (20 B
+                                        // each beside 20.5 KB of stacks and staged rays: 7 workgroups per CU must stay within 160 KB -- at 128 entries the any-hit
+                                        // instantiation's 23 056 B round up past a seventh of it and the kernel runs at 6 waves per SIMD: 89.1 -> 94.6 ms per batch)
 constexpr int kDescentStack = 3; // entries of a START stack (pt_descend.h: rays that leave one pixel's footprint take the way from the root to their origin together)
 static_assert(kDescentStack <= kLdsStack, "the hand-out copies a start stack into the LDS part of the lane's stack");
 constexpr int kSpillStack = 100; // further entries in global memory
@@ -170,8 +172,16 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 #endif
 // DESCENT: rays do not start at the root but where k_descend (pt_descend.h) left them -- a reference and up to kDescentStack stacked
 // entries per queue slot, taken at the hand-out; everything else is the same kernel.
-template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false>
-__global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
+// SMALL (round 5): the instantiation for launches that hold fewer rays than the machine has lanes -- the passes of a 1-spp frame
+// (RayTracer::rayTrace).  Such a launch is a latency chain, not a throughput problem: a wave needs ~70 iterations of ~1.3 us for its 64
+// divergent rays because every iteration serves EITHER the lanes at inner nodes OR the lanes at leaves (the vote that pays on a full
+// machine: lane utilisation).  Here every iteration serves both kinds, one after the other: more instructions per iteration, but a ray
+// advances every iteration and the chain is as long as the longest ray, not as the wave's mix of step kinds.
+#ifndef PT_TRACE_MIN_WAVES_SMALL
+#define PT_TRACE_MIN_WAVES_SMALL PT_TRACE_MIN_WAVES
+#endif
+template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false, bool SMALL = false>
+__global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL : (TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES)) k_trace(TraceArgs a)
 {
     constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
@@ -556,7 +566,9 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
             constexpr int parkedBreak = TWO_LEVEL ? (ANY_HIT ? PT_PARKED_BREAK_ANY_TL : PT_PARKED_BREAK_TL) : (ANY_HIT ? kParkedBreakAny : kParkedBreak);
             if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= (TWO_LEVEL ? PT_REFILL_IDLE_TL : kRefillIdleLanes)))
                 break;
-            if (nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF) {
+            const bool innerTurn = SMALL ? nInner > 0 : nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF;
+            const bool leafTurn = SMALL ? nLeaf > 0 : !innerTurn;
+            if (innerTurn) {
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
                 PT_TIC(tInner);
@@ -694,7 +706,8 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                 PT_STAT(18, __popcll(__ballot(statInside)));
 #endif
                 PT_TOC(11, tInner);
-            } else {
+            }
+            if (leafTurn) { // (SMALL: the lanes that stood at a leaf when this iteration began -- wantLeaf -- after the lanes at inner nodes had their step)
                 PT_STAT(3, 1);
                 PT_STAT(6, nLeaf);
                 PT_TIC(tLeaf);

@@ -256,6 +256,7 @@ struct pt_ctx {
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
+    bool smallLaunches = false; // the batch in flight holds fewer rays than the machine has lanes x 2 (renderSampleFixed): launchTrace picks the SMALL instantiations
 
     double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0, msDescend = 0;
 };
@@ -1209,6 +1210,13 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stre
         }
         return;
     }
+    if (c->smallLaunches && !twoLevel) { // a latency-bound launch (the passes of a 1-spp frame): every iteration serves inner nodes AND leaves (pt_trace.h, SMALL)
+        if (anyHit)
+            hipLaunchKernelGGL((k_trace<true, false, false, true>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<false, false, false, true>), grid, block, 0, stream, a);
+        return;
+    }
     if (anyHit) {
         if (twoLevel)
             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
@@ -1531,6 +1539,10 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // b + 1 waits for both, so the accumulator sees its deposits in the same order as in the serial schedule (bit-identical images).
     // Large batches fill the machine with one kernel; two traversal kernels side by side only evict each other's nodes (measured: slower).
     const bool overlap = PT_OVERLAP_SMALL && entries <= (4u << 20) && !c->profile && !(c->packetUse & 2u);
+    {
+        static const int smallMode = getenv("PTAMD_SMALL_LAUNCHES") ? atoi(getenv("PTAMD_SMALL_LAUNCHES")) : 1; // diagnostics: 0 = never, 1 = batches of <= 2 rays per lane
+        c->smallLaunches = smallMode != 0 && entries <= 2u * c->traceBlocks[0] * kTraceBlock;
+    }
     // One sample in flight (RayTracer::rayTrace's frames): every entry deposits into the accumulator proper, so the shade launch of bounce b + 1 had to wait
     // for the shadow rays of bounce b (same words, same order as the serial schedule) -- and the shadow passes, the longer ones, were the frame's critical path.
     // There the shadow rays get an accumulator of their own (added to the other at the end of pt_render, in either schedule: the images stay bit-identical
@@ -1590,6 +1602,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         c->passCountsPending = entries;
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
+    c->smallLaunches = false;
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
     HIPCHK(c, hipGetLastError());
     return PT_OK;

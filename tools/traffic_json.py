@@ -54,7 +54,10 @@ try:
     waves = table("SQ_WAVES")
 except OSError:
     waves = {}
-STEPS = 2  # the PMC passes run --rounds 1 --warmup 1 --steps 1: two batches
+# batches a PMC pass rendered: --rounds 1 --warmup 1 --steps 1 = two (rounds 2-4); since round 5 bench.py renders one more while it settles the samples in
+# flight that fit the device (three).  Counted, not assumed: the any-hit kernel is launched four times per batch.
+_anyhit = insts.get("k_trace<true>", {}).get("SQ_INSTS_VALU", (0, 8))[1]
+STEPS = max(1, _anyhit // 4)
 # bytes per unit that FETCH_SIZE misses: the 16-B-per-lane reads of consecutive queue entries, counted at 1/2
 HALF_COUNTED = {
     "k_trace<true>": (16.0, "ray origin+length and direction+pixel, 2 x 16 B per ray at hand-out"),
