@@ -1539,10 +1539,11 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // b + 1 waits for both, so the accumulator sees its deposits in the same order as in the serial schedule (bit-identical images).
     // Large batches fill the machine with one kernel; two traversal kernels side by side only evict each other's nodes (measured: slower).
     const bool overlap = PT_OVERLAP_SMALL && entries <= (4u << 20) && !c->profile && !(c->packetUse & 2u);
-    {
-        static const int smallMode = getenv("PTAMD_SMALL_LAUNCHES") ? atoi(getenv("PTAMD_SMALL_LAUNCHES")) : 1; // diagnostics: 0 = never, 1 = batches of <= 2 rays per lane
-        c->smallLaunches = smallMode != 0 && entries <= 2u * c->traceBlocks[0] * kTraceBlock;
-    }
+    // latency-bound batches (<= 2.1 rays per lane of the persistent grid: the 1-spp frames of RayTracer::rayTrace up to 1280 x 720) trace with the SMALL
+    // instantiations from pass `smallFromPass` on.  PTAMD_SMALL_LAUNCHES=tenths of rays per lane (0: never), PTAMD_SMALL_FROM_PASS=n: diagnostics.
+    static const int smallTenths = getenv("PTAMD_SMALL_LAUNCHES") ? atoi(getenv("PTAMD_SMALL_LAUNCHES")) : 21;
+    static const uint32_t smallFromPass = getenv("PTAMD_SMALL_FROM_PASS") ? (uint32_t)atoi(getenv("PTAMD_SMALL_FROM_PASS")) : 0u;
+    const bool smallBatch = smallTenths > 0 && (uint64_t)entries * 10u <= (uint64_t)smallTenths * c->traceBlocks[0] * kTraceBlock;
     // One sample in flight (RayTracer::rayTrace's frames): every entry deposits into the accumulator proper, so the shade launch of bounce b + 1 had to wait
     // for the shadow rays of bounce b (same words, same order as the serial schedule) -- and the shadow passes, the longer ones, were the frame's critical path.
     // There the shadow rays get an accumulator of their own (added to the other at the end of pt_render, in either schedule: the images stay bit-identical
@@ -1560,6 +1561,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     const bool descent = c->startState.p && fp.interleave >= 16u && !overlap && !split;
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
+        c->smallLaunches = smallBatch && b >= smallFromPass;
         const bool descentExt = descent && b == 1 && (c->descentUse & 2u), descentShadow = descent && b == 0 && (c->descentUse & 1u);
         if (descentExt) {
             prof.begin(6);
@@ -2757,7 +2759,8 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     if (d.used)
         HIPCHK(c, hipStreamWaitEvent(c->copyStream, d.lastUse, 0));
     const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->st->numTris + 1;
-    const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size(), needTris = staticTris + h.bakedTris;
+    // (+ 1: the SMALL traversal instantiations fetch 96 bytes from wherever a lane stands -- 32 beyond a node, 48 beyond a one-triangle leaf)
+    const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size() + 1, needTris = staticTris + h.bakedTris + 1;
     const size_t bytes[7] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
         h.jobs.size() * sizeof(BakeJob), h.instRoots.size() * sizeof(WideNode), h.instFold.size() * sizeof(float4), h.instRootSrc.size() * sizeof(uint32_t) };
     const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4] + bytes[5] + bytes[6];
