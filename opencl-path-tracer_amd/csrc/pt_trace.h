@@ -172,16 +172,8 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 #endif
 // DESCENT: rays do not start at the root but where k_descend (pt_descend.h) left them -- a reference and up to kDescentStack stacked
 // entries per queue slot, taken at the hand-out; everything else is the same kernel.
-// SMALL (round 5): the instantiation for launches that hold fewer rays than the machine has lanes -- the passes of a 1-spp frame
-// (RayTracer::rayTrace).  Such a launch is a latency chain, not a throughput problem: a wave needs ~70 iterations of ~1.3 us for its 64
-// divergent rays because every iteration serves EITHER the lanes at inner nodes OR the lanes at leaves (the vote that pays on a full
-// machine: lane utilisation).  Here every iteration serves both kinds, one after the other: more instructions per iteration, but a ray
-// advances every iteration and the chain is as long as the longest ray, not as the wave's mix of step kinds.
-#ifndef PT_TRACE_MIN_WAVES_SMALL
-#define PT_TRACE_MIN_WAVES_SMALL 4 // (the unified 96-byte fetch below wants ~95 registers; a launch that does not fill the machine does not need 7 waves per SIMD)
-#endif
-template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false, bool SMALL = false>
-__global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL : (TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES)) k_trace(TraceArgs a)
+template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false>
+__global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
@@ -566,17 +558,7 @@ __global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL 
             constexpr int parkedBreak = TWO_LEVEL ? (ANY_HIT ? PT_PARKED_BREAK_ANY_TL : PT_PARKED_BREAK_TL) : (ANY_HIT ? kParkedBreakAny : kParkedBreak);
             if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= (TWO_LEVEL ? PT_REFILL_IDLE_TL : kRefillIdleLanes)))
                 break;
-            const bool innerTurn = SMALL ? nInner > 0 : nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF;
-            const bool leafTurn = SMALL ? nLeaf > 0 : !innerTurn;
-            // SMALL: ONE memory round trip per iteration -- every lane fetches 96 bytes from where it stands, a node (64 B + the 32 behind it) or the
-            // (up to) two triangles of its leaf (2 x 48 B: leaves hold two at most since round 5), before either kind of step runs
-            uint4 smallLine[6] = {};
-            if constexpr (SMALL) {
-                const uint4* at = wantLeaf ? (const uint4*)&sc.tris[refIndex(cur)] : (const uint4*)&sc.wide[wantInner ? refIndex(cur) : 0u];
-#pragma unroll
-                for (int q = 0; q < 6; q++)
-                    smallLine[q] = at[q];
-            }
+            const bool innerTurn = nInner * PT_VOTE_INNER >= nLeaf * PT_VOTE_LEAF;
             if (innerTurn) {
                 PT_STAT(2, 1);
                 PT_STAT(5, nInner);
@@ -599,9 +581,9 @@ __global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL 
                         foldScale = ldsInstScale[slot];
                     }
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
-                    const uint4 A = SMALL ? smallLine[0] : wp[0], B = SMALL ? smallLine[1] : wp[1];
-                    const uint2 C = SMALL ? make_uint2(smallLine[2].x, smallLine[2].y) : *(const uint2*)&wp[2];
-                    const uint4 D = SMALL ? smallLine[3] : wp[3];
+                    const uint4 A = wp[0], B = wp[1];
+                    const uint2 C = *(const uint2*)&wp[2];
+                    const uint4 D = wp[3];
 #ifdef PT_EXTRA_LOADS // diagnostic: how sensitive is the kernel to vector-memory instruction count?
                     uint32_t extra = 0;
                     for (int q = 0; q < PT_EXTRA_LOADS; q++) {
@@ -715,8 +697,7 @@ __global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL 
                 PT_STAT(18, __popcll(__ballot(statInside)));
 #endif
                 PT_TOC(11, tInner);
-            }
-            if (leafTurn) { // (SMALL: the lanes that stood at a leaf when this iteration began -- wantLeaf -- after the lanes at inner nodes had their step)
+            } else {
                 PT_STAT(3, 1);
                 PT_STAT(6, nLeaf);
                 PT_TIC(tLeaf);
@@ -740,16 +721,8 @@ __global__ void __launch_bounds__(kTraceBlock, SMALL ? PT_TRACE_MIN_WAVES_SMALL 
 #endif
                     for (uint32_t k = 0; k < n; k++) {
                         const TriIsect* tp = &sc.tris[first + k];
-                        float4 ta, tb;
-                        float tcx;
-                        if (SMALL && k < 2u) { // fetched at the head of the iteration
-                            const uint4 la = k == 0u ? smallLine[0] : smallLine[3], lb = k == 0u ? smallLine[1] : smallLine[4];
-                            ta = make_float4(asF(la.x), asF(la.y), asF(la.z), asF(la.w)), tb = make_float4(asF(lb.x), asF(lb.y), asF(lb.z), asF(lb.w));
-                            tcx = asF(k == 0u ? smallLine[2].x : smallLine[5].x);
-                        } else {
-                            ta = tp->a, tb = tp->b;
-                            tcx = tp->c.x;
-                        }
+                        const float4 ta = tp->a, tb = tp->b;
+                        const float tcx = tp->c.x;
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
                         const V3 P = cross(ld_, e2);
                         const float det = dot(e1, P);

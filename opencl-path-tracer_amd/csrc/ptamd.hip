@@ -256,7 +256,6 @@ struct pt_ctx {
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
-    bool smallLaunches = false; // the batch in flight holds fewer rays than the machine has lanes x 2 (renderSampleFixed): launchTrace picks the SMALL instantiations
 
     double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0, msDescend = 0;
 };
@@ -1210,13 +1209,6 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stre
         }
         return;
     }
-    if (c->smallLaunches && !twoLevel) { // a latency-bound launch (the passes of a 1-spp frame): every iteration serves inner nodes AND leaves (pt_trace.h, SMALL)
-        if (anyHit)
-            hipLaunchKernelGGL((k_trace<true, false, false, true>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((k_trace<false, false, false, true>), grid, block, 0, stream, a);
-        return;
-    }
     if (anyHit) {
         if (twoLevel)
             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
@@ -1539,11 +1531,6 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // b + 1 waits for both, so the accumulator sees its deposits in the same order as in the serial schedule (bit-identical images).
     // Large batches fill the machine with one kernel; two traversal kernels side by side only evict each other's nodes (measured: slower).
     const bool overlap = PT_OVERLAP_SMALL && entries <= (4u << 20) && !c->profile && !(c->packetUse & 2u);
-    // latency-bound batches (<= 2.1 rays per lane of the persistent grid: the 1-spp frames of RayTracer::rayTrace up to 1280 x 720) trace with the SMALL
-    // instantiations from pass `smallFromPass` on.  PTAMD_SMALL_LAUNCHES=tenths of rays per lane (0: never), PTAMD_SMALL_FROM_PASS=n: diagnostics.
-    static const int smallTenths = getenv("PTAMD_SMALL_LAUNCHES") ? atoi(getenv("PTAMD_SMALL_LAUNCHES")) : 21;
-    static const uint32_t smallFromPass = getenv("PTAMD_SMALL_FROM_PASS") ? (uint32_t)atoi(getenv("PTAMD_SMALL_FROM_PASS")) : 0u;
-    const bool smallBatch = smallTenths > 0 && (uint64_t)entries * 10u <= (uint64_t)smallTenths * c->traceBlocks[0] * kTraceBlock;
     // One sample in flight (RayTracer::rayTrace's frames): every entry deposits into the accumulator proper, so the shade launch of bounce b + 1 had to wait
     // for the shadow rays of bounce b (same words, same order as the serial schedule) -- and the shadow passes, the longer ones, were the frame's critical path.
     // There the shadow rays get an accumulator of their own (added to the other at the end of pt_render, in either schedule: the images stay bit-identical
@@ -1561,7 +1548,6 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     const bool descent = c->startState.p && fp.interleave >= 16u && !overlap && !split;
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
-        c->smallLaunches = smallBatch && b >= smallFromPass;
         const bool descentExt = descent && b == 1 && (c->descentUse & 2u), descentShadow = descent && b == 0 && (c->descentUse & 1u);
         if (descentExt) {
             prof.begin(6);
@@ -1604,7 +1590,6 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         c->passCountsPending = entries;
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
-    c->smallLaunches = false;
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
     HIPCHK(c, hipGetLastError());
     return PT_OK;
