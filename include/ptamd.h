@@ -157,6 +157,7 @@ typedef struct {
                                          rounds 2-4).  Default since round 5: instances whose transform is a translation + uniform scale are walked by the per-ray
                                          kernels without parking (entry nodes, the ray taken into the instance's space on the fly; csrc/pt_trace.h); rotated /
                                          non-uniformly scaled ones keep the general route either way */
+#define PT_FLAG_TEAM_INTERSECT 8192u /* pt_intersect (test hook) uses the team kernel (four lanes per ray, csrc/pt_team.h) where the scene allows it */
 #define PT_FLAG_INTEGRATOR_MIS 32u
 /* exactly the reference's COMPARE_SHADING build (kernel.cl:48-51,248-265; raytracer.cpp:464-495): neeMisShading for the pixels of
  * the left half of the image, neeIsShading for the right half, both halves showing the left half's view -- two estimators of one
@@ -187,7 +188,8 @@ typedef struct {
     uint64_t descent_launches; /* launches of the shared-descent kernel (rays that leave one pixel's footprint walk from the root to their origin together) */
     double ms_descend; /* its device ms in the last pt_render (already counted in ms_shadow / ms_intersect) */
     uint32_t stack_need; /* worst-case traversal stack entries of the active scene state (packet kernels need <= 64) */
-    uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk through an entry node (translation + uniform scale, not copied to world space) */
+    uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk without parking (translation + uniform scale, not copied to world space) */
+    uint64_t team_launches; /* traversal launches served by the team kernel (four lanes per ray: launches that do not fill the machine, csrc/pt_team.h) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

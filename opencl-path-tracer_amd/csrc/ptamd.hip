@@ -8,6 +8,7 @@
 #include "pt_packet_multi.h"
 #include "pt_bake.h"
 #include "pt_descend.h"
+#include "pt_team.h"
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
 #endif
@@ -254,6 +255,10 @@ struct pt_ctx {
     uint32_t descendBlocks = 0;
     uint64_t descentLaunches = 0;
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
+    uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
+    uint32_t teamRounds = 2; // ... used where the previous batch's pass held at most this many rays per team
+    uint32_t batchEntries = 0; // entries of the batch being enqueued (renderSampleFixed)
+    uint64_t teamLaunches = 0;
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
 
@@ -1171,6 +1176,14 @@ int ensureSpill(pt_ctx* c)
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&d1, (const void*)k_descend<true>, kDescendBlock, 0));
         c->descendBlocks = (uint32_t)(std::max(1, std::min(d0, d1)) * c->numCUs);
     }
+    {
+        int t0 = 0, t1 = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&t0, (const void*)k_trace_team<false>, kTeamBlock, 0));
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&t1, (const void*)k_trace_team<true>, kTeamBlock, 0));
+        c->teamBlocks = (uint32_t)(std::max(1, std::min(t0, t1)) * c->numCUs);
+        if (const char* e = getenv("PTAMD_TEAM_ROUNDS")) // diagnostics: 0 = never use the team kernel
+            c->teamRounds = (uint32_t)std::max(0, atoi(e));
+    }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
     c->spillHalf = threads * kSpillStack;
@@ -1183,8 +1196,31 @@ inline int sceneKind(const pt_ctx* c)
     return (c->dyn[c->active].hasInstances || forceTwoLevel) ? 1 : 0;
 }
 
+// Is this launch small enough for four lanes per ray (pt_team.h)?  Known only as a hint -- the live count is a device word --: what the same pass of
+// the previous batch of the same size held (its counters come back through pinned memory, renderSampleFixed); shadow rays of pass b are at most the
+// extension rays of pass b.  Scenes that are one world-space tree whose depth-first stack need fits the team's stack; never in parity mode.
+bool teamLaunch(const pt_ctx* c, uint32_t pass)
+{
+    if (!c->teamRounds || !c->teamBlocks || parityMode(c) || c->dyn[c->active].hasInstances || c->dyn[c->active].stackNeed > kTeamStackNeedMax)
+        return false;
+    if (c->cfg.flags & PT_FLAG_TEAM_INTERSECT)
+        return true; // the pt_intersect hook (tests)
+    if (!c->batchEntries || c->passCountsEntries != c->batchEntries || pass > (uint32_t)kMaxPasses)
+        return false;
+    const uint64_t teams = (uint64_t)c->teamBlocks * (kTeamBlock / 4);
+    return (uint64_t)c->passCountsHint[pass] <= teams * c->teamRounds;
+}
+
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stream = nullptr)
 {
+    if (teamLaunch(c, args.pass) && !args.start) {
+        c->teamLaunches++;
+        if (anyHit)
+            hipLaunchKernelGGL(k_trace_team<true>, dim3(c->teamBlocks), dim3(kTeamBlock), 0, stream ? stream : c->stream, args);
+        else
+            hipLaunchKernelGGL(k_trace_team<false>, dim3(c->teamBlocks), dim3(kTeamBlock), 0, stream ? stream : c->stream, args);
+        return;
+    }
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
     TraceArgs a = args;
@@ -1508,6 +1544,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     }
     const uint32_t bounces = maxBounces(c);
     const uint32_t entries = c->numOwned * batch;
+    c->batchEntries = entries;
     // Where the packet kernel serves the primary rays it generates them itself, from the entry index, and queues them for
     // k_shade: no k_gen launch (3.3 ms of a 121 ms batch, HBM-write-bound) and no read of 32 B per ray in a kernel that has
     // bandwidth to spare for the two stores instead.  (k_shade regenerating the rays as well, so that they are never stored,
@@ -1590,6 +1627,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         c->passCountsPending = entries;
     }
     hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
+    c->batchEntries = 0;
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
     HIPCHK(c, hipGetLastError());
     return PT_OK;
@@ -3175,6 +3213,7 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->ms_descend = c->msDescend;
     out->stack_need = c->dyn[c->active].stackNeed;
     out->folded_instances = c->dyn[c->active].foldedInstances;
+    out->team_launches = c->teamLaunches;
     return PT_OK;
 }
 
@@ -3184,7 +3223,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
-    c->packetLaunches = c->genLaunches = c->bundleLaunches = c->descentLaunches = 0;
+    c->packetLaunches = c->genLaunches = c->bundleLaunches = c->descentLaunches = c->teamLaunches = 0;
     return PT_OK;
 }
 

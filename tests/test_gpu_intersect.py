@@ -12,7 +12,7 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "descent", "unbaked_descent", "two_level_parked", "unbaked_parked"]
+MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "descent", "unbaked_descent", "two_level_parked", "unbaked_parked", "team"]
 
 
 def _flags(gpu, mode):
@@ -26,7 +26,9 @@ def _flags(gpu, mode):
             "descent": gpu.FLAG_DESCENT_INTERSECT, "unbaked_descent": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_DESCENT_INTERSECT,
             # *parked: the general route into an instance for every instance (rounds 2-4); without it (round 5) the per-ray kernels walk instances that are a
             # translation + uniform scale through entry nodes, the ray taken into the instance's space on the fly
-            "two_level_parked": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PARKED_INSTANCES, "unbaked_parked": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PARKED_INSTANCES}[mode]
+            "two_level_parked": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PARKED_INSTANCES, "unbaked_parked": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PARKED_INSTANCES,
+            # team: four lanes per ray on the world-space tree (pt_team.h: the kernel of launches that do not fill the machine)
+            "team": gpu.FLAG_TEAM_INTERSECT}[mode]
 
 
 def _entered(mode):
@@ -35,6 +37,7 @@ def _entered(mode):
 
 def _check_kernel_used(ctx, mode, folded=None):
     assert (ctx.stats()["packet_launches"] > 0) == mode.endswith("packet"), "wrong traversal kernel ran"
+    assert (ctx.stats()["team_launches"] > 0) == (mode == "team"), "the team kernel did not run where it should (or ran where it should not)"
     if folded is not None:  # how many instances of the scene the per-ray kernels walk through entry nodes
         assert ctx.stats()["folded_instances"] == folded, (ctx.stats()["folded_instances"], folded)
     assert (ctx.stats()["descent_launches"] > 0) == mode.endswith("descent"), "the shared descent did not run where it should (or ran where it should not)"

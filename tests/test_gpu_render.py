@@ -226,6 +226,35 @@ def test_interactive_frames_packets_and_overlapped_passes_are_bit_identical(gpu,
     plain.close()
 
 
+def test_late_passes_of_a_frame_through_the_team_kernel(gpu, monkeypatch):
+    """1-spp frames (RayTracer::rayTrace): once the pass counters of a frame have come back, the passes that hold fewer rays than the machine has
+    teams are traced by k_trace_team (four lanes per ray, pt_team.h).  Against a context that never uses it (PTAMD_TEAM_ROUNDS=0): the same rays, the
+    same shading events, the same image except where a closest-hit ray finds two triangles at exactly the same distance (the team visits a ray's
+    subtrees in another order) -- and the oracle gate of the production renders."""
+    W, Hh = 640, 360
+    b = scenes.blob_room(W, Hh, level=4, material=L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7))
+    monkeypatch.setenv("PTAMD_TEAM_ROUNDS", "0")
+    plain = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1)
+    monkeypatch.setenv("PTAMD_TEAM_ROUNDS", "64")  # every pass whose counters are known (a frame this small has fewer rays than 64 per team)
+    team = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1)
+    for frame in range(12):
+        plain.render(1)
+        team.render(1)
+    sp, st = plain.stats(), team.stats()
+    assert sp["team_launches"] == 0 and st["team_launches"] >= 16, (sp["team_launches"], st["team_launches"])
+    a, p = team.read_accum()[:, :3], plain.read_accum()[:, :3]
+    same = (a == p).all(axis=1)
+    assert same.mean() > 0.995, f"{(~same).sum()} of {len(same)} pixels differ"
+    for k in ("rays_generated",):
+        assert sp[k] == st[k]
+    for k in ("rays_extension", "rays_shadow", "shade_hits", "deposits"):
+        assert abs(int(sp[k]) - int(st[k])) <= 1e-4 * sp[k], k  # (a tie resolved the other way may end on another material)
+    ref, _ = O.render(U.oracle_scene(b), b.camera, W, Hh, 12, seed=9, threads=8)
+    U.image_margins("1-spp frames, late passes through the team kernel, 12 frames", a, ref[:, :3], 12, b.camera, 1e-3, 1e-3)
+    plain.close()
+    team.close()
+
+
 @pytest.mark.parametrize("pattern", ["patches", "confetti"])
 def test_material_ordered_shading_traces_the_same_paths(gpu, pattern):
     """PT_FLAG_MATERIAL_BINS: k_shade walks the tiles of a scene with several material types in material order (pt_shade.h, BINNED).
