@@ -235,9 +235,11 @@ def test_late_passes_of_a_frame_through_the_team_kernel(gpu, monkeypatch):
     b = scenes.blob_room(W, Hh, level=4, material=L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7))
     monkeypatch.setenv("PTAMD_TEAM_ROUNDS", "0")
     plain = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1)
+    plain.render(1)  # (the variable is read when a context sets up its launch grids: at its first render)
     monkeypatch.setenv("PTAMD_TEAM_ROUNDS", "64")  # every pass whose counters are known (a frame this small has fewer rays than 64 per team)
     team = U.make_ctx(gpu, b, W, Hh, seed=9, samples_in_flight=1)
-    for frame in range(12):
+    team.render(1)
+    for frame in range(11):
         plain.render(1)
         team.render(1)
     sp, st = plain.stats(), team.stats()
