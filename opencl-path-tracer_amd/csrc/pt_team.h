@@ -9,7 +9,7 @@
 // leaves in one iteration and push what they found behind each other (counts exchanged inside the quad by DPP): the chain shrinks from "nodes a ray
 // visits" towards "depth of the tree".  The price is order: the ray's subtrees are no longer visited strictly nearest first, so a closest-hit ray
 // tests a few more triangles (each member culls with the team's best distance so far) and exact-t ties may resolve differently than in k_trace; any-hit
-// rays do not care.  A wave = 16 teams; 4 waves per SIMD (LDS: 96 stack entries x 16 teams x 4 B = 6 KB per wave).
+// rays do not care.  A wave = 16 teams (LDS: 64 stack entries x 16 teams x 4 B = 4 KB per wave).
 //
 // Stack discipline: while the team's stack is short every member pops (breadth); beyond kTeamDfsAbove entries only member 0 pops (depth first:
 // from any state the stack then grows by at most the tree's worst-case depth-first need, which ptamd.hip checks against kTeamStack before it
@@ -20,8 +20,12 @@
 namespace ptd {
 
 constexpr int kTeamBlock = 256;
-constexpr int kTeamStack = 96; // entries per team
-constexpr int kTeamDfsAbove = 40; // more entries than this: depth first (one pop per iteration)
+#ifndef PT_TEAM_STACK
+#define PT_TEAM_STACK 64
+#define PT_TEAM_DFS_ABOVE 16
+#endif
+constexpr int kTeamStack = PT_TEAM_STACK; // entries per team (4 KB of LDS per wave)
+constexpr int kTeamDfsAbove = PT_TEAM_DFS_ABOVE; // more entries than this: depth first (one pop per iteration); four members need no more than four entries to be busy
 constexpr uint32_t kTeamStackNeedMax = (uint32_t)(kTeamStack - kTeamDfsAbove - 12); // breadth adds <= 12 per iteration (4 popped, <= 16 pushed)
 #ifndef PT_TEAM_MIN_WAVES
 #define PT_TEAM_MIN_WAVES 4

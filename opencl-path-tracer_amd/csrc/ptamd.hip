@@ -257,6 +257,7 @@ struct pt_ctx {
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
     uint32_t teamRounds = 2; // ... used where the previous batch's pass held at most this many rays per team
+    uint32_t teamUse = 3; // bit 0: the camera rays of 1-spp frames, bit 1: later passes by the previous batch's counters (PTAMD_TEAM_USE: diagnostics)
     uint32_t batchEntries = 0; // entries of the batch being enqueued (renderSampleFixed)
     uint64_t teamLaunches = 0;
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
@@ -1183,6 +1184,8 @@ int ensureSpill(pt_ctx* c)
         c->teamBlocks = (uint32_t)(std::max(1, std::min(t0, t1)) * c->numCUs);
         if (const char* e = getenv("PTAMD_TEAM_ROUNDS")) // diagnostics: 0 = never use the team kernel
             c->teamRounds = (uint32_t)std::max(0, atoi(e));
+        if (const char* e = getenv("PTAMD_TEAM_USE"))
+            c->teamUse = (uint32_t)atoi(e);
     }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
@@ -1205,7 +1208,13 @@ bool teamLaunch(const pt_ctx* c, uint32_t pass)
         return false;
     if (c->cfg.flags & PT_FLAG_TEAM_INTERSECT)
         return true; // the pt_intersect hook (tests)
-    if (!c->batchEntries || c->passCountsEntries != c->batchEntries || pass > (uint32_t)kMaxPasses)
+    if (!c->batchEntries || pass > (uint32_t)kMaxPasses)
+        return false;
+    // the camera rays of a 1-spp frame (no bundles there: too few samples of a pixel): coherent rays, few leaves per ray -- four lanes per ray walk them
+    // faster than one however many there are (1280 x 720: 190 instead of 263 us, profiles/round5/r5l_frame_trace_team.txt)
+    if (pass == 0u && c->planes == 1u && c->batchEntries <= (4u << 20) && (c->teamUse & 1u))
+        return true;
+    if (c->passCountsEntries != c->batchEntries || !(c->teamUse & 2u))
         return false;
     const uint64_t teams = (uint64_t)c->teamBlocks * (kTeamBlock / 4);
     return (uint64_t)c->passCountsHint[pass] <= teams * c->teamRounds;
