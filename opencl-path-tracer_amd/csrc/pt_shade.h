@@ -1044,18 +1044,24 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ accu
 constexpr uint32_t kFoldLanes = 16;
 // small launches (one sample in flight): the shadow rays deposit into an accumulator of their own (ptamd.hip, renderSampleFixed), added to the accumulator
 // proper -- and cleared -- once per pt_render
-__global__ void __launch_bounds__(256) k_merge_accum(float4* __restrict__ acc, float4* __restrict__ shadowAcc, uint32_t n)
+__global__ void __launch_bounds__(256) k_merge_accum(float4* __restrict__ acc, float4* __restrict__ shadowAcc, uint32_t n, uint32_t planes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const float4 b = shadowAcc[i];
-    if (b.x != 0.f || b.y != 0.f || b.z != 0.f) { // (adding zero changes nothing: pixels no shadow ray reached are neither read nor written)
-        float4 a = acc[i];
-        a.x += b.x, a.y += b.y, a.z += b.z;
-        acc[i] = a;
-        shadowAcc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // one plane per bounce, added in the order of the bounces whatever order the passes ran in (the serial and the overlapped schedule: the same sums)
+    float4 a = acc[i];
+    bool any = false;
+    for (uint32_t p = 0; p < planes; p++) {
+        const float4 b = shadowAcc[(size_t)p * n + i];
+        if (b.x != 0.f || b.y != 0.f || b.z != 0.f) { // (adding zero changes nothing: planes no shadow ray of this pixel reached are not written)
+            a.x += b.x, a.y += b.y, a.z += b.z;
+            shadowAcc[(size_t)p * n + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            any = true;
+        }
     }
+    if (any)
+        acc[i] = a;
 }
 
 __global__ void __launch_bounds__(256) k_fold_planes(AccumView acc, uint32_t planes, const uint32_t* pixels, uint32_t numOwned)

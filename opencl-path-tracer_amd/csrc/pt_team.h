@@ -28,7 +28,7 @@ constexpr int kTeamStack = PT_TEAM_STACK; // entries per team (4 KB of LDS per w
 constexpr int kTeamDfsAbove = PT_TEAM_DFS_ABOVE; // more entries than this: depth first (one pop per iteration); four members need no more than four entries to be busy
 constexpr uint32_t kTeamStackNeedMax = (uint32_t)(kTeamStack - kTeamDfsAbove - 12); // breadth adds <= 12 per iteration (4 popped, <= 16 pushed)
 #ifndef PT_TEAM_MIN_WAVES
-#define PT_TEAM_MIN_WAVES 4
+#define PT_TEAM_MIN_WAVES 6 // 4 / 5 / 6 / 7 waves per SIMD: 720p frames 0.82-0.94 / - / 0.77-0.90 / 0.77-0.92 ms (more teams in flight: fewer rounds per launch; 7 spills)
 #endif
 
 // lane j of the caller's quad (j = 0..3)

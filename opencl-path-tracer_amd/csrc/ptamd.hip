@@ -201,6 +201,8 @@ struct pt_ctx {
     // small launches (a 1-spp interactive frame): the shadow rays of bounce b are traced on `sideStream` while the main stream traces
     // the extension rays of bounce b + 1 (independent: both only need shade b; shade b + 1 waits for both)
     hipStream_t sideStream = nullptr;
+    hipStream_t sideStream2 = nullptr; // one sample in flight: the shadow passes of a frame alternate between two side streams (each bounce has its own shadow queue AND
+                                       // accumulator plane: nothing orders them but their own shade launch)
     hipEvent_t evShaded[kMaxPasses] = {}, evShadowed[kMaxPasses] = {};
     // ... and, with ONE sample in flight, deposit into an accumulator of their own (merged into the accumulator proper at the end of pt_render) from a shadow
     // queue per bounce: the shadow passes then depend on nothing but their own shade launch and run back to back on the side stream
@@ -1074,7 +1076,7 @@ int ensureQueues(pt_ctx* c)
         // image) and a shadow queue per bounce (48 B per entry and bounce), renderSampleFixed -- set aside HERE, not in the first frame
         const bool split = splitShadowAccum(c, cap);
         const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4)
-            + (split ? (uint64_t)cap * 48 * maxBounces(c) + (uint64_t)c->cfg.width * c->cfg.height * sizeof(float4) : 0);
+            + (split ? (uint64_t)cap * 48 * maxBounces(c) + (uint64_t)c->cfg.width * c->cfg.height * sizeof(float4) * maxBounces(c) : 0);
         size_t freeB = 0, totalB = 0;
         HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
         if (need > (uint64_t)freeB)
@@ -1115,9 +1117,9 @@ int ensureQueues(pt_ctx* c)
     }
     if (splitShadowAccum(c, cap)) { // (a first-frame stall otherwise: thirteen hipMallocs inside the first pt_render)
         const size_t npx = (size_t)c->cfg.width * c->cfg.height;
-        if (!c->accumShadow.p) {
-            HIPCHK(c, c->accumShadow.alloc(npx));
-            HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, npx * sizeof(float4), c->stream));
+        if (!c->accumShadow.p || c->accumShadow.n < npx * maxBounces(c)) { // one plane per bounce: the shadow passes of a frame deposit side by side
+            HIPCHK(c, c->accumShadow.alloc(npx * maxBounces(c)));
+            HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, npx * maxBounces(c) * sizeof(float4), c->stream));
         }
         for (uint32_t b = 0; b < maxBounces(c); b++) {
             HIPCHK(c, c->shadowQ[b].o.alloc(cap));
@@ -1188,7 +1190,7 @@ int ensureSpill(pt_ctx* c)
             c->teamUse = (uint32_t)atoi(e);
     }
     const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
-    HIPCHK(c, c->spill.alloc(2 * threads * kSpillStack)); // second half: the traversal kernel that runs beside another one (side stream)
+    HIPCHK(c, c->spill.alloc(3 * threads * kSpillStack)); // second and third part: the traversal kernels that run beside another one (the two side streams)
     c->spillHalf = threads * kSpillStack;
     return PT_OK;
 }
@@ -1437,13 +1439,13 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t s
     TraceArgs a = traceArgsBase(c);
     if (descent) // the caller has launched k_descend on this queue
         a.start = c->startState.p;
-    if (side) // runs beside the closest-hit traversal of the next bounce: a spill region of its own
-        a.spill = c->spill.p + c->spillHalf;
+    if (side) // runs beside the closest-hit traversal of the next bounce (and, with two side streams, beside another shadow pass): a spill region of its own
+        a.spill = c->spill.p + c->spillHalf * (side == c->sideStream2 ? 2u : 1u);
     const ShadowQueueBuf& q = own ? *own : c->shadow;
     a.rayO = q.o.p;
     a.rayD = q.d.p;
     a.rayC = q.c.p;
-    a.accum = own ? AccumView { c->accumShadow.p, nullptr, nullptr, 0u } : accumView(c);
+    a.accum = own ? AccumView { c->accumShadow.p + (size_t)pass * c->cfg.width * c->cfg.height, nullptr, nullptr, 0u } : accumView(c); // (own: this bounce's plane)
     a.ctl = ctl;
     a.pass = pass;
     if (coherent && c->dyn[c->active].packetOk && (c->packetUse & 2u))
@@ -1618,18 +1620,24 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         }
         prof.begin(3);
         if (overlap) {
+            // (with a plane and a queue per bounce the shadow passes depend on nothing but their own shade launch: two side streams take them in turn, so
+            // that the pass of bounce b does not queue behind the longer one of bounce b - 1 -- the side stream had become a frame's critical path)
+            hipStream_t side = split && (b & 1u) ? c->sideStream2 : c->sideStream;
             HIPCHK(c, hipEventRecord(c->evShaded[b], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->sideStream, c->evShaded[b], 0));
-            launchShadow(c, b, coherent, c->sideStream, split ? &c->shadowQ[b] : nullptr);
-            HIPCHK(c, hipEventRecord(c->evShadowed[b], c->sideStream));
+            HIPCHK(c, hipStreamWaitEvent(side, c->evShaded[b], 0));
+            launchShadow(c, b, coherent, side, split ? &c->shadowQ[b] : nullptr);
+            HIPCHK(c, hipEventRecord(c->evShadowed[b], side));
         } else {
             launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr, descentShadow);
         }
         prof.end();
         std::swap(in, out);
     }
-    if (overlap)
+    if (overlap) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 1], 0));
+        if (split && bounces > 1)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 2], 0)); // the other side stream's last pass
+    }
     if (c->passCountsPinned && !c->passCountsPending) { // (a copy still in flight keeps its slot: the host reads it only once its event has fired)
         HIPCHK(c, hipMemcpyAsync(c->passCountsPinned, &c->control.p->extCount[0], sizeof(c->passCountsHint), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->passCountsCopied, c->stream));
@@ -1649,7 +1657,7 @@ void foldPlanesNow(pt_ctx* c)
 {
     if (c->mergePending) { // the shadow rays' own accumulator (one sample in flight) into the accumulator proper
         const uint32_t n = c->cfg.width * c->cfg.height;
-        hipLaunchKernelGGL(k_merge_accum, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, c->accum, c->accumShadow.p, n);
+        hipLaunchKernelGGL(k_merge_accum, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, c->accum, c->accumShadow.p, n, maxBounces(c));
         c->mergePending = false;
     }
     if (c->foldPlanes > 1) {
@@ -1813,7 +1821,7 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         return bail(e, "hipStreamCreate (copy stream)");
     if ((e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess)
         return bail(e, "hipEventCreate");
-    if ((e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->sideStream2, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate (side stream)");
     for (int k = 0; k < kMaxPasses; k++)
         if ((e = hipEventCreateWithFlags(&c->evShaded[k], hipEventDisableTiming)) != hipSuccess
@@ -1859,6 +1867,8 @@ void pt_destroy(pt_ctx* c)
         (void)hipStreamSynchronize(c->copyStream);
     if (c->sideStream)
         (void)hipStreamSynchronize(c->sideStream);
+    if (c->sideStream2)
+        (void)hipStreamSynchronize(c->sideStream2);
     c->accumShadow.release();
     c->startState.release();
     for (ShadowQueueBuf& q : c->shadowQ)
@@ -1891,6 +1901,7 @@ void pt_destroy(pt_ctx* c)
     for (hipEvent_t ev : c->profEvents)
         (void)hipEventDestroy(ev);
     if (c->sideStream) (void)hipStreamDestroy(c->sideStream);
+    if (c->sideStream2) (void)hipStreamDestroy(c->sideStream2);
     for (int k = 0; k < kMaxPasses; k++) {
         if (c->evShaded[k]) (void)hipEventDestroy(c->evShaded[k]);
         if (c->evShadowed[k]) (void)hipEventDestroy(c->evShadowed[k]);
