@@ -332,6 +332,42 @@ def test_thousand_instances_of_a_small_mesh(gpu, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("n", [60, 200])
+def test_translated_and_scaled_instances_around_the_fold_table(gpu, n):
+    """The per-ray kernels walk translated + uniformly scaled instances without parking while the scene's instances fit the LDS table of their transforms
+    (95 entries, pt_trace.h); a scene with more falls back to the parked route for all of them.  Both sides of that limit, every instance entered
+    (PT_FLAG_NO_BAKED_INSTANCES): hits equal the oracle's, occlusion verdicts too, with mixed scales and a rotated instance in between (the general
+    route and the folded one in one traversal)."""
+    mat = L.material_pbr_dielectric((0.7, 0.3, 0.2), 0.6)
+    mesh = scenes.blob_mesh(mat, level=2, seed=3, builder=H.BVH_BINNED_SAH)
+    scene = H.Scene()
+    mb = scenes._MeshBuilder()
+    ext = 0.5 * n ** 0.5 + 2
+    mb.add_quad((-ext, 0, -ext), (-ext, 0, ext), (ext, 0, ext), (ext, 0, -ext), 0)
+    scene.add_node(mb.build([L.material_diffuse((0.6, 0.6, 0.6))], H.BVH_BINNED_SAH))
+    rng = np.random.default_rng(n)
+    side = 0.45 * n ** 0.5
+    for k in range(n - 1):
+        s = float(rng.uniform(0.4, 1.3))
+        q = (1, 0, 0, 0) if k != 7 else (float(np.cos(0.4)), 0.0, float(np.sin(0.4)), 0.0)  # one rotated instance: the general route
+        scene.add_node(mesh, location=(float(rng.uniform(-side, side)), float(rng.uniform(0.4, 2.0)), float(rng.uniform(-side, side))), orientation_wxyz=q, scale=(s, s, s))
+    flat = scene.flatten()
+    assert flat.num_instances == n
+    ctx = gpu.Context(64, 36, flags=gpu.FLAG_NO_BAKED_INSTANCES)
+    ctx.upload_scene(flat)
+    assert ctx.stats()["folded_instances"] == (n - 1 if n + 1 <= 96 else 0)
+    sc = O.BoundScene(flat)
+    o, d = U.random_rays(40000, n, (-side, 0.05, -side), (side, 3, side))
+    got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
+    info = U.compare_hits(flat, got, want, uv_atol=2e-2, t_atol=1e-5)
+    assert info["n"] > 8000 and info["flips"] == 0
+    tmax = np.random.default_rng(1).uniform(0.05, 6, len(o)).astype(np.float32)
+    occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
+    ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
+    assert (occ != ref).sum() <= 3
+    ctx.close()
+
+
 def test_invalid_scenes_are_rejected_not_traversed(gpu):
     b = scenes.cornell_box(16, 16)
     f = b.flat
