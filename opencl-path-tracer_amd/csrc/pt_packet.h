@@ -463,7 +463,6 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                     const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                     const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
-                    const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
                     const float tLimit = here ? tClosest : -INFINITY; // a lane that is not in this node sees no child
                     unsigned long long m[4];
                     uint32_t key[4]; // entry distance of the first lane that sees the child (float bits, >= 0: ordered as integers), slot in the low bits
@@ -472,8 +471,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                         const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
                         const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
                         const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
-                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
-                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const f2 tx = planePair(qx, ax, bx), ty = planePair(qy, ay, by), tz = planePair(qz, az, bz);
                         const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                         const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
                         // tmax >= tmin && tmax >= 0 && tmin < closest (bvh.cl:72,114), the first two folded into one compare

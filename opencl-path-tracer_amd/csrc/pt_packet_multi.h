@@ -423,7 +423,6 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                             const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                             const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                             const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
-                            const f2 kx2 = { kx, kx }, ky2 = { ky, ky }, kz2 = { kz, kz }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
                             const float tLimit = here ? tC : -INFINITY; // a lane that is not in this node sees no child
                             unsigned long long m[4];
                             uint32_t key[4];
@@ -432,7 +431,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                                 const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
                                 const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
                                 const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
-                                const f2 tx = __builtin_elementwise_fma(qx, kx2, bx2), ty = __builtin_elementwise_fma(qy, ky2, by2), tz = __builtin_elementwise_fma(qz, kz2, bz2);
+                                const f2 tx = planePair(qx, kx, bx), ty = planePair(qy, ky, by), tz = planePair(qz, kz, bz);
                                 const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                                 const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
                                 const float tlo = fmaxf(tmin, 0.f);

@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
             const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
             const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
             const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
-            const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
             float key[4];
             ref[0] = D.x, ref[1] = D.y, ref[2] = D.z, ref[3] = D.w;
 #pragma unroll
@@ -128,7 +127,7 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
                 const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
                 const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
                 const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
-                const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2), tz = __builtin_elementwise_fma(qz, az2, bz2);
+                const f2 tx = planePair(qx, ax, bx), ty = planePair(qy, ay, by), tz = planePair(qz, az, bz);
                 const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                 const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
                 const bool vis = tmax >= tmin && tmax >= 0.f && tmin < tCull; // the accept test of bvh.cl:72,114 on the (slightly larger) quantised box

@@ -34,6 +34,7 @@
 //    40.4: the near-first descent finds occluders sooner than fuller steps save.
 #pragma once
 #include "pt_shade.h"
+#include <type_traits>
 
 namespace ptd {
 
@@ -57,6 +58,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_VOTE_INNER
 #define PT_VOTE_INNER 2 // an inner step runs when 2 * (lanes wanting one) >= 3 * (lanes wanting a leaf): leaf steps are the
 #define PT_VOTE_LEAF 3 // long ones (sequential triangle fetches), so they are not left waiting for a majority
+#endif
+#ifndef PT_PACKED_FMA
+#define PT_PACKED_FMA 0 // 1: the plane distances as 12 v_pk_fma_f32 instead of 24 v_fma_f32 (rounds 2-4; see fmaPlain: 11 040 -> 11 270 Mrays/s without them)
 #endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
@@ -138,6 +142,25 @@ __device__ unsigned long long g_traceStats[64]; // [0..23] closest-hit launches,
 #endif
 
 __device__ inline float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); } // v_rcp_f32, 1 ulp
+// v_fma_f32 that stays a plain v_fma_f32 (the vectoriser would pack two of them into one v_pk_fma_f32: a half-rate instruction that competes with the
+// conversions, compares and selects around it, while a plain FP32 multiply-add next to one of those issues at about half its price -- measured,
+// profiles/round5/r5r_valu_issue_pairs.md: v_cmp / v_cndmask / v_min3 / v_cvt_f32_ubyte + v_fma_f32 pairs take 2.55 units against 2.0 for the half-rate one alone)
+__device__ inline float fmaPlain(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the distances to a child's entry and exit planes of one axis: q * a + b for both
+__device__ inline f2 planePair(const f2 q, const float a, const float b)
+{
+#if PT_PACKED_FMA
+    const f2 a2 = { a, a }, b2 = { b, b };
+    return __builtin_elementwise_fma(q, a2, b2);
+#else
+    return { fmaPlain(q.x, a, b), fmaPlain(q.y, a, b) };
+#endif
+}
 // Reciprocal direction for the slab test, clamped to +-1e18: a zero (or FLT_MIN, scene.cl:123-137)
 // component then yields plane distances of +-1e18 * (b - o) -- far beyond any scene, with the correct
 // sign -- instead of the inf - inf = NaN the one-FMA form would produce from an infinite reciprocal.
@@ -614,7 +637,6 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
                     const uint32_t qnz = nz ? C.y : C.x, qfz = nz ? C.x : C.y;
-                    const f2 ax2 = { ax, ax }, ay2 = { ay, ay }, az2 = { az, az }, bx2 = { bx, bx }, by2 = { by, by }, bz2 = { bz, bz };
                     float key[4];
                     uint32_t ref[4] = { D.x, D.y, D.z, D.w };
 #ifdef PT_TRACE_STATS
@@ -625,8 +647,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         const f2 qx = { (float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu) };
                         const f2 qy = { (float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu) };
                         const f2 qz = { (float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu) };
-                        const f2 tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
-                                 tz = __builtin_elementwise_fma(qz, az2, bz2);
+                        const f2 tx = planePair(qx, ax, bx), ty = planePair(qy, ay, by), tz = planePair(qz, az, bz);
                         const float tmin = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                         const float tmax = fminf(fminf(tx.y, ty.y), tz.y);
                         // accept test of bvh.cl:72,114 on the (slightly larger) quantised box

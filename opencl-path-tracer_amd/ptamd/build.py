@@ -57,7 +57,11 @@ def build_sanitized(force=False):
 # Division and square root as v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded expansions (~10
 # instructions each): a quarter of k_shade's instructions were those expansions.  The reference builds its kernels
 # with -cl-fast-relaxed-math (raytracer.cpp:819); every parity test passes either way.
-DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# -fno-slp-vectorize (device code only): the vectoriser packs pairs of FP32 multiplies and multiply-adds into v_pk_* instructions, which issue at half
+# rate and compete with the conversions, compares and selects of the traversal kernels; plain FP32 arithmetic next to one of those is nearly free
+# (profiles/round5/r5r_valu_issue_pairs.md).  Benchmark scene: 11 040 -> 11 660 Mrays/s, k_shade 85 -> 75 VGPRs.
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+                "-Xarch_device", "-fno-slp-vectorize"]
 
 
 def build_device(force=False):

@@ -31,7 +31,7 @@ KERNELS = {"k_traceILb1ELb0ELb0": "k_trace<true>", "k_traceILb0ELb0ELb0": "k_tra
 
 def main():
     out = sys.argv[1]
-    from_build = ["-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+    from_build = ["-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *from_build, "-S", "--cuda-device-only", "ptamd.hip", "-o", "-"], cwd=CSRC,
                          check=True, capture_output=True, text=True).stdout
     res, hot, cur, depth = {}, {}, None, 0

@@ -53,7 +53,7 @@
 
 enum Kind {
     K_FMA, K_MUL, K_ADD, K_MIN, K_MAX3, K_MIN3, K_CVT_UB0, K_CVT_UB1, K_CVT_UB2, K_CVT_UB3, K_CVT_U32, K_CNDMASK, K_CMP, K_CMP_SGPR, K_AND, K_LSHR, K_BFE,
-    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_FMAMIX_LO, K_FMAMIX_HI, K_PKFMA16, K_PKMAX16, K_PKMIN16, K_PKADD16, K_PKMUL16, K_CVT16, K_CVT16_SDWA, K_CVTUB_SDWA, K_PKRTZ, K_PKMAXI16, K_PKMADU16, K_CVTPKFP8, K_MED3, K_PKMOV, K_DOT2, K_OR_SDWA_B1, K_OR_SDWA_B3, K_OR_SDWA_SGPR, K_AND_SDWA, K_MULU24_SDWA, K_ADDU_SDWA, K_MOV_SDWA, K_LSHL_SDWA, K_ALIGNBIT, K_ALIGNBYTE, K_OR_SDWA_FMA, K_CVTUB_FMA, K_COUNT
+    K_ADDU, K_MOV, K_PERM, K_PKFMA, K_PKMUL, K_RCP, K_LSHLOR, K_ANDOR, K_MADU24, K_CMPCND, K_CND64, K_OR, K_MAX, K_MINU, K_CMPU, K_LSHLADD, K_MAD64, K_SUB, K_CVTI, K_FMAC, K_CND_VCC_SET, K_CND64_VCC, K_CMP64_CND64, K_CMP_4CND, K_CMP64_4CND64, K_XORSWAP, K_ASHR, K_XOR, K_BFI, K_MINMAX_SWAP, K_DSW, K_DSR, K_FMAMIX_LO, K_FMAMIX_HI, K_PKFMA16, K_PKMAX16, K_PKMIN16, K_PKADD16, K_PKMUL16, K_CVT16, K_CVT16_SDWA, K_CVTUB_SDWA, K_PKRTZ, K_PKMAXI16, K_PKMADU16, K_CVTPKFP8, K_MED3, K_PKMOV, K_DOT2, K_OR_SDWA_B1, K_OR_SDWA_B3, K_OR_SDWA_SGPR, K_AND_SDWA, K_MULU24_SDWA, K_ADDU_SDWA, K_MOV_SDWA, K_LSHL_SDWA, K_ALIGNBIT, K_ALIGNBYTE, K_OR_SDWA_FMA, K_CVTUB_FMA, K_P_CVT_PKFMA, K_P_CVT_MIN3, K_P_CVT_CMP, K_P_CVT_CND, K_P_CVT_MUL, K_P_CMP_FMA, K_P_CND_FMA, K_P_MIN3_FMA, K_P_MAX_FMA, K_P_CVT_AND, K_P_CVT_CVT_FMA, K_P_RCP_FMA, K_COUNT
 };
 static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_min_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1",
     "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_cvt_f32_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair, VOP3)", "v_and_b32", "v_lshrrev_b32",
@@ -71,7 +71,11 @@ static const char* kNames[K_COUNT] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v
     "v_and_b32_sdwa src1_sel:BYTE_1", "v_mul_u32_u24_sdwa src1_sel:BYTE_1", "v_add_u32_sdwa src1_sel:BYTE_1", "v_mov_b32_sdwa src0_sel:BYTE_1", "v_lshlrev_b32_sdwa src1_sel:BYTE_1",
     "v_alignbit_b32", "v_alignbyte_b32",
     "v_or_b32_sdwa BYTE_k + v_fma_f32 on its result (per instruction of the pair: the box test's byte -> plane distance)",
-    "v_cvt_f32_ubyteK + v_fma_f32 on its result (per instruction of the pair: today's form)" };
+    "v_cvt_f32_ubyteK + v_fma_f32 on its result (per instruction of the pair: today's form)",
+    "pair: v_cvt_f32_ubyte + v_mul_f32, second run (independent)", "pair: v_cvt_f32_ubyte + v_min3_f32 (independent)", "pair: v_cvt_f32_ubyte + v_cmp_lt_f32 (independent)",
+    "pair: v_cvt_f32_ubyte + v_cndmask_b32 (independent)", "pair: v_cvt_f32_ubyte + v_mul_f32 (independent)", "pair: v_cmp_lt_f32 + v_fma_f32 (independent)",
+    "pair: v_cndmask_b32 + v_fma_f32 (independent)", "pair: v_min3_f32 + v_fma_f32 (independent)", "pair: v_max_f32 + v_fma_f32 (independent)",
+    "pair: v_cvt_f32_ubyte + v_and_b32 (independent)", "triple: 2 x v_cvt_f32_ubyte + v_fma_f32 (independent; per instruction)", "pair: v_rcp_f32 + v_fma_f32 (independent)" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int iters, float seed)
@@ -172,6 +176,21 @@ __global__ void __launch_bounds__(1024) k_issue(unsigned long long* out, int ite
 #define PAIRS8(P) P("%0", "0") P("%1", "1") P("%2", "2") P("%3", "3") P("%4", "0") P("%5", "1") P("%6", "2") P("%7", "3")
         if (KIND == K_OR_SDWA_FMA) asm volatile(PAIRS8(PAIR_OR) PAIRS8(PAIR_OR) : OPS : "v"(s), "v"(t));
         if (KIND == K_CVTUB_FMA) asm volatile(PAIRS8(PAIR_CVT) PAIRS8(PAIR_CVT) : OPS : "v"(s), "v"(t));
+        // independent pairs (round 5): which half-rate instruction overlaps with which neighbour?  registers r0..r3 take instruction A, r4..r7 instruction B, alternating
+#define IP(A0, A1, B0, B1) A0 "%0" A1 "\n\t" B0 "%4" B1 "\n\t" A0 "%1" A1 "\n\t" B0 "%5" B1 "\n\t" A0 "%2" A1 "\n\t" B0 "%6" B1 "\n\t" A0 "%3" A1 "\n\t" B0 "%7" B1 "\n\t"
+#define IP32(A0, A1, B0, B1) IP(A0, A1, B0, B1) IP(A0, A1, B0, B1) IP(A0, A1, B0, B1) IP(A0, A1, B0, B1)
+        if (KIND == K_P_CVT_PKFMA) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t)); // (placeholder row replaced below for the packed form)
+        if (KIND == K_P_CVT_MIN3) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_min3_f32 ", ", %8, %9, %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_CVT_CMP) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_cmp_lt_f32 vcc, %8, ", "") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_P_CVT_CND) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_cndmask_b32 ", ", %8, %9, vcc") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_P_CVT_MUL) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_CMP_FMA) asm volatile(IP32("v_cmp_lt_f32 vcc, %8, ", "", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_P_CND_FMA) asm volatile(IP32("v_cndmask_b32 ", ", %8, %9, vcc", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t) : "vcc");
+        if (KIND == K_P_MIN3_FMA) asm volatile(IP32("v_min3_f32 ", ", %8, %9, %8", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_MAX_FMA) asm volatile(IP32("v_max_f32 ", ", %8, %9", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_CVT_AND) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_and_b32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_CVT_CVT_FMA) asm volatile(IP32("v_cvt_f32_ubyte1 ", ", %8", "v_cvt_f32_ubyte2 ", ", %9") IP32("v_mul_f32 ", ", %8, %9", "v_cvt_f32_ubyte0 ", ", %8") : OPS : "v"(s), "v"(t));
+        if (KIND == K_P_RCP_FMA) asm volatile(IP32("v_rcp_f32 ", ", %8", "v_mul_f32 ", ", %8, %9") : OPS : "v"(s), "v"(t));
 #undef OPS
         if (KIND == K_CVTPKFP8)
             asm volatile(REP32("v_cvt_pk_f32_fp8 ", ", %8")
@@ -257,7 +276,7 @@ int main(int argc, char** argv)
     printf("| instruction | W=1 wave | W=2 wave / SIMD | W=4 wave / SIMD | W=7 wave / SIMD | W=8 wave / SIMD | wall ns per inst per SIMD at W=8 | shader clock at W=8 (MHz) | class |\n|---|---|---|---|---|---|---|---|---|\n");
     double pw[5], ns[5], mhz[5];
 #define RUN(K)                                                                                                                        \
-    if (K >= firstKind) runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND || K == K_CMP64_CND64 ? 16 : (K == K_CMP_4CND || K == K_CMP64_4CND64 || K == K_XORSWAP ? 30 : (K == K_MINMAX_SWAP ? 24 : 32)));                                                      \
+    if (K >= firstKind) runKind<K>(dOut, iters, numCUs, W, 5, pw, ns, mhz, K == K_CMPCND || K == K_CMP64_CND64 ? 16 : (K == K_CMP_4CND || K == K_CMP64_4CND64 || K == K_XORSWAP ? 30 : (K == K_MINMAX_SWAP ? 24 : (K == K_P_CVT_CVT_FMA ? 64 : 32))));                                                      \
     if (K >= firstKind) printf("| `%s` | %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.2f / %.2f | %.3f | %.0f | %s |\n", kNames[K], pw[0], pw[1], pw[1] / 2, pw[2], pw[2] / 4, pw[3], \
         pw[3] / 7, pw[4], pw[4] / 8, ns[4], mhz[4], pw[4] / 8 < 1.6 ? "full rate" : (pw[4] / 8 < 3.0 ? "half rate" : "quarter rate or slower"));
     RUN(K_FMA) RUN(K_MUL) RUN(K_ADD) RUN(K_MIN) RUN(K_MAX3) RUN(K_MIN3) RUN(K_CVT_UB0) RUN(K_CVT_UB1) RUN(K_CVT_UB2) RUN(K_CVT_UB3) RUN(K_CVT_U32)
@@ -269,6 +288,8 @@ int main(int argc, char** argv)
     RUN(K_PKRTZ) RUN(K_PKMAXI16) RUN(K_PKMADU16) RUN(K_CVTPKFP8) RUN(K_MED3) RUN(K_PKMOV) RUN(K_DOT2)
     RUN(K_OR_SDWA_B1) RUN(K_OR_SDWA_B3) RUN(K_OR_SDWA_SGPR) RUN(K_AND_SDWA) RUN(K_MULU24_SDWA) RUN(K_ADDU_SDWA) RUN(K_MOV_SDWA) RUN(K_LSHL_SDWA) RUN(K_ALIGNBIT) RUN(K_ALIGNBYTE)
     RUN(K_OR_SDWA_FMA) RUN(K_CVTUB_FMA)
+    RUN(K_P_CVT_PKFMA) RUN(K_P_CVT_MIN3) RUN(K_P_CVT_CMP) RUN(K_P_CVT_CND) RUN(K_P_CVT_MUL) RUN(K_P_CMP_FMA) RUN(K_P_CND_FMA) RUN(K_P_MIN3_FMA) RUN(K_P_MAX_FMA) RUN(K_P_CVT_AND)
+    RUN(K_P_CVT_CVT_FMA) RUN(K_P_RCP_FMA)
     CHECK(hipFree(dOut));
     return 0;
 }
