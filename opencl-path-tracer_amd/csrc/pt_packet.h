@@ -378,14 +378,8 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
                         const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
                         const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
-                        const V3 P = cross(cd, e2);
-                        const float det = dot(e1, P);
-                        const float inv = rcpFast(det);
-                        const V3 T = co - v0;
-                        const float u = dot(T, P) * inv;
-                        const V3 Q = cross(T, e1);
-                        const float v = dot(cd, Q) * inv;
-                        const float t = dot(e2, Q) * inv;
+                        float det, u, v, t;
+                        triangleTest(co, cd, v0, e1, e2, &det, &u, &v, &t);
                         const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tClosest;
                         if (hit) {
                             tClosest = t;
@@ -514,14 +508,8 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
                         const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
                         const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
-                        const V3 P = cross(cd, e2);
-                        const float det = dot(e1, P);
-                        const float inv = rcpFast(det);
-                        const V3 T = co - v0;
-                        const float u = dot(T, P) * inv;
-                        const V3 Q = cross(T, e1);
-                        const float v = dot(cd, Q) * inv;
-                        const float t = dot(e2, Q) * inv;
+                        float det, u, v, t;
+                        triangleTest(co, cd, v0, e1, e2, &det, &u, &v, &t);
                         const bool hit = here && !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f
                             && t < tClosest;
                         if (hit) {

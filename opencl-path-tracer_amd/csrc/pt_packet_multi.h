@@ -27,43 +27,7 @@
 
 namespace ptd {
 
-// Moeller-Trumbore in two halves, operation by operation.  The per-ray and packet kernels write the test as cross / dot expressions and
-// leave the choice of fused multiply-adds to the compiler; with the origin half hoisted out of the loop over a lane's rays it chooses
-// differently, and the barycentrics move in their fifth digit (cancellation in T x e1) -- harmless to a picture, but "the same hits as
-// k_trace, to the bit" is what the tests of these kernels assert.  So the sequence the compiler emits for those kernels is spelled out here:
-//   cross(a, b).x = fma(a.y, b.z, -(a.z * b.y))              dot(a, b) = fma(a.z, b.z, fma(a.x, b.x, a.y * b.y))
-//   det           = e1.z * P.z + fma(e1.x, P.x, e1.y * P.y)  (the last product rounded on its own)
-// tests/test_gpu_intersect.py (first pass of a batch) fails if the two ever drift apart.
-__device__ inline V3 crossExact(const V3 a, const V3 b)
-{
-#pragma clang fp contract(off)
-    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
-}
-__device__ inline float dotExact(const V3 a, const V3 b)
-{
-#pragma clang fp contract(off)
-    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
-}
-// the half that only knows the origin
-__device__ inline void triOriginHalf(const V3 o, const V3 v0, const V3 e1, const V3 e2, V3* T, V3* Q, float* e2Q)
-{
-#pragma clang fp contract(off)
-    *T = mk(o.x - v0.x, o.y - v0.y, o.z - v0.z);
-    *Q = crossExact(*T, e1);
-    *e2Q = dotExact(e2, *Q);
-}
-// the half per ray: det (the caller rejects |det| < FLT_MIN), u, v, t
-__device__ inline void triRayHalf(const V3 d, const V3 e1, const V3 e2, const V3 T, const V3 Q, const float e2Q, float* det, float* u, float* v, float* t)
-{
-#pragma clang fp contract(off)
-    const V3 P = crossExact(d, e2);
-    const float pz = e1.z * P.z;
-    *det = pz + __builtin_fmaf(e1.x, P.x, e1.y * P.y);
-    const float inv = rcpFast(*det);
-    *u = dotExact(T, P) * inv;
-    *v = dotExact(d, Q) * inv;
-    *t = e2Q * inv;
-}
+// (Moeller-Trumbore in two halves, operation by operation: triOriginHalf / triRayHalf, pt_trace.h)
 
 // Do the R x 64 directions point into one octant?  Per axis: the interval of |1 / direction| over the lane's rays (folded over the wave by
 // bundleBeam) and the common sign.

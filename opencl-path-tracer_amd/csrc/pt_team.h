@@ -164,14 +164,8 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
                     ta = tp->a, tb = tp->b, tcx = tp->c.x;
                 }
                 const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
-                const V3 P = cross(cd, e2);
-                const float det = dot(e1, P);
-                const float inv = rcpFast(det);
-                const V3 T = co - v0;
-                const float u = dot(T, P) * inv;
-                const V3 Q = cross(T, e1);
-                const float v = dot(cd, Q) * inv;
-                const float t = dot(e2, Q) * inv;
+                float det, u, v, t;
+                triangleTest(co, cd, v0, e1, e2, &det, &u, &v, &t);
                 const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tBest;
                 if (hit) {
                     if (ANY_HIT) {

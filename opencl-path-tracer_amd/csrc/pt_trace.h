@@ -166,6 +166,51 @@ __device__ inline f2 planePair(const f2 q, const float a, const float b)
 // sign -- instead of the inf - inf = NaN the one-FMA form would produce from an infinite reciprocal.
 __device__ inline float rcpSlab(float x) { return fminf(fmaxf(rcpFast(x), -1e18f), 1e18f); }
 
+// Moeller-Trumbore (shapes.cl:20-72), operation by operation.  Rounds 1-4 wrote the test as cross / dot expressions and left the choice of fused
+// multiply-adds to the compiler: every kernel then had to happen on the same choice ("the same hits as k_trace, to the bit" is what the tests of the
+// packet, bundle and team kernels assert), and a build option that changes the choice in one of them (round 5: -fno-slp-vectorize) moves
+// barycentrics in their fifth digit (cancellation in T x e1).  So the sequence those builds emitted is spelled out once, for every kernel:
+//   cross(a, b).x = fma(a.y, b.z, -(a.z * b.y))              dot(a, b) = fma(a.z, b.z, fma(a.x, b.x, a.y * b.y))
+//   det           = e1.z * P.z + fma(e1.x, P.x, e1.y * P.y)  (the last product rounded on its own)
+// The bundle kernel computes the origin half once per triangle and the ray half per ray; the others call triangleTest.
+__device__ inline V3 crossExact(const V3 a, const V3 b)
+{
+#pragma clang fp contract(off)
+    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ inline float dotExact(const V3 a, const V3 b)
+{
+#pragma clang fp contract(off)
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
+}
+// the half that only knows the origin
+__device__ inline void triOriginHalf(const V3 o, const V3 v0, const V3 e1, const V3 e2, V3* T, V3* Q, float* e2Q)
+{
+#pragma clang fp contract(off)
+    *T = mk(o.x - v0.x, o.y - v0.y, o.z - v0.z);
+    *Q = crossExact(*T, e1);
+    *e2Q = dotExact(e2, *Q);
+}
+// the half per ray: det (the caller rejects |det| < FLT_MIN), u, v, t
+__device__ inline void triRayHalf(const V3 d, const V3 e1, const V3 e2, const V3 T, const V3 Q, const float e2Q, float* det, float* u, float* v, float* t)
+{
+#pragma clang fp contract(off)
+    const V3 P = crossExact(d, e2);
+    const float pz = e1.z * P.z;
+    *det = pz + __builtin_fmaf(e1.x, P.x, e1.y * P.y);
+    const float inv = rcpFast(*det);
+    *u = dotExact(T, P) * inv;
+    *v = dotExact(d, Q) * inv;
+    *t = e2Q * inv;
+}
+__device__ inline void triangleTest(const V3 o, const V3 d, const V3 v0, const V3 e1, const V3 e2, float* det, float* u, float* v, float* t)
+{
+    V3 T, Q;
+    float e2Q;
+    triOriginHalf(o, v0, e1, e2, &T, &Q, &e2Q);
+    triRayHalf(d, e1, e2, T, Q, e2Q, det, u, v, t);
+}
+
 // A ray taken into an instance's space (scene.cl:116-139): rows r0..r2 of the inverse transform; the direction is NOT
 // renormalised, so t is shared between the two spaces; exactly-zero components are nudged (NO_PARALLEL_RAYS, scene.cl:123-137).
 // One spelling (explicit FMAs) for every kernel that enters instances, so that they produce the same bits.
@@ -745,14 +790,8 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);
-                        const V3 P = cross(ld_, e2);
-                        const float det = dot(e1, P);
-                        const float inv = rcpFast(det);
-                        const V3 T = lo_ - v0;
-                        const float u = dot(T, P) * inv;
-                        const V3 Q = cross(T, e1);
-                        const float v = dot(ld_, Q) * inv;
-                        const float t = dot(e2, Q) * inv;
+                        float det, u, v, t;
+                        triangleTest(lo_, ld_, v0, e1, e2, &det, &u, &v, &t);
                         const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f
                             && t < tClosest;
                         if (hit) {
