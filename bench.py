@@ -235,7 +235,7 @@ def aggregate(dist, torch, counts, elapsed, backend, world, device="cuda"):
     return [float(x) for x in c.tolist()], float(t.item())
 
 
-def frame_times(D, H, scenes, L, device, frames, width=1280, height=720):
+def frame_times(D, H, scenes, L, device, frames, width=1280, height=720, only=""):
     """What the reference publishes (BASELINE.md 1a): wall ms per interactive frame = RayTracer::rayTrace, one sample per
     pixel through the whole queue loop + the accumulate kernel into a device image (the reference writes a GL texture),
     stream synchronised every frame as its queue.finish() does (src/raytracer.cpp:88-151, src/main.cpp:106-119)."""
@@ -245,6 +245,8 @@ def frame_times(D, H, scenes, L, device, frames, width=1280, height=720):
             "diffuse 0.8": L.material_diffuse((0.8, 0.8, 0.8))}
     out = {}
     for name, mat in mats.items():
+        if only and only not in name:
+            continue
         b = scenes.blob_room(width, height, material=mat, builder=H.BVH_SPATIAL_SPLIT, level=6)
         ctx = D.Context(width, height, seed=1, device=device, samples_in_flight=1)
         ctx.upload_scene(b.flat, sky=b.sky, material_textures=b.material_textures)
@@ -619,6 +621,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1-spp 720p frame-time figure")
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--frame-scene", default="", help="--mode frame: only the scenes whose name contains this (profiling one scene's frames)")
     ap.add_argument("--no-frame-after", dest="frame_after", action="store_false", help="skip the second frame-time figure (after the headline's allocations)")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "frame"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
@@ -666,7 +669,7 @@ def main():
     if args.mode == "frame":
         if world != 1:
             raise SystemExit("--mode frame is a single-GPU measurement")
-        fr = frame_times(D, H, scenes, L, local_rank, args.frames)
+        fr = frame_times(D, H, scenes, L, local_rank, args.frames, only=args.frame_scene)
         best = min(v["ms_per_frame"] for v in fr["scenes"].values())
         print(json.dumps({"metric": "ms per 1-spp 1280x720 frame (RayTracer::rayTrace + accumulate)", "value": best, "unit": "ms", "n_gpus": 1,
                           "steps": args.frames, "warmup": 20, "ms_per_step": best, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,

@@ -28,7 +28,6 @@ __host__ __device__ inline void quantiseWideNode(const float (*lo)[3], const flo
                 nhi[a] = fmaxf(nhi[a], hi[k][a]);
             }
     WideNode w {};
-    uint32_t ex[3];
     float scale[3];
     for (int a = 0; a < 3; a++) {
         if (!(nlo[a] <= nhi[a]))
@@ -41,10 +40,9 @@ __host__ __device__ inline void quantiseWideNode(const float (*lo)[3], const flo
         scale[a] = ldexpf(1.0f, e);
         while (extent > 0.f && nlo[a] + scale[a] * 255.0f < nhi[a] && e < 127) // guard float round-off
             scale[a] = ldexpf(1.0f, ++e);
-        ex[a] = (uint32_t)(e + 127);
     }
     w.ox = nlo[0], w.oy = nlo[1], w.oz = nlo[2];
-    w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+    w.scaleX = scale[0], w.scaleY = scale[1], w.scaleZ = scale[2];
     uint32_t q[6] = { 0, 0, 0, 0, 0, 0 }; // qlox, qhix, qloy, qhiy, qloz, qhiz
     for (int k = 0; k < 4; k++) {
         w.child[k] = empty[k] ? emptyRef : refs[k];

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kDescendBlock, PT_DESCENT_MIN_WAVES) k_descend
                 pref = __builtin_nontemporal_load((const uint32_t*)sc.wide + (size_t)refIndex(childRef) * 16u + dwordOfLane);
 #endif
             // the box test of k_trace's inner step, operation by operation (pt_trace.h): the same planes, the same visible set
-            const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y, az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+            const float ax = asF(A.w) * cid.x, ay = asF(C.z) * cid.y, az = asF(C.w) * cid.z;
             const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
             const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
             const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kDescendBlock, PT_DESCENT_MIN_WAVES) k_descend
 #define RL(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
                 A = u4v { RL(pref, l0 + 0u), RL(pref, l0 + 1u), RL(pref, l0 + 2u), RL(pref, l0 + 3u) };
                 B = u4v { RL(pref, l0 + 4u), RL(pref, l0 + 5u), RL(pref, l0 + 6u), RL(pref, l0 + 7u) };
-                C = u4v { RL(pref, l0 + 8u), RL(pref, l0 + 9u), 0u, 0u };
+                C = u4v { RL(pref, l0 + 8u), RL(pref, l0 + 9u), RL(pref, l0 + 10u), RL(pref, l0 + 11u) };
                 D = u4v { RL(pref, l0 + 12u), RL(pref, l0 + 13u), RL(pref, l0 + 14u), RL(pref, l0 + 15u) };
 #undef RL
 #else

@@ -32,9 +32,11 @@ struct PairNode {
 // now needs four 16-byte loads for four children instead of eight for the same two levels.
 struct WideNode {
     float ox, oy, oz; // quantisation origin = min corner of the union of the children
-    uint32_t exps; // biased float exponents of the per-axis scale: ex | ey << 8 | ez << 16
+    float scaleX; // per-axis scale of the plane bytes: a power of two, as a float (rounds 1-4 packed three exponent bytes into this word: every
+                  // traversal step then spent six shift / mask instructions on unpacking them -- the node had eight spare bytes)
     uint32_t qlox, qhix, qloy, qhiy; // byte k of each word belongs to child k
-    uint32_t qloz, qhiz, _pad0, _pad1;
+    uint32_t qloz, qhiz;
+    float scaleY, scaleZ;
     uint32_t child[4]; // references; an unused slot has an inverted box and refers to an all-zero triangle
 };
 

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
         if (!ANY_HIT && viaBeam) {
             // lane roles (lanes 32-63 repeat 0-31 and are never read): group of 8 lanes per child, (axis, near | far) inside it
             const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
-            const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
+            const uint32_t ofsO = 4u * axis, ofsE = axis == 0u ? 12u : 36u + 4u * axis, shift = 8u * child; // (the lane's origin component / scale: WideNode, pt_device.h)
             float S, negSO, mulPos, mulNeg;
             uint32_t ofsQ;
             // The beam of the rays as they are now (signs uniform): per axis the interval of a REFERENCE POINT of every ray and of |1 / direction|.
@@ -334,10 +334,10 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
                     const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
                     const char* nb = (const char*)&sc.wide[ni];
                     const float originA = *(const float*)(nb + ofsO);
-                    const uint32_t ebits = *(const uint8_t*)(nb + ofsE);
+                    const float scaleA = *(const float*)(nb + ofsE);
                     const uint32_t qd = *(const uint32_t*)(nb + ofsQ);
                     const float q = (float)((qd >> shift) & 0xFFu);
-                    const float g = fmaf(q, S * asF(ebits << 23), fmaf(S, originA, negSO));
+                    const float g = fmaf(q, S * scaleA, fmaf(S, originA, negSO));
                     float v = g * (g >= 0.f ? mulPos : mulNeg);
                     v = maxRowShr2(v);
                     v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
@@ -447,12 +447,11 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_PACKET_MIN_WAVES_
 #endif
                     // -------- inner node: four quantised child boxes (scene.cl:197-231 / bvh.cl:76-115) ----------
                     const uint32_t ni = refIndex(cur);
-                    const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u]; // scalar: origin + exponents, child references
+                    const u4v A = wideS[ni * 4u + 0u], Cs = wideS[ni * 4u + 2u], D = wideS[ni * 4u + 3u]; // scalar: origin + scales, child references
                     const uint4* wp = (const uint4*)&sc.wide[ni]; // the plane bytes are selected per lane: vector registers
                     const uint4 B = wp[1];
                     const uint2 C = *(const uint2*)&wp[2];
-                    const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y,
-                                az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                    const float ax = asF(A.w) * cid.x, ay = asF(Cs.z) * cid.y, az = asF(Cs.w) * cid.z;
                     const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
                     const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                     const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;

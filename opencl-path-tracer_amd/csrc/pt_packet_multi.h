@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
         if (whole) {
             // ---- beam walk (pt_packet.h) for the bundle of R x 64 rays ---------------------------------------------------------------
             const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
-            const uint32_t ofsO = 4u * axis, ofsE = 12u + axis, shift = 8u * child;
+            const uint32_t ofsO = 4u * axis, ofsE = axis == 0u ? 12u : 36u + 4u * axis, shift = 8u * child; // (the lane's origin component / scale: WideNode, pt_device.h)
             float S, negSO, mulPos, mulNeg;
             uint32_t ofsQ;
             bundleBeam(co, mLo, mHi, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
@@ -243,10 +243,10 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                     const u4v D = wideS[ni * 4u + 3u]; // child references: scalar
                     const char* nb = (const char*)&sc.wide[ni];
                     const float originA = *(const float*)(nb + ofsO);
-                    const uint32_t ebits = *(const uint8_t*)(nb + ofsE);
+                    const float scaleA = *(const float*)(nb + ofsE);
                     const uint32_t qd = *(const uint32_t*)(nb + ofsQ);
                     const float q = (float)((qd >> shift) & 0xFFu);
-                    const float g = fmaf(q, S * asF(ebits << 23), fmaf(S, originA, negSO));
+                    const float g = fmaf(q, S * scaleA, fmaf(S, originA, negSO));
                     float v = g * (g >= 0.f ? mulPos : mulNeg);
                     v = maxRowShr2(v);
                     v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
@@ -378,11 +378,11 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                             curInst = -1;
                         } else if (refCount(cur) == 0u) {
                             const uint32_t ni = refIndex(cur);
-                            const u4v A = wideS[ni * 4u + 0u], D = wideS[ni * 4u + 3u];
+                            const u4v A = wideS[ni * 4u + 0u], Cs = wideS[ni * 4u + 2u], D = wideS[ni * 4u + 3u];
                             const uint4* wp = (const uint4*)&sc.wide[ni];
                             const uint4 B = wp[1];
                             const uint2 C = *(const uint2*)&wp[2];
-                            const float kx = asF((A.w & 0xFFu) << 23) * cid.x, ky = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y, kz = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+                            const float kx = asF(A.w) * cid.x, ky = asF(Cs.z) * cid.y, kz = asF(Cs.w) * cid.z;
                             const float bx = (asF(A.x) - o.x) * cid.x, by = (asF(A.y) - o.y) * cid.y, bz = (asF(A.z) - o.z) * cid.z;
                             const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;
                             const uint32_t qny = ny ? B.w : B.z, qfy = ny ? B.z : B.w;

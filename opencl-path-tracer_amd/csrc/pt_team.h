@@ -97,7 +97,12 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
         // leaf (2 x 48 B: leaves hold two at most since round 5; ptamd.hip keeps one record of slack behind both arrays)
         uint4 line[6];
         {
+#if PT_OFFSET32 // base + 32-bit byte offset (pt_trace.h)
+            const uint4* at = isLeaf ? (const uint4*)((const char*)sc.tris + (size_t)(uint32_t)(refIndex(cur) * (uint32_t)sizeof(TriIsect)))
+                                     : (const uint4*)((const char*)sc.wide + (size_t)(uint32_t)((isInner ? refIndex(cur) : 0u) << 6));
+#else
             const uint4* at = isLeaf ? (const uint4*)&sc.tris[refIndex(cur)] : (const uint4*)&sc.wide[isInner ? refIndex(cur) : 0u];
+#endif
 #pragma unroll
             for (int q = 0; q < 6; q++)
                 line[q] = at[q];
@@ -113,8 +118,8 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
         if (isInner) {
             // -------- k_trace's inner step (pt_trace.h): four quantised child boxes, entry / exit planes by the sign of the direction ----------
             const uint4 A = line[0], B = line[1], D = line[3];
-            const uint2 C = make_uint2(line[2].x, line[2].y);
-            const float ax = asF((A.w & 0xFFu) << 23) * cid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * cid.y, az = asF(((A.w >> 16) & 0xFFu) << 23) * cid.z;
+            const uint4 C = line[2];
+            const float ax = asF(A.w) * cid.x, ay = asF(C.z) * cid.y, az = asF(C.w) * cid.z;
             const float bx = (asF(A.x) - co.x) * cid.x, by = (asF(A.y) - co.y) * cid.y, bz = (asF(A.z) - co.z) * cid.z;
             const bool nx = cid.x < 0.f, ny = cid.y < 0.f, nz = cid.z < 0.f;
             const uint32_t qnx = nx ? B.y : B.x, qfx = nx ? B.x : B.y;

@@ -62,6 +62,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_PACKED_FMA
 #define PT_PACKED_FMA 0 // 1: the plane distances as 12 v_pk_fma_f32 instead of 24 v_fma_f32 (rounds 2-4; see fmaPlain: 11 040 -> 11 270 Mrays/s without them)
 #endif
+#ifndef PT_OFFSET32
+#define PT_OFFSET32 1
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 12 // 16 and 10 measure the same on the benchmark scene; deeper entries spill to global memory
 #endif
@@ -648,9 +651,14 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         foldIs = ldsInstFold[slot];
                         foldScale = ldsInstScale[slot];
                     }
+#if PT_OFFSET32
+                    // base (scalar registers) + 32-bit byte offset: one shift instead of two 64-bit vector operations per step (nodes < 4 GB: checked at upload)
+                    const uint4* wp = (const uint4*)((const char*)sc.wide + (size_t)(uint32_t)(refIndex(cur) << 6));
+#else
                     const uint4* wp = (const uint4*)&sc.wide[refIndex(cur)];
+#endif
                     const uint4 A = wp[0], B = wp[1];
-                    const uint2 C = *(const uint2*)&wp[2];
+                    const uint4 C = wp[2];
                     const uint4 D = wp[3];
 #ifdef PT_EXTRA_LOADS // diagnostic: how sensitive is the kernel to vector-memory instruction count?
                     uint32_t extra = 0;
@@ -669,9 +677,8 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         no = mk(fmaf(co.x, foldIs.x, foldIs.y), fmaf(co.y, foldIs.x, foldIs.z), fmaf(co.z, foldIs.x, foldIs.w));
                         nid = mk(cid.x * foldScale, cid.y * foldScale, cid.z * foldScale);
                     }
-                    // box plane = origin + 2^exp * q  =>  t = q * (2^exp / d) + (origin - o) / d : one FMA per plane
-                    const float ax = asF((A.w & 0xFFu) << 23) * nid.x, ay = asF(((A.w >> 8) & 0xFFu) << 23) * nid.y,
-                                az = asF(((A.w >> 16) & 0xFFu) << 23) * nid.z;
+                    // box plane = origin + scale * q  =>  t = q * (scale / d) + (origin - o) / d : one FMA per plane
+                    const float ax = asF(A.w) * nid.x, ay = asF(C.z) * nid.y, az = asF(C.w) * nid.z;
                     // (origin - o) / d from the live registers: keeping -o/d around as well would cost three VGPRs, and 72 is
                     // what 7 waves per SIMD allow
                     const float bx = (asF(A.x) - no.x) * nid.x, by = (asF(A.y) - no.y) * nid.y, bz = (asF(A.z) - no.z) * nid.z;
@@ -786,7 +793,11 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     uint32_t statTri = 0xFFFFFFFFu;
 #endif
                     for (uint32_t k = 0; k < n; k++) {
+#if PT_OFFSET32
+                        const TriIsect* tp = (const TriIsect*)((const char*)sc.tris + (size_t)(uint32_t)((first + k) * (uint32_t)sizeof(TriIsect)));
+#else
                         const TriIsect* tp = &sc.tris[first + k];
+#endif
                         const float4 ta = tp->a, tb = tp->b;
                         const float tcx = tp->c.x;
                         const V3 v0 = mk(ta.x, ta.y, ta.z), e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tcx);

@@ -18,6 +18,7 @@
 #include <rccl/rccl.h> // only for the two enumerators pt_reduce_accum passes (the library itself is bound at run time, below)
 #define PT_HAVE_RCCL_HEADER 1
 #endif
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -837,12 +838,45 @@ void buildFat(pt_ctx* c)
     }
 }
 
+// PTAMD_UPLOAD_TIMING=1: host time of the stages of an upload, one line per call on stderr (diagnostics; tools/r5_upload_timing.sh)
+struct StageTimer {
+    const char* what;
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    std::string line;
+    explicit StageTimer(const char* w)
+        : what(w)
+        , on(getenv("PTAMD_UPLOAD_TIMING") != nullptr)
+    {
+        if (on)
+            t0 = last = std::chrono::steady_clock::now();
+    }
+    void lap(const char* name)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.3f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~StageTimer()
+    {
+        if (on)
+            fprintf(stderr, "[ptamd] %s: total %.3f ms;%s\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), line.c_str());
+    }
+};
+
 int buildStaticGeom(pt_ctx* c)
 {
     StaticScene::StaticGeom& g = c->st->sg;
+    StageTimer tm("buildStaticGeom");
     refreshHostGeometry(c);
+    tm.lap("refreshHostGeometry");
     const uint32_t nN = c->st->numRefNodes, nT = c->st->numTris;
     const std::vector<WideKids> kids = collapseKids(c->st->hostBottomNodes, collapseCostsFromEnv());
+    tm.lap("collapseKids");
     const uint32_t emptyRef = makeRef(nT, 1u); // the all-zero triangle stored right after the caller's triangles (det == 0: never hit)
     std::vector<uint8_t> isChild(nN, 0);
     for (uint32_t i = 0; i < nN; i++) {
@@ -861,6 +895,7 @@ int buildStaticGeom(pt_ctx* c)
         if (c->st->denseOfNode[i] != 0xFFFFFFFFu)
             pairLeft[c->st->denseOfNode[i]] = c->st->hostSubNodes[i].leftChildOrFirstTriangle;
     g.rootOfNode.assign(nN, -1);
+    tm.lap("roots");
     constexpr uint32_t kUnset = 0xFFFFFFFFu;
     std::vector<uint32_t> newIndex(kids.size(), kUnset), order;
     auto isInner = [&](uint32_t r) { return r != kRefNone && refCount(r) == 0u && refIndex(r) < kids.size(); };
@@ -934,6 +969,7 @@ int buildStaticGeom(pt_ctx* c)
     // children sit after their parent; a child that lies in ANOTHER run (a top-level leaf named an interior node, whose subtree an
     // earlier root had packed already) lies in an earlier one.  So: run by run in ascending order, each run in reverse -- every child
     // is final when its parent is reached.  (One reverse sweep over everything took 0 for the shared children: too small a bound.)
+    tm.lap("pack");
     g.stackNeed.assign(g.wide.size(), 0u);
     for (const StaticScene::StaticGeom::Root& root : g.roots)
         for (size_t q = (size_t)root.nodeBase + root.numNodes; q-- > root.nodeBase;) {
@@ -966,7 +1002,9 @@ int buildStaticGeom(pt_ctx* c)
                 fprintf(stderr, " %u:%llu", n, (unsigned long long)hist[n]);
         fprintf(stderr, "\n");
     }
+    tm.lap("stackNeed");
     buildFat(c);
+    tm.lap("buildFat");
     g.emptyRef = emptyRef;
     g.version = ++c->staticVersions;
     g.topology = g.version;
@@ -980,8 +1018,10 @@ int uploadStaticGeom(pt_ctx* c)
     StaticScene::StaticGeom& g = c->st->sg;
     if (g.onDevice)
         return PT_OK;
+    StageTimer tm("uploadStaticGeom");
     // the copy stream may still be reading the old master (a set being refreshed from it)
     HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    tm.lap("syncCopyStream");
     if (c->st->hostGeomStale) { // refitted before the master copy ever reached the device
         refreshHostGeometry(c);
         buildFat(c);
@@ -994,6 +1034,7 @@ int uploadStaticGeom(pt_ctx* c)
         || (rc = uploadVec(c, g.dVerts, c->st->rawVerts)) || (rc = uploadVec(c, c->st->triShade, c->st->hostTriShade))
         || (rc = uploadVec(c, g.dNodes, c->st->hostSubNodes)) || (rc = uploadVec(c, g.dKidBoxNode, g.kidBoxNode)))
         return rc;
+    tm.lap("uploads");
     g.onDevice = true;
     return PT_OK;
 }
@@ -1945,6 +1986,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     if (nT > kRefIndexMask || nN > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "pt_upload_static: more than 2^27 triangle references or nodes");
     HIPCHK(c, hipSetDevice(c->device));
+    StageTimer tm("uploadStatic");
     // ---- validate: every index in range, children after their parent (rules out cycles) -----
     for (uint32_t t = 0; t < nT; t++) {
         if (tris[t].indices[0] >= nV || tris[t].indices[1] >= nV || tris[t].indices[2] >= nV)
@@ -1964,6 +2006,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
             return fail(c, PT_ERR_INVALID, "sub-BVH leaf %u: triangle range out of bounds", i);
     }
 
+    tm.lap("validate");
     // ---- triangles / vertices / materials ------------------------------------------------------
     std::vector<TriIsect> hTris(nT);
     std::vector<TriShade> hShade(nT);
@@ -1985,6 +2028,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     static_assert(sizeof(Material) == sizeof(pt_material), "material record is copied verbatim");
     std::memcpy(hMats.data(), mats, (size_t)nM * sizeof(pt_material));
 
+    tm.lap("records");
     // ---- pair nodes ----------------------------------------------------------------------------
     std::vector<uint32_t> dense(nN, 0xFFFFFFFFu);
     uint32_t numInner = 0;
@@ -2103,6 +2147,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     if (hNodes.size() > kRefIndexMask)
         return fail(c, PT_ERR_UNSUPPORTED, "too many BVH nodes");
 
+    tm.lap("pairNodes");
     int rc;
     c->st->hostTris = hTris;
     c->st->hostBottomNodes = std::move(hNodes);
@@ -2141,8 +2186,10 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
         c->st->materialBins = (types & (types - 1u)) != 0u && (c->cfg.flags & PT_FLAG_MATERIAL_BINS) != 0u; // opt-in: measured slower (pt_shade.h)
     }
     c->st->sg.extraRoots.clear();
+    tm.lap("mirrors");
     if ((rc = buildStaticGeom(c)))
         return rc;
+    tm.lap("buildStaticGeom");
     if (!async)
         refreshSceneView(c);
     return PT_OK;
@@ -2790,10 +2837,13 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     } useScene { c, c->st };
     if (c->statPending >= 0)
         c->st = &c->stat[c->statPending];
+    StageTimer tm("uploadDynamicAsync");
     DynamicHost h;
     int rc = convertDynamic(c, lights, nL, topNodes, nTop, topRoot, h);
+    tm.lap("convertDynamic");
     if (rc || (rc = uploadStaticGeom(c)))
         return rc;
+    tm.lap("uploadStaticGeom");
     StaticScene::StaticGeom& sg = c->st->sg;
     const int target = c->haveDynamic ? 1 - c->active : c->active; // nothing active yet: fill the active set itself
     pt_ctx::DynamicSet& d = c->dyn[target];
@@ -2804,6 +2854,10 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     const size_t staticNodes = sg.wide.size(), staticTris = (size_t)c->st->numTris + 1;
     // (+ 1: the SMALL traversal instantiations fetch 96 bytes from wherever a lane stands -- 32 beyond a node, 48 beyond a one-triangle leaf)
     const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size() + 1, needTris = staticTris + h.bakedTris + 1;
+    // the traversal kernels address nodes and triangle records by base + 32-bit byte offset (pt_trace.h, PT_OFFSET32)
+    if (needWide * sizeof(WideNode) > 0xFFFFFFFFull || needTris * sizeof(TriIsect) > 0xFFFFFFFFull)
+        return fail(c, PT_ERR_UNSUPPORTED, "scene of %zu packed nodes and %zu triangle records (world-space copies included): more than 4 GB of either; enter the instances instead (PT_FLAG_NO_BAKED_INSTANCES)",
+            needWide, needTris);
     const size_t bytes[7] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),
         h.jobs.size() * sizeof(BakeJob), h.instRoots.size() * sizeof(WideNode), h.instFold.size() * sizeof(float4), h.instRootSrc.size() * sizeof(uint32_t) };
     const size_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4] + bytes[5] + bytes[6];
@@ -2835,6 +2889,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         HIPCHK(c, hipEventSynchronize(d.stageRead));
         d.stageBusy = false;
     }
+    tm.lap("grow");
     if (d.staticVersion != sg.version) { // device to device, from the master copy
         if (staticNodes)
             HIPCHK(c, hipMemcpyAsync(d.wide.p, sg.dWide.p, staticNodes * sizeof(WideNode), hipMemcpyDeviceToDevice, c->copyStream));
@@ -2879,6 +2934,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(d.uploaded, c->copyStream));
+    tm.lap("enqueue");
     d.numLights = h.numLights;
     d.rootRef = h.rootRef;
     d.staticIndex = (int)(c->st - c->stat);

@@ -89,8 +89,10 @@ def test_quantised_child_boxes_contain_the_exact_ones():
         out = np.zeros(16, np.uint32)
         assert lib.pt_debug_quantise_node(lo.ctypes.data, hi.ctypes.data, refs.ctypes.data, empty.ctypes.data, empty_ref, out.ctypes.data) == 0
         origin = out[:3].view(np.float32)
-        exps = [(int(out[3]) >> (8 * a)) & 0xFF for a in range(3)]
-        scale = [np.float32(np.ldexp(1.0, e - 127)) for e in exps]
+        scale = [out[3:4].view(np.float32)[0], out[10:11].view(np.float32)[0], out[11:12].view(np.float32)[0]]  # scaleX, scaleY, scaleZ (pt_device.h)
+        for sc in scale:
+            m, _ = np.frexp(sc)
+            assert m == 0.5 and sc > 0, "the scale of an axis is a power of two"
         q = out[4:10]  # qlox, qhix, qloy, qhiy, qloz, qhiz: byte k = child k
         for k in range(4):
             assert out[12 + k] == (empty_ref if empty[k] else refs[k])
