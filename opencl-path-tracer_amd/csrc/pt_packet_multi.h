@@ -132,8 +132,14 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                 uint32_t px, pl;
                 primaryEntry(a.fp, a.pixelList, idx, &px, &pl);
                 primaryRay(a.fp, px, pl, &o, &d);
-                ((float4*)a.rayO)[idx] = make_float4(o.x, o.y, o.z, asF(px)); // queued for k_shade (the throughput of a primary ray is 1 and is not stored)
-                ((float4*)a.rayD)[idx] = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, pl)));
+                // queued for k_shade (the throughput of a primary ray is 1 and is not stored).  Round 5: nor is the origin where the caller says so -- every
+                // ray of a pinhole camera starts at the eye, and (pixel, sample) follow from the entry index: 16 B per ray less each way
+                if (a.noOrigins) {
+                    ((float4*)a.rayD)[idx] = make_float4(d.x, d.y, d.z, asF(px));
+                } else {
+                    ((float4*)a.rayO)[idx] = make_float4(o.x, o.y, o.z, asF(px));
+                    ((float4*)a.rayD)[idx] = make_float4(d.x, d.y, d.z, asF(packState(FLAG_LASTSPECULAR, 0u, pl)));
+                }
             }
             // zero components are nudged as at k_trace's hand-out (NO_PARALLEL_RAYS, scene.cl:123-137)
             if (d.x == 0.0f) d.x = FLT_MIN;

@@ -716,6 +716,7 @@ struct ShadeArgs {
     // parity mode: un-compacted staging + active flags for the stable compaction pass
     uint32_t* activeFlag;
     uint32_t firstTile; // first 512-entry tile this launch is responsible for
+    uint32_t derivedPrimaries; // pass 0 behind k_trace_multi (pinhole): the queue holds (direction, pixel) only -- origin = the eye, sample from the entry index
 };
 
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
@@ -831,10 +832,25 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
     ShadeResult r;
     uint32_t pixel = 0, bounce = 0, plane = 0;
     if (i < count) {
-        const float4 ro = ldQ(&a.in.o[i]);
         const float4 rd = ldQ(&a.in.d[i]);
-        const uint32_t fb = asU(rd.w);
-        pixel = asU(ro.w);
+        float4 ro;
+        uint32_t fb;
+        if (!PARITY && a.derivedPrimaries) { // (uniform) camera rays of a pinhole as k_trace_multi queued them
+            ro = a.fp.cam.eye;
+            pixel = asU(rd.w);
+            // the sample of the batch this entry is (k_gen's order, primaryEntry): group of `interleave` samples = i / span, sample inside it = the low bits
+            const uint32_t span = a.fp.numOwned << a.fp.interleaveShift;
+            uint32_t group = (uint32_t)((float)i * a.fp.invSpan);
+            if (group * span > i)
+                group--;
+            if ((group + 1u) * span <= i)
+                group++;
+            fb = packState(FLAG_LASTSPECULAR, 0u, (group << a.fp.interleaveShift) + (i & ((1u << a.fp.interleaveShift) - 1u)));
+        } else {
+            ro = ldQ(&a.in.o[i]);
+            fb = asU(rd.w);
+            pixel = asU(ro.w);
+        }
         bounce = (fb >> 8) & 0xFFu;
         plane = fb >> 16;
         if (!(fb & FLAG_FINISHED)) {

@@ -117,6 +117,7 @@ struct TraceArgs {
     uint32_t pass;
     // packet kernel, first pass of a batch: the camera rays are generated from the entry index instead of read from the queue
     uint32_t fused;
+    uint32_t noOrigins; // fused bundles of a pinhole camera: only the direction (with the pixel in .w) is queued for k_shade, which knows the eye and derives the rest from the entry index
     const uint32_t* pixelList;
     FrameParams fp;
     uint32_t* spill; // kSpillStack * totalThreads dwords
@@ -152,6 +153,13 @@ __device__ inline float fmaPlain(float a, float b, float c)
 {
     float r;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// 3 * x as one shift-add (the compiler turns "x * 48" and "(x + 2 x) << 4" alike into v_mul_lo_u32: a quarter-rate instruction)
+__device__ inline uint32_t times3(uint32_t x)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(x));
     return r;
 }
 // the distances to a child's entry and exit planes of one axis: q * a + b for both
@@ -794,7 +802,9 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
 #endif
                     for (uint32_t k = 0; k < n; k++) {
 #if PT_OFFSET32
-                        const TriIsect* tp = (const TriIsect*)((const char*)sc.tris + (size_t)(uint32_t)((first + k) * (uint32_t)sizeof(TriIsect)));
+                        static_assert(sizeof(TriIsect) == 48, "48 = 3 << 4: a shift-add and a shift instead of a quarter-rate 32-bit multiply");
+                        const uint32_t ti = first + k;
+                        const TriIsect* tp = (const TriIsect*)((const char*)sc.tris + (size_t)(uint32_t)(times3(ti) << 4));
 #else
                         const TriIsect* tp = &sc.tris[first + k];
 #endif

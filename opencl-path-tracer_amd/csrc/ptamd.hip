@@ -1401,6 +1401,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #ifndef PT_SHADE_SPLIT
 #define PT_SHADE_SPLIT 1
 #endif
+#ifndef PT_DERIVED_PRIMARIES
+#define PT_DERIVED_PRIMARIES 1
+#endif
 #ifndef PT_OVERLAP_SMALL
 #define PT_OVERLAP_SMALL 1 // small launches: shadow rays of bounce b beside the extension rays of bounce b + 1 (side stream)
 #endif
@@ -1438,7 +1441,7 @@ inline bool primaryBundles(const pt_ctx* c) { return PT_MULTI_RAYS > 1 && !c->ca
 inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
 
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
-void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr, bool descent = false)
+void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr, bool descent = false, bool noOrigins = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
@@ -1459,6 +1462,7 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
         // camera rays of a pinhole generated in the kernel: PT_MULTI_RAYS x 64 consecutive entries -- the samples of
         // one pixel, or of neighbouring pixels -- are ONE bundle and are walked as one (pt_packet_multi.h)
         if (fused && primaryBundles(c)) {
+            a.noOrigins = noOrigins ? 1u : 0u;
             c->packetLaunches++;
             c->bundleLaunches++;
             if (sceneKind(c) != 0)
@@ -1496,7 +1500,7 @@ void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t s
 }
 
 // shade over `launchEntries` slots (upper bound of the live count) of queue `in` -> queue `out` + shadow queue
-void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pass, uint32_t launchEntries, const ShadowQueueBuf* ownShadow = nullptr)
+void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pass, uint32_t launchEntries, const ShadowQueueBuf* ownShadow = nullptr, bool derivedPrimaries = false)
 {
     Control* ctl = c->control.p;
     ShadeArgs a {};
@@ -1511,6 +1515,7 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.shadeHits = &ctl->shadeHits[pass];
     a.deposits = parityMode(c) ? &ctl->depositsShade : &ctl->depositSlots[0][0]; // the production kernel spreads its count over the slots (pt_device.h)
     a.streams = c->streams.p;
+    a.derivedPrimaries = derivedPrimaries ? 1u : 0u;
     const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock; // those beyond the live count leave at once
     if (parityMode(c)) {
         a.out = c->stagedRays.view();
@@ -1609,6 +1614,9 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     const bool coherentFirst = firstPassCoherent(c, fp, batch);
     const bool packetsFirst = coherentFirst && c->dyn[c->active].packetOk && (c->packetUse & 1u);
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
+    // ... and where those are the bundles of a pinhole camera, only (direction, pixel) is queued: k_shade takes the eye as the origin and the sample from the
+    // entry index (12 instructions; the full regeneration the paragraph above dismissed is 70) -- 16 B per camera ray less written and 16 B less read
+    const bool derived = fused && primaryBundles(c) && PT_DERIVED_PRIMARIES;
     prof.begin(0);
     if (fused)
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, &c->control.p->extCount[0], &c->control.p->generated, entries);
@@ -1647,12 +1655,12 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         const bool coherent = b == 0 && coherentFirst;
         if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
-        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr, descentExt);
+        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr, descentExt, derived && b == 0);
         prof.end();
         if (overlap && !split && b > 0)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
-        launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr);
+        launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr, derived && b == 0);
         prof.end();
         if (descentShadow) {
             prof.begin(5);
