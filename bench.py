@@ -902,8 +902,9 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
     add("k_trace_multi<4>" if bundles else "k_trace_packet<false>",
         ("closest-hit traversal of the primary rays, one bundle of 4 x 64 per wave (one tree walk, four rays per lane)" if bundles
          else "closest-hit traversal of the primary rays, one packet of 64 per wave")
-        + (" (generates the camera rays itself and queues them for k_shade: 32 B written per ray instead of 28 B read)" if fused else ""),
-        ps["ms_packet"], batches, primary, BYTES_PER_GEN_RAY + 20 if fused else BYTES_PER_EXT_RAY)
+        + ((" (generates the camera rays itself and queues direction + pixel for k_shade, which knows the eye: 16 B + the 20 B hit record written per ray, nothing read)"
+            if bundles else " (generates the camera rays itself and queues them for k_shade: 32 B written per ray instead of 28 B read)") if fused else ""),
+        ps["ms_packet"], batches, primary, ((16 if bundles else BYTES_PER_GEN_RAY) + 20) if fused else BYTES_PER_EXT_RAY)
     add("k_shade<false>", "shade + NEE + continuation + compaction (+ deposits of emissive hits and sky misses)", ps["ms_shade"], 4 * batches,
         ps["shade_hits"], BYTES_PER_SHADED_HIT, BYTES_PER_DEPOSIT * dep_shade)
     if not fused:
