@@ -32,7 +32,8 @@ def build_host(force=False):
 # PTAMD_SANITIZE=1: the host library (the parsers of untrusted bytes: PNG / Radiance / OBJ / MTL / PLY / .bvh) and the oracle built with
 # AddressSanitizer + UndefinedBehaviorSanitizer next to the regular files (lib*_san.so); ptamd.host and oracle/orclib.py load those when
 # the variable is set.  CPU build only (the GPU pool refuses sanitizer runs).  Run python with the sanitizer runtime preloaded:
-#   PTAMD_SANITIZE=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_scene.py ...
+#   PTAMD_SANITIZE=1 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so)" ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m 'not gpu'
+# (libstdc++ too: python does not link it, and the sanitizer's __cxa_throw interceptor aborts at the first C++ exception if it was not there at start-up)
 SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
 
 

@@ -198,6 +198,13 @@ def test_determinism_batching_refill_and_tiles(gpu):
     assert sp0["rays_extension"] + sp1["rays_extension"] == stp["rays_extension"]
     assert not (p0.any(axis=1) & p1.any(axis=1)).any()
     assert np.allclose(p0 + p1, ap, rtol=1e-5, atol=1e-5 * ap.max())
+    # ... and in batches that are not the context's full width (48 = 32 + 16 samples): the shading kernel takes the sample of a camera ray from its
+    # queue index (the bundles queue direction + pixel only, round 5), so the index arithmetic of every batch shape has to agree with k_gen's
+    aq, stq = run(spp=48, tiles=rects[1::2], samples_in_flight=64)
+    ar, str_ = run(spp=48, tiles=rects[1::2], samples_in_flight=64, flags=gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS)
+    assert stq["bundle_launches"] > 0 and str_["packet_launches"] == 0
+    assert stq["rays_extension"] == str_["rays_extension"] and stq["rays_shadow"] == str_["rays_shadow"]
+    assert np.allclose(aq, ar, rtol=1e-5, atol=1e-5 * ar.max())
 
 
 @pytest.mark.parametrize("scene", ["room", "grid_two_level"])
