@@ -633,6 +633,7 @@ def main():
     ap.add_argument("--thin-lens", action="store_true", help="configs[4]'s camera: thin lens f/2 focused on the grid centre (with --width 3840 --height 2160: config 5)")
     ap.add_argument("--grid", default="4x3", help="instances of the two meshes, columns x rows (4x3 = 985 012 instanced triangles: the headline since round 1; "
                                                   "5x3 = SURVEY 8(d)'s 15 instances, 1 231 264 with these meshes -- also reported as the `grid_5x3` object of the default line)")
+    ap.add_argument("--builder", default="spatial", choices=["spatial", "binned", "fast"], help="BVH builder of the instanced meshes (diagnostic: how much the tree's quality is worth)")
     ap.add_argument("--flags", type=int, default=0, help="pt_config.flags of the render context (2 = PT_FLAG_NO_BAKED_INSTANCES: two-level traversal)")
     ap.add_argument("--dump-accum", default=None, help="rank 0 saves the (reduced) HDR accumulator as .npy (tests)")
     args = ap.parse_args()
@@ -694,7 +695,8 @@ def main():
         except Exception as e:  # a secondary figure must not take the headline down
             frame = {"error": str(e)[:300]}
     gx, gz = (int(v) for v in args.grid.lower().split("x"))
-    bundle = scenes.instanced_grid(W, Hh, nx=gx, nz=gz, level=args.level, builder=H.BVH_SPATIAL_SPLIT, thin_lens=args.thin_lens)
+    bundle = scenes.instanced_grid(W, Hh, nx=gx, nz=gz, level=args.level, thin_lens=args.thin_lens,
+                                   builder={"spatial": H.BVH_SPATIAL_SPLIT, "binned": H.BVH_BINNED_SAH, "fast": H.BVH_BINNED_FAST}[args.builder])
     flat = bundle.flat
     rects = tile_rects(W, Hh, rank, world) if world > 1 else []
     owned = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in rects) if rects else W * Hh
