@@ -2,6 +2,7 @@
 // conversion into the HBM layouts of pt_device.h, the launch schedule that replaces the reference's
 // RayTracer::traceRays (src/raytracer.cpp:289-430), and the kernel-granular test hooks.
 #include "../../include/ptamd.h"
+#include "../host/parallel.h" // (header only: the worker threads the host library uses, here for the conversion of an upload)
 #include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_packet.h"
@@ -940,26 +941,33 @@ int buildStaticGeom(pt_ctx* c)
         g.kidSrc.resize(order.size() * 4, 0u);
         g.kidEmpty.resize(order.size() * 4, 1u);
         g.kidBoxNode.resize(order.size() * 4, 0xFFFFFFFFu);
-        for (size_t q = root.nodeBase; q < order.size(); q++) {
+        for (size_t q = root.nodeBase; q < order.size(); q++) { // the leaves' runs in the table of triangle references: in node order, one after the other
             const WideKids& wk = kids[order[q]];
-            uint32_t refs[4];
-            for (int k = 0; k < 4; k++) {
-                g.kidSrc[q * 4 + k] = wk.src[k], g.kidEmpty[q * 4 + k] = wk.empty[k] ? 1u : 0u;
-                if (!wk.empty[k]) { // the caller's node whose box this slot takes: the left / right child of the node its pair mirrors
-                    const uint32_t pr = wk.src[k] >> 1, side = wk.src[k] & 1u;
-                    g.kidBoxNode[q * 4 + k] = pr < c->st->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->st->numDensePairs) * 2u + side));
-                }
-                refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+            for (int k = 0; k < 4; k++)
                 if (!wk.empty[k] && !isInner(wk.ref[k])) {
                     g.leafOfs[q * 4 + k] = (uint32_t)g.refTri.size() - root.refBase;
                     for (uint32_t t = 0; t < refCount(wk.ref[k]); t++)
                         g.refTri.push_back(refIndex(wk.ref[k]) + t);
                 }
-                for (int a = 0; a < 3; a++)
-                    g.boxes[q].lo[k][a] = wk.lo[k][a], g.boxes[q].hi[k][a] = wk.hi[k][a];
-            }
-            quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, emptyRef, &g.wide[q]);
         }
+        // ... everything else per node on its own (the quantiser is most of a conversion's time): the host library's worker threads take ranges of them
+        raytracer::WorkerPool::get().parallelFor(order.size() - root.nodeBase, 512, [&](size_t q0, size_t q1) {
+            for (size_t q = root.nodeBase + q0; q < root.nodeBase + q1; q++) {
+                const WideKids& wk = kids[order[q]];
+                uint32_t refs[4];
+                for (int k = 0; k < 4; k++) {
+                    g.kidSrc[q * 4 + k] = wk.src[k], g.kidEmpty[q * 4 + k] = wk.empty[k] ? 1u : 0u;
+                    if (!wk.empty[k]) { // the caller's node whose box this slot takes: the left / right child of the node its pair mirrors
+                        const uint32_t pr = wk.src[k] >> 1, side = wk.src[k] & 1u;
+                        g.kidBoxNode[q * 4 + k] = pr < c->st->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->st->numDensePairs) * 2u + side));
+                    }
+                    refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+                    for (int a = 0; a < 3; a++)
+                        g.boxes[q].lo[k][a] = wk.lo[k][a], g.boxes[q].hi[k][a] = wk.hi[k][a];
+                }
+                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, emptyRef, &g.wide[q]);
+            }
+        });
         root.numRefs = (uint32_t)g.refTri.size() - root.refBase;
         g.rootOfNode[rn] = (int32_t)g.roots.size();
         g.roots.push_back(root);

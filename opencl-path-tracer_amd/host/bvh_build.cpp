@@ -1,9 +1,14 @@
 // Bottom-level BVH construction: binned SAH (3 axes or longest axis) and SBVH with spatial
 // splits + reference unsplitting.  See bvh_build.h for the contract and the reference citations.
 #include "bvh_build.h"
+#include "parallel.h"
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cassert>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -49,6 +54,13 @@ namespace {
         return a;
     }
 
+    constexpr size_t kParallelBinning = 4096; // references of a node from which the object-split bins are filled by all workers
+    inline bool sequentialBuild()
+    {
+        const char* env = std::getenv("PTAMD_BUILD_THREADS");
+        return env && std::atoi(env) == 1;
+    }
+
     inline int binOf(float x, float lo, float invWidth, int numBins)
     {
         int b = (int)((x - lo) * invWidth);
@@ -67,10 +79,33 @@ namespace {
             const float invWidth = (float)kObjectBins / ext[axis];
             std::array<AABB, kObjectBins> box;
             std::array<size_t, kObjectBins> count {};
-            for (const PrimRef& r : refs) {
-                int b = binOf(r.box.center()[axis], nodeBox.min[axis], invWidth, kObjectBins);
-                box[b].fit(r.box);
-                count[b]++;
+            auto binRange = [&](size_t begin, size_t end, std::array<AABB, kObjectBins>& bx, std::array<size_t, kObjectBins>& cn) {
+                for (size_t i = begin; i < end; i++) {
+                    const PrimRef& r = refs[i];
+                    int b = binOf(r.box.center()[axis], nodeBox.min[axis], invWidth, kObjectBins);
+                    bx[b].fit(r.box);
+                    cn[b]++;
+                }
+            };
+            if (refs.size() >= kParallelBinning && WorkerPool::get().threads() > 1 && !WorkerPool::insideTask() && !sequentialBuild()) {
+                // the top of a large tree: every worker bins a range into bins of its own (min / max and counts: the merged bins do not depend on the split)
+                WorkerPool& pool = WorkerPool::get();
+                const size_t parts = pool.threads(), chunk = (refs.size() + parts - 1) / parts;
+                std::vector<std::array<AABB, kObjectBins>> pbox(parts);
+                std::vector<std::array<size_t, kObjectBins>> pcount(parts);
+                for (auto& c : pcount)
+                    c.fill(0);
+                pool.parallelFor(parts, 1, [&](size_t p0, size_t p1) {
+                    for (size_t p = p0; p < p1; p++)
+                        binRange(std::min(p * chunk, refs.size()), std::min((p + 1) * chunk, refs.size()), pbox[p], pcount[p]);
+                });
+                for (size_t p = 0; p < parts; p++)
+                    for (int b = 0; b < kObjectBins; b++) {
+                        box[b].fit(pbox[p][b]);
+                        count[b] += pcount[p][b];
+                    }
+            } else {
+                binRange(0, refs.size(), box, count);
             }
             // suffix boxes/counts, then a forward sweep
             std::array<AABB, kObjectBins> rightBox;
@@ -183,6 +218,8 @@ namespace {
             storeBox(blank, AABB());
             nodes.push_back(blank);
             nodes.push_back(blank);
+            if (deferred)
+                pairEpoch.push_back((uint32_t)deferred->size());
             return first;
         }
 
@@ -351,21 +388,31 @@ namespace {
             nodes[node].leftChildOrFirstTriangle = (uint32_t)leafRefs.size();
             nodes[node].triangleCount = (uint32_t)refs.size();
             leafRefs.insert(leafRefs.end(), refs.begin(), refs.end());
+            if (deferred)
+                topLeaves.push_back({ node, (uint32_t)deferred->size() });
         }
 
-        void run(std::vector<PrimRef>&& all)
-        {
-            AABB rootBox;
-            for (auto& r : all) rootBox.fit(r.box);
-            rootArea = rootBox.surfaceArea();
-            uint32_t root = allocPair();
-            storeBox(nodes[root], rootBox);
+        // A subtree set aside by the top phase of a parallel build: the slot of its root (already holding its box), and where the sequential build's arrays
+        // stood when it would have been built -- everything it allocates comes right there, ahead of what the top phase allocated afterwards.
+        struct Deferred {
+            uint32_t slot, depth;
+            std::vector<PrimRef> refs;
+            size_t nodesBefore, leavesBefore; // sizes of the top phase's arrays at that moment
+        };
+        std::vector<uint32_t> pairEpoch; // per pair of `nodes` (top phase): how many subtrees had been set aside when it was allocated
+        std::vector<std::pair<uint32_t, uint32_t>> topLeaves; // (node, epoch) of the leaves the top phase made itself
+        std::vector<Deferred>* deferred = nullptr;
+        size_t deferBelow = 0;
 
-            std::vector<Work> stack;
-            stack.push_back({ root, 0, std::move(all) });
+        void build(std::vector<Work>& stack)
+        {
             while (!stack.empty()) {
                 Work w = std::move(stack.back());
                 stack.pop_back();
+                if (deferred && w.depth > 0 && w.refs.size() <= deferBelow && w.refs.size() > kLeafSize) { // a worker thread's share (buildParallel)
+                    deferred->push_back({ w.node, w.depth, std::move(w.refs), nodes.size(), leafRefs.size() });
+                    continue;
+                }
                 maxDepthSeen = std::max(maxDepthSeen, w.depth);
                 const AABB nodeBox = loadBox(nodes[w.node]);
                 const size_t n = w.refs.size();
@@ -428,6 +475,99 @@ namespace {
                 stack.push_back({ pair, w.depth + 1, std::move(left) });
                 stack.push_back({ pair + 1, w.depth + 1, std::move(right) });
             }
+        }
+
+        void run(std::vector<PrimRef>&& all)
+        {
+            AABB rootBox;
+            for (auto& r : all) rootBox.fit(r.box);
+            rootArea = rootBox.surfaceArea();
+            // Large meshes: the top of the tree here, the subtrees below ~1/12 of the references on the worker threads, each into arrays of its own; the
+            // result is put together in the order the sequential build allocates (a subtree's nodes and leaves are contiguous there: the build is depth
+            // first), so the arrays are the same bytes whatever the thread count -- PTAMD_BUILD_THREADS=1 builds sequentially (tests compare the two).
+            const size_t n = all.size();
+            const bool parallel = n >= 8192 && WorkerPool::get().threads() > 1 && !sequentialBuild();
+            std::vector<Deferred> subtrees;
+            if (parallel) {
+                deferred = &subtrees;
+                deferBelow = std::max<size_t>(1024, n / 12);
+            }
+            uint32_t root = allocPair();
+            storeBox(nodes[root], rootBox);
+            std::vector<Work> stack;
+            stack.push_back({ root, 0, std::move(all) });
+            const auto t0 = std::chrono::steady_clock::now();
+            build(stack);
+            const auto t1 = std::chrono::steady_clock::now();
+            deferred = nullptr;
+            if (!subtrees.empty())
+                finishParallel(subtrees);
+            if (std::getenv("PTAMD_BUILD_TIMING"))
+                fprintf(stderr, "[ptamd_host] buildBVH: %zu references, top phase %.3f ms (%zu subtrees set aside), subtrees + assembly %.3f ms\n", n,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), subtrees.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+        }
+
+        void finishParallel(std::vector<Deferred>& subtrees)
+        {
+            const size_t numSub = subtrees.size();
+            std::vector<Builder> local(numSub, Builder { verts, tris, kind });
+            std::atomic<size_t> next { 0 };
+            WorkerPool& pool = WorkerPool::get();
+            pool.parallelFor(pool.threads(), 1, [&](size_t, size_t) {
+                for (size_t k; (k = next.fetch_add(1)) < numSub;) {
+                    Builder& b = local[k];
+                    b.rootArea = rootArea;
+                    b.nodes.reserve(subtrees[k].refs.size() + 2);
+                    b.leafRefs.reserve(subtrees[k].refs.size() + subtrees[k].refs.size() / 4);
+                    b.allocPair(); // [0]: a copy of the subtree's root slot, [1]: unused
+                    b.nodes[0] = nodes[subtrees[k].slot];
+                    std::vector<Work> stack;
+                    stack.push_back({ 0u, subtrees[k].depth, std::move(subtrees[k].refs) });
+                    b.build(stack);
+                }
+            });
+            // where everything goes: a subtree's nodes behind what the top phase had allocated when it set the subtree aside, plus the earlier subtrees
+            std::vector<size_t> nodesOfEarlier(numSub + 1, 0), leavesOfEarlier(numSub + 1, 0);
+            for (size_t k = 0; k < numSub; k++) {
+                nodesOfEarlier[k + 1] = nodesOfEarlier[k] + local[k].nodes.size() - 2;
+                leavesOfEarlier[k + 1] = leavesOfEarlier[k] + local[k].leafRefs.size();
+                maxDepthSeen = std::max(maxDepthSeen, local[k].maxDepthSeen);
+            }
+            std::vector<SubBVHNode> allNodes(nodes.size() + nodesOfEarlier[numSub]);
+            std::vector<PrimRef> allLeaves(leafRefs.size() + leavesOfEarlier[numSub]);
+            std::vector<uint8_t> isSubtreeRoot(nodes.size(), 0);
+            for (const Deferred& d : subtrees)
+                isSubtreeRoot[d.slot] = 1;
+            auto topIndex = [&](uint32_t i) { return i + (uint32_t)nodesOfEarlier[pairEpoch[i / 2]]; };
+            for (const auto& [node, epoch] : topLeaves) { // the top phase's own leaves
+                SubBVHNode& nd = nodes[node];
+                const uint32_t first = nd.leftChildOrFirstTriangle;
+                std::copy(leafRefs.begin() + first, leafRefs.begin() + first + nd.triangleCount, allLeaves.begin() + first + leavesOfEarlier[epoch]);
+                nd.leftChildOrFirstTriangle = first + (uint32_t)leavesOfEarlier[epoch];
+            }
+            for (uint32_t i = 0; i < nodes.size(); i++) {
+                SubBVHNode nd = nodes[i];
+                if (!isSubtreeRoot[i] && nd.triangleCount == 0 && nd.leftChildOrFirstTriangle != 0)
+                    nd.leftChildOrFirstTriangle = topIndex(nd.leftChildOrFirstTriangle);
+                allNodes[topIndex(i)] = nd;
+            }
+            for (size_t k = 0; k < numSub; k++) {
+                const Builder& b = local[k];
+                const size_t nodeBase = subtrees[k].nodesBefore + nodesOfEarlier[k], leafBase = subtrees[k].leavesBefore + leavesOfEarlier[k];
+                auto moved = [&](SubBVHNode nd) {
+                    if (nd.triangleCount == 0)
+                        nd.leftChildOrFirstTriangle = (uint32_t)(nodeBase + nd.leftChildOrFirstTriangle - 2);
+                    else
+                        nd.leftChildOrFirstTriangle = (uint32_t)(leafBase + nd.leftChildOrFirstTriangle);
+                    return nd;
+                };
+                allNodes[topIndex(subtrees[k].slot)] = moved(b.nodes[0]);
+                for (size_t i = 2; i < b.nodes.size(); i++)
+                    allNodes[nodeBase + i - 2] = moved(b.nodes[i]);
+                std::copy(b.leafRefs.begin(), b.leafRefs.end(), allLeaves.begin() + leafBase);
+            }
+            nodes = std::move(allNodes);
+            leafRefs = std::move(allLeaves);
         }
     };
 

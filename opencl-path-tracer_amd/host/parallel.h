@@ -24,7 +24,7 @@ public:
     void parallelFor(size_t count, size_t minPerThread, const std::function<void(size_t, size_t)>& fn)
     {
         const size_t parts = std::max<size_t>(1, std::min<size_t>(m_threads.size() + 1, count / std::max<size_t>(minPerThread, 1)));
-        if (parts <= 1) {
+        if (parts <= 1 || insideTask()) { // (a loop inside a task of the pool runs where it is: the pool serves one parallelFor at a time)
             if (count)
                 fn(0, count);
             return;
@@ -36,12 +36,19 @@ public:
             m_fn = &fn, m_count = count, m_chunk = chunk, m_parts = parts, m_pending = parts - 1, m_generation++;
         }
         m_wake.notify_all();
+        insideTask() = true;
         fn(0, std::min(chunk, count));
+        insideTask() = false;
         std::unique_lock<std::mutex> lock(m_mutex);
         m_done.wait(lock, [&] { return m_pending == 0; });
         m_fn = nullptr;
     }
     size_t threads() const { return m_threads.size() + 1; }
+    static bool& insideTask()
+    {
+        static thread_local bool inside = false;
+        return inside;
+    }
 
 private:
     WorkerPool()
@@ -77,8 +84,11 @@ private:
                     continue; // fewer parts than threads this time
                 fn = m_fn, begin = std::min(part * m_chunk, m_count), end = std::min(begin + m_chunk, m_count);
             }
-            if (begin < end)
+            if (begin < end) {
+                insideTask() = true;
                 (*fn)(begin, end);
+                insideTask() = false;
+            }
             {
                 std::lock_guard<std::mutex> lock(m_mutex);
                 if (--m_pending == 0)

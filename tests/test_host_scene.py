@@ -55,6 +55,22 @@ def test_empty_mesh_and_bad_indices_are_errors():
         H.Mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32), [L.material_diffuse((1, 1, 1))])
 
 
+@pytest.mark.parametrize("builder", [H.BVH_BINNED_SAH, H.BVH_BINNED_FAST, H.BVH_SPATIAL_SPLIT])
+def test_the_worker_pool_builds_the_sequential_builders_arrays(builder, monkeypatch):
+    """Meshes of >= 8 192 triangles are built by the worker pool -- the top of the tree (with every worker filling object-split bins of its own),
+    then the subtrees below a twelfth of the references one per task -- and put together in the order the sequential build allocates: the node,
+    triangle and original-index arrays must be the same bytes as with PTAMD_BUILD_THREADS=1."""
+    v, f = scenes.icosphere(5)  # 20 480 triangles
+    p = (v * 0.5 * (1.0 + 0.1 * np.sin(7.0 * v[:, :1]))).astype(np.float32)
+    f = f.astype(np.uint32)
+    mat = [L.material_diffuse((0.8, 0.8, 0.8))]
+    pooled = H.Mesh(p, f, mat, builder=builder).bvh()
+    monkeypatch.setenv("PTAMD_BUILD_THREADS", "1")
+    alone = H.Mesh(p, f, mat, builder=builder).bvh()
+    for a, b in zip(pooled, alone):
+        assert a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
 def test_flatten_rebases_indices_and_shares_instanced_meshes():
     b = scenes.instanced_grid(64, 36, nx=3, nz=2, level=2, sky_size=(16, 8))
     f = b.flat
