@@ -62,6 +62,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PT_PACKED_FMA
 #define PT_PACKED_FMA 0 // 1: the plane distances as 12 v_pk_fma_f32 instead of 24 v_fma_f32 (rounds 2-4; see fmaPlain: 11 040 -> 11 270 Mrays/s without them)
 #endif
+#ifndef PT_CLOSEST_SORT
+#define PT_CLOSEST_SORT 5
+#endif
 #ifndef PT_OFFSET32
 #define PT_OFFSET32 1
 #endif
@@ -739,7 +742,13 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     } else
 #endif
                     {
+#if PT_CLOSEST_SORT == 3 // (experiments: the nearest first, the others as they come / nearest first and farthest last)
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2)
+#elif PT_CLOSEST_SORT == 4
+                        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3)
+#else
                         PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#endif
                     }
 #undef PT_CSWAP
                     // farthest first onto the stack, continue with the nearest
