@@ -1116,7 +1116,9 @@ __global__ void k_set_word(uint32_t* p, uint32_t v)
 // end-of-sample bookkeeping: fold the per-pass counters into 64-bit totals and zero the control
 // block for the next sample (replaces updateKernelData, kernel.cl:303-317, and the per-pass
 // blocking KernelData read-back of raytracer.cpp:381-389).
-__global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
+// `countsOut` (may be null): pinned host memory that receives the pass counters -- next frame's launch sizes and kernel choices (a copy command on the
+// stream was a blit kernel and two launch gaps on a 1-spp frame's critical path: ~20 us of ~750)
+__global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes, uint32_t* countsOut)
 {
     // one wave: lane p folds and clears the counters of pass p, lane k the k-th deposit slot (17 passes, 64 slots: one round of loads instead of a
     // single thread's hundred dependent ones -- 13 us of a 1-spp frame's critical path were this kernel)
@@ -1125,6 +1127,8 @@ __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes)
         return;
     const uint32_t lane = threadIdx.x;
     unsigned long long ext = 0, sh = 0, hits = 0, slots = 0;
+    if (countsOut && lane <= (uint32_t)kMaxPasses)
+        countsOut[lane] = lane <= passes ? ctl->extCount[lane] : 0u;
     if (lane <= passes && lane <= (uint32_t)kMaxPasses) {
         ext = ctl->extCount[lane];
         sh = ctl->shadowCount[lane];

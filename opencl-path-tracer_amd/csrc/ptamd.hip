@@ -1695,12 +1695,13 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         if (split && bounces > 1)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 2], 0)); // the other side stream's last pass
     }
-    if (c->passCountsPinned && !c->passCountsPending) { // (a copy still in flight keeps its slot: the host reads it only once its event has fired)
-        HIPCHK(c, hipMemcpyAsync(c->passCountsPinned, &c->control.p->extCount[0], sizeof(c->passCountsHint), hipMemcpyDeviceToHost, c->stream));
+    // the pass counters go to pinned memory from inside k_end_sample (a report still unread keeps its slot: the host reads it only once its event has fired)
+    const bool report = c->passCountsPinned && !c->passCountsPending;
+    hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces, report ? c->passCountsPinned : nullptr);
+    if (report) {
         HIPCHK(c, hipEventRecord(c->passCountsCopied, c->stream));
         c->passCountsPending = entries;
     }
-    hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, bounces);
     c->batchEntries = 0;
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
     HIPCHK(c, hipGetLastError());
@@ -1763,7 +1764,7 @@ int renderSampleRefill(pt_ctx* c, uint32_t sample)
         if (counts[1] != 0)
             launchShadow(c, 0);
         // fold this pass into the totals (entries/ shadow counted on the host side of the loop)
-        hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, 0u);
+        hipLaunchKernelGGL(k_end_sample, dim3(1), dim3(64), 0, c->stream, c->control.p, c->totals.p, 0u, (uint32_t*)nullptr);
         if (surviving == 0 && issued >= c->numOwned)
             break;
         std::swap(in, out);
