@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
     uint32_t i = tile * kShadeBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (BINNED) {
-        constexpr uint32_t kKeys = 8u, kWaves = kShadeBlock / 64u;
+        constexpr uint32_t kWaves = kShadeBlock / 64u, kKeys = 64u / kWaves; // (8 keys with the 512-thread workgroups of the build; six are in use)
         static_assert(kKeys * kWaves == 64u, "one lane per (key, wave) counter");
         __shared__ uint32_t sBin[kKeys * kWaves]; // [key][wave]
         __shared__ uint16_t sPerm[kShadeBlock];
