@@ -6,7 +6,7 @@ A *step* is one pass of the hot path over one batch: `512*N*R` samples per pixel
 owns (N = ranks, R = --rounds, default 3: with the driver's 20 steps the timed region is ~11 s), i.e. R x [gen ->
 4 x (intersect, shade, shadow intersect)] over ~1.06 G path segments in the first launches on every rank.  Every launch ends in a latency-bound tail of ~0.15 ms, so
 large batches matter (64 / 128 / 256 samples in flight: 7.8 / 8.1 / 8.3 Grays/s in round 1; 256 / 512 / 768 on round 4's build, one box: 10 916 / 11 122 / 11 160
-Mrays/s); 512 in flight keep ~200 GB of queues + accumulator planes resident (round 1-3: 256, ~100 GB), which is what 288 GB of HBM are for.  Image tiles (32x32, interleaved)
+Mrays/s); 512 in flight keep ~200 GB of queues + accumulator planes resident (round 1-3: 256, ~100 GB), which is what 288 GB of HBM are for.  Image tiles (16x16, interleaved)
 shard across ranks, every rank traces the same number of paths per step whatever N is (weak scaling: the image
 simply receives N x more samples per step), and there is no data-path collective: the only exchange is ONE
 RCCL reduce of the HDR accumulator at the end of the job (torch.distributed, backend nccl == RCCL), inside the
@@ -53,10 +53,13 @@ IN_FLIGHT = 512  # samples in flight per pixel at 1080p on one rank (x N on 1/N 
 MAX_ENTRIES = 1920 * 1080 * IN_FLIGHT  # path segments resident per rank (~200 GB of queues and planes): the 1080p job at any N; caps 4K
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
 BYTES_PER_QUEUE_ENTRY = 164  # resident per queue entry: two extension queues (2 x 48 B), the shadow queue (48 B), the hit record (20 B) -- ensureQueues' accounting
+TILE = int(os.environ.get("PTAMD_TILE", "16"))  # edge of the image tiles dealt to the ranks of an N-GPU job.  16 since round 5: every rank's share of the N = 8 job emulated on one
+# GPU (tools/rank_emul.py), slowest rank over fastest: 32 x 32 tiles 1.037 (7.70 x predicted), 16 x 16 1.024 (7.80 x), 8 x 8 1.015 (7.84 x); the variable: diagnostics
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
 
 
-def tile_rects(width, height, rank, world, tile=32):
+def tile_rects(width, height, rank, world, tile=None):
+    tile = tile or TILE
     rects, t = [], 0
     for y in range(0, height, tile):
         for x in range(0, width, tile):
@@ -827,7 +830,7 @@ def main():
                 "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
                 "resident_gb": round(resident_bytes(in_flight, owned) / 1e9, 1),  # queues + accumulator planes of this rank (164 B per entry, 16 B per plane and pixel)
                 "device_memory_gb": {"total": round(total_b / 1e9, 1), "free_before": round(free_b / 1e9, 1), "free_while_rendering": round(free_after / 1e9, 1)},
-                "tiles": "whole frame" if world == 1 else "32x32 tiles interleaved over ranks",
+                "tiles": "whole frame" if world == 1 else f"{TILE}x{TILE} tiles interleaved over ranks",
                 "pixels_per_rank": owned, "paths_per_step_per_rank": owned * spp_step,
                 "collective": "none" if world == 1 else f"1 x reduce(SUM) of the HDR accumulator ({args.backend}) per job, inside the timed region",
             },

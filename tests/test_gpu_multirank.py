@@ -62,7 +62,7 @@ def test_bench_starts_its_own_ranks_and_strong_scaling_keeps_the_job_fixed(gpu, 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_four_rank_job_on_one_gpu_equals_the_single_rank_job(gpu, tmp_path, scaling):
     """Four ranks on the test box's one GPU (the box admits six processes on its card; the driver's own scaling run uses N = 1, 2, 4, 8
-    GPUs -- the eight-rank planning is rehearsed on the CPU, tests/test_multirank_gloo.py): interleaved 32x32 tiles over four ranks, the
+    GPUs -- the eight-rank planning is rehearsed on the CPU, tests/test_multirank_gloo.py): interleaved 16x16 tiles over four ranks, the
     smallest share deciding the batch, the reduce and the aggregation over four processes."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
