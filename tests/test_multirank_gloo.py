@@ -130,3 +130,15 @@ def test_bench_without_a_launcher_starts_its_ranks_as_child_processes():
     assert r.returncode != 0
     assert "bench.py needs a GPU" in r.stderr and "launch with torch.distributed.run" not in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_bench_line_reads_the_counters_of_the_newest_round():
+    """roofline.traffic and the per-kernel issue figures of the bench line come from the committed PMC summaries (profiles/roundN/traffic*.json) of the
+    timed configuration: the NEWEST round's, and the file written by tools/traffic_json.py for that build -- not an archived copy that happens to sort
+    behind it (round 5: `traffic_r5p_before_plain_fma.json` did, and two bench lines quoted the instructions per ray of the build before)."""
+    import re
+    import bench
+    rounds = sorted(int(m.group(1)) for m in (re.match(r"round(\d+)$", d) for d in os.listdir(os.path.join(ROOT, "profiles"))) if m)
+    for flags, name in ((0, "traffic.json"), (2, "traffic_two_level.json")):
+        tj = bench.newest_traffic_json(1920, 1080, 6, bench.IN_FLIGHT, 1, flags)
+        assert tj is not None and tj["_path"] == os.path.join("profiles", f"round{rounds[-1]}", name), tj and tj["_path"]
