@@ -9,6 +9,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace raytracer {
@@ -24,7 +25,9 @@ public:
     void parallelFor(size_t count, size_t minPerThread, const std::function<void(size_t, size_t)>& fn)
     {
         const size_t parts = std::max<size_t>(1, std::min<size_t>(m_threads.size() + 1, count / std::max<size_t>(minPerThread, 1)));
-        if (parts <= 1 || insideTask()) { // (a loop inside a task of the pool runs where it is: the pool serves one parallelFor at a time)
+        // (a loop inside a task of the pool runs where it is: the pool serves one parallelFor at a time; so does everything in a process that was
+        // forked after the pool had started -- fork copies the calling thread only, the workers are not there)
+        if (parts <= 1 || insideTask() || getpid() != m_pid) {
             if (count)
                 fn(0, count);
             return;
@@ -43,7 +46,7 @@ public:
         m_done.wait(lock, [&] { return m_pending == 0; });
         m_fn = nullptr;
     }
-    size_t threads() const { return m_threads.size() + 1; }
+    size_t threads() const { return getpid() == m_pid ? m_threads.size() + 1 : 1; }
     static bool& insideTask()
     {
         static thread_local bool inside = false;
@@ -96,6 +99,7 @@ private:
             }
         }
     }
+    const pid_t m_pid = getpid();
     std::vector<std::thread> m_threads;
     std::mutex m_mutex, m_callers;
     std::condition_variable m_wake, m_done;

@@ -2,6 +2,7 @@
 src/bvh/bvh_test.cpp:117-139, as real tests), top-level BVH, flattening with index rebasing
 (src/raytracer.cpp:244-270) and camera derivation (src/camera.cpp:18-58)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -69,6 +70,32 @@ def test_the_worker_pool_builds_the_sequential_builders_arrays(builder, monkeypa
     alone = H.Mesh(p, f, mat, builder=builder).bvh()
     for a, b in zip(pooled, alone):
         assert a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_a_forked_child_builds_without_the_parents_worker_threads():
+    """fork() copies the calling thread only: a child of a process whose worker pool has started must not wait for workers that are not there."""
+    v, f = scenes.icosphere(5)
+    p = (v * 0.5).astype(np.float32)
+    f = f.astype(np.uint32)
+    mat = [L.material_diffuse((0.8, 0.8, 0.8))]
+    here = H.Mesh(p, f, mat, builder=H.BVH_BINNED_FAST).bvh()  # (the pool is running now)
+    pid = os.fork()
+    if pid == 0:
+        try:
+            there = H.Mesh(p, f, mat, builder=H.BVH_BINNED_FAST).bvh()
+            os._exit(0 if all(a.tobytes() == b.tobytes() for a, b in zip(here, there)) else 3)
+        except BaseException:
+            os._exit(4)
+    for _ in range(600):  # (a deadlocked child would hang the suite: poll with a deadline)
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        pytest.fail("the forked child did not finish its build within 30 s")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
 
 
 def test_flatten_rebases_indices_and_shares_instanced_meshes():
