@@ -63,6 +63,11 @@ private:
     }
     ~WorkerPool()
     {
+        if (getpid() != m_pid) { // a forked child: there is nothing to join
+            for (std::thread& t : m_threads)
+                t.detach();
+            return;
+        }
         {
             std::lock_guard<std::mutex> lock(m_mutex);
             m_quit = true;
