@@ -18,8 +18,12 @@ class WorkerPool {
 public:
     static WorkerPool& get()
     {
-        static WorkerPool pool;
-        return pool;
+        // on the heap, never destroyed by a static destructor: a forked child inherits the object but not the workers, and glibc's
+        // pthread_cond_destroy waits for the waiters the copied condition variable still counts -- forever.  The process that made the pool
+        // stops its workers at exit (Stopper); a child leaves the copy alone.
+        static WorkerPool* pool = new WorkerPool;
+        static Stopper stopper { pool };
+        return *pool;
     }
     // fn(begin, end) on disjoint ranges covering [0, count); below `minPerThread` items per thread the caller does it alone
     void parallelFor(size_t count, size_t minPerThread, const std::function<void(size_t, size_t)>& fn)
@@ -61,13 +65,16 @@ private:
         for (unsigned i = 0; i < n; i++)
             m_threads.emplace_back([this, i] { run(i + 1); });
     }
+    struct Stopper {
+        WorkerPool* pool;
+        ~Stopper()
+        {
+            if (getpid() == pool->m_pid)
+                delete pool;
+        }
+    };
     ~WorkerPool()
     {
-        if (getpid() != m_pid) { // a forked child: there is nothing to join
-            for (std::thread& t : m_threads)
-                t.detach();
-            return;
-        }
         {
             std::lock_guard<std::mutex> lock(m_mutex);
             m_quit = true;

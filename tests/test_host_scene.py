@@ -2,6 +2,7 @@
 src/bvh/bvh_test.cpp:117-139, as real tests), top-level BVH, flattening with index rebasing
 (src/raytracer.cpp:244-270) and camera derivation (src/camera.cpp:18-58)."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -73,7 +74,8 @@ def test_the_worker_pool_builds_the_sequential_builders_arrays(builder, monkeypa
 
 
 def test_a_forked_child_builds_without_the_parents_worker_threads():
-    """fork() copies the calling thread only: a child of a process whose worker pool has started must not wait for workers that are not there."""
+    """fork() copies the calling thread only: a child of a process whose worker pool has started must not wait for workers that are not there --
+    neither in its loops nor at exit (glibc's pthread_cond_destroy waits for the waiters a copied condition variable still counts)."""
     v, f = scenes.icosphere(5)
     p = (v * 0.5).astype(np.float32)
     f = f.astype(np.uint32)
@@ -83,9 +85,13 @@ def test_a_forked_child_builds_without_the_parents_worker_threads():
     if pid == 0:
         try:
             there = H.Mesh(p, f, mat, builder=H.BVH_BINNED_FAST).bvh()
-            os._exit(0 if all(a.tobytes() == b.tobytes() for a, b in zip(here, there)) else 3)
+            same = all(a.tobytes() == b.tobytes() for a, b in zip(here, there))
         except BaseException:
             os._exit(4)
+        sys.stdout.flush()
+        os.closerange(0, 3)  # (pytest's capture files: not this process's to flush)
+        import ctypes
+        ctypes.CDLL(None).exit(0 if same else 3)  # exit(3) of the C library: the host library's static destructors run -- they must not wait for the workers either
     for _ in range(600):  # (a deadlocked child would hang the suite: poll with a deadline)
         done, status = os.waitpid(pid, os.WNOHANG)
         if done:
