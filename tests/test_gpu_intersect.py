@@ -94,6 +94,30 @@ def test_random_rays_two_level(gpu, builder, mode, rotate):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["baked", "two_level"])
+def test_a_launch_of_between_one_and_two_rays_per_lane(gpu, kind):
+    """A launch of 1-2 rays per lane: every wave of the per-ray kernels takes its static packet of 64, the rest comes from the shared cursor in spans
+    (pt_trace.h, requestPacket).  600 000 rays in one launch (459 k lanes) must find what the same rays find in two launches of 300 000 (static
+    packets only), closest hit and any hit, ray for ray; and so must the ragged sizes around the boundaries of the static part."""
+    b = scenes.instanced_grid(64, 36, level=4, sky_size=(16, 8))
+    ctx = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_TWO_LEVEL_ONLY if kind == "two_level" else 0)
+    lanes = 256 * 4 * 7 * 64  # the persistent grid of the per-ray kernels on an MI355X
+    for n in (600_000, lanes + 1, 2 * lanes, 2 * lanes + 64 + 5):
+        o, d = U.random_rays(n, 11, (-4, 0.05, -4), (4, 3, 4))
+        tmax = np.random.default_rng(2).uniform(0.05, 4, n).astype(np.float32)
+        h = n // 2
+        for any_hit in (False, True):
+            kw = dict(any_hit=True) if any_hit else {}
+            whole = ctx.intersect(o, d, tmax=tmax if any_hit else None, **kw)
+            parts = [ctx.intersect(o[s], d[s], tmax=tmax[s] if any_hit else None, **kw) for s in (slice(0, h), slice(h, n))]
+            for k in ("prim", "inst") if not any_hit else ("prim",):
+                assert np.array_equal(whole[k], np.concatenate([q[k] for q in parts])), (n, any_hit, k)
+            if not any_hit:
+                assert np.array_equal(whole["t"].view(np.uint32), np.concatenate([q["t"] for q in parts]).view(np.uint32))
+                assert 0.2 < (whole["prim"] >= 0).mean() < 1.0
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode", ["baked", "packet"])
 def test_edge_cases(gpu, mode):
     """empty queue tail / ragged sizes, axis-parallel rays (zero components), origins exactly on box faces
