@@ -261,7 +261,7 @@ struct pt_ctx {
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
     uint32_t teamRounds = 2; // ... used where the previous batch's pass held at most this many rays per team
-    uint32_t teamUse = 3; // bit 0: the camera rays of 1-spp frames, bit 1: later passes by the previous batch's counters (PTAMD_TEAM_USE: diagnostics)
+    uint32_t teamUse = 7; // bit 0: the camera rays of 1-spp frames, bit 2: their shadow rays, bit 1: later passes by the previous batch's counters (PTAMD_TEAM_USE: diagnostics)
     uint32_t batchEntries = 0; // entries of the batch being enqueued (renderSampleFixed)
     uint64_t teamLaunches = 0;
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
@@ -1253,7 +1253,7 @@ inline int sceneKind(const pt_ctx* c)
 // Is this launch small enough for four lanes per ray (pt_team.h)?  Known only as a hint -- the live count is a device word --: what the same pass of
 // the previous batch of the same size held (its counters come back through pinned memory, renderSampleFixed); shadow rays of pass b are at most the
 // extension rays of pass b.  Scenes that are one world-space tree whose depth-first stack need fits the team's stack; never in parity mode.
-bool teamLaunch(const pt_ctx* c, uint32_t pass)
+bool teamLaunch(const pt_ctx* c, uint32_t pass, bool anyHit = false)
 {
     if (!c->teamRounds || !c->teamBlocks || parityMode(c) || c->dyn[c->active].hasInstances || c->dyn[c->active].stackNeed > kTeamStackNeedMax)
         return false;
@@ -1263,7 +1263,7 @@ bool teamLaunch(const pt_ctx* c, uint32_t pass)
         return false;
     // the camera rays of a 1-spp frame (no bundles there: too few samples of a pixel): coherent rays, few leaves per ray -- four lanes per ray walk them
     // faster than one however many there are (1280 x 720: 190 instead of 263 us, profiles/round5/r5l_frame_trace_team.txt)
-    if (pass == 0u && c->planes == 1u && c->batchEntries <= (4u << 20) && (c->teamUse & 1u))
+    if (pass == 0u && c->planes == 1u && c->batchEntries <= (4u << 20) && (c->teamUse & (anyHit ? 4u : 1u)))
         return true;
     if (c->passCountsEntries != c->batchEntries || !(c->teamUse & 2u))
         return false;
@@ -1273,7 +1273,7 @@ bool teamLaunch(const pt_ctx* c, uint32_t pass)
 
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stream = nullptr)
 {
-    if (teamLaunch(c, args.pass) && !args.start) {
+    if (teamLaunch(c, args.pass, anyHit) && !args.start) {
         c->teamLaunches++;
         if (anyHit)
             hipLaunchKernelGGL(k_trace_team<true>, dim3(c->teamBlocks), dim3(kTeamBlock), 0, stream ? stream : c->stream, args);
