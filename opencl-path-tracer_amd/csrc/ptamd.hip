@@ -2872,7 +2872,10 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     // (+ 1: the SMALL traversal instantiations fetch 96 bytes from wherever a lane stands -- 32 beyond a node, 48 beyond a one-triangle leaf)
     const size_t needWide = staticNodes + h.topSlots + h.bakedNodes + h.instRoots.size() + 1, needTris = staticTris + h.bakedTris + 1;
     // the traversal kernels address nodes and triangle records by base + 32-bit byte offset (pt_trace.h, PT_OFFSET32)
-    if (needWide * sizeof(WideNode) > 0xFFFFFFFFull || needTris * sizeof(TriIsect) > 0xFFFFFFFFull)
+    uint64_t offsetLimit = 0xFFFFFFFFull;
+    if (const char* e = getenv("PTAMD_OFFSET_LIMIT")) // (tests: the refusal below without a 4 GB scene)
+        offsetLimit = std::min<uint64_t>(offsetLimit, strtoull(e, nullptr, 10));
+    if (needWide * sizeof(WideNode) > offsetLimit || needTris * sizeof(TriIsect) > offsetLimit)
         return fail(c, PT_ERR_UNSUPPORTED, "scene of %zu packed nodes and %zu triangle records (world-space copies included): more than 4 GB of either; enter the instances instead (PT_FLAG_NO_BAKED_INSTANCES)",
             needWide, needTris);
     const size_t bytes[7] = { h.topWide.size() * sizeof(WideNode), h.instances.size() * sizeof(Instance), h.lights.size() * sizeof(Light),

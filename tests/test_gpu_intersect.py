@@ -392,6 +392,20 @@ def test_translated_and_scaled_instances_around_the_fold_table(gpu, n):
     ctx.close()
 
 
+def test_a_scene_beyond_the_32_bit_offsets_is_refused(gpu, monkeypatch):
+    """The traversal kernels address nodes and triangle records by base + 32-bit byte offset: a dynamic state whose node or triangle array (world-space
+    copies included) would pass 4 GB is refused with a message that names the way out, not traversed with wrapped offsets.  (The limit is lowered
+    through PTAMD_OFFSET_LIMIT here; entering the instances instead of copying them fits again.)"""
+    b = scenes.instanced_grid(64, 36, level=4, sky_size=(16, 8))
+    monkeypatch.setenv("PTAMD_OFFSET_LIMIT", str(2 << 20))  # 2 MB: the 12 world-space copies of the 5 120-triangle meshes need ~3 MB of triangle records
+    with pytest.raises(RuntimeError, match="more than 4 GB|PT_FLAG_NO_BAKED_INSTANCES"):
+        U.make_ctx(gpu, b, 64, 36)
+    ctx = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_NO_BAKED_INSTANCES)  # nothing copied: 2 x 5 120 triangles
+    o, d = U.random_rays(2000, 3, (-4, 0.05, -4), (4, 3, 4))
+    assert (ctx.intersect(o, d)["prim"] >= 0).mean() > 0.2
+    ctx.close()
+
+
 def test_invalid_scenes_are_rejected_not_traversed(gpu):
     b = scenes.cornell_box(16, 16)
     f = b.flat
