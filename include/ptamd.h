@@ -221,7 +221,10 @@ int pt_upload_static_async(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts
  * is double-buffered on the device.  pt_upload_dynamic_async converts the next state on the host ("Lot of CPU work", :185) and
  * copies it into the INACTIVE buffers on a copy stream of its own -- the GPU keeps rendering the active state meanwhile, nothing
  * waits on the host; pt_frame_tick makes the render stream wait for that copy (the barrier of :593) and flips m_activeBuffer.
- * pt_upload_dynamic is the two in a row. */
+ * pt_upload_dynamic is the two in a row.
+ * Limits (PT_ERR_UNSUPPORTED, with the way out in pt_last_error): the packed nodes and the triangle records of a state -- the world-space copies
+ * of instances included -- are addressed by 32-bit byte offsets on the device: at most 4 GB of either (64 M nodes, 89 M triangle records); a
+ * scene whose copies would pass that, or the library's 2 GB copy budget, is traversed with its instances entered (PT_FLAG_NO_BAKED_INSTANCES). */
 int pt_upload_dynamic_async(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t n_lights,
     const pt_top_bvh_node* top_nodes, uint32_t n_top, uint32_t top_root);
 int pt_frame_tick(pt_ctx* ctx);
