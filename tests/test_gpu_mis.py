@@ -102,3 +102,24 @@ def test_weighted_light_choice_matches_oracle(gpu):
         ref, cnt = O.render(U.oracle_scene(b), b.camera, W, Hh, 16, seed=7, threads=8, integrator=integrator, light_sampling=O.LIGHTS_SOLID_ANGLE)
         # the walk over the light weights ends on a float comparison per light: a few more round-off flips than elsewhere
         _gates(a, ref[:, :3], st, cnt, 16, b.camera, close_frac=0.95)
+
+
+@pytest.mark.parametrize("flag", ["FLAG_INTEGRATOR_MIS", "FLAG_COMPARE_SHADING", "FLAG_SOLID_ANGLE_LIGHTS"])
+def test_batches_through_the_bundle_kernel_shade_like_queued_camera_rays(gpu, flag):
+    """64 samples in flight: the camera rays go through k_trace_multi, which queues (direction, pixel) only -- the general shading kernel (MIS,
+    COMPARE_SHADING's remapped pixels, the weighted light sampler) then takes the eye as origin and the sample from the queue index (round 5).
+    Same paths as with k_gen's full ray records and the per-ray kernel: the same ray counts, images equal but for the order of a pixel's sums."""
+    b = scenes.instanced_grid(W, Hh, level=3, sky_size=(64, 32))
+    fl = getattr(gpu, flag)
+    imgs, stats = [], []
+    for extra in (0, gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS):
+        ctx = U.make_ctx(gpu, b, W, Hh, seed=11, samples_in_flight=64, flags=fl | extra)
+        ctx.render(128)
+        imgs.append(ctx.read_accum()[:, :3].copy())
+        stats.append(ctx.stats())
+        ctx.close()
+    assert stats[0]["bundle_launches"] > 0 and stats[1]["packet_launches"] == 0
+    for k in ("rays_generated", "rays_extension", "rays_shadow", "shade_hits"):
+        assert abs(stats[0][k] - stats[1][k]) <= 2e-4 * stats[1][k], (k, stats[0][k], stats[1][k])  # (exact-t ties between the two camera-ray kernels)
+    close = np.isclose(imgs[0], imgs[1], rtol=1e-4, atol=1e-4 * imgs[1].max()).all(axis=1)
+    assert close.mean() > 0.999, close.mean()
