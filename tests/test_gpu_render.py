@@ -288,6 +288,16 @@ def test_material_ordered_shading_traces_the_same_paths(gpu, pattern):
     assert close.mean() > 0.97, close.mean()
     binned.close()
     plain.close()
+    # ... and with 32 samples of a pixel next to each other in the queue: the camera rays come from the bundle kernel as (direction, pixel), the sample
+    # of an entry from its queue index -- which the material-ordered kernel permutes inside a tile before it shades
+    binned = U.make_ctx(gpu, b, W, Hh, seed=4, samples_in_flight=32, flags=gpu.FLAG_MATERIAL_BINS)
+    plain = U.make_ctx(gpu, b, W, Hh, seed=4, samples_in_flight=32)
+    binned.render(32)
+    plain.render(32)
+    assert binned.stats()["bundle_launches"] > 0 and plain.stats()["bundle_launches"] > 0
+    assert np.array_equal(binned.read_accum()[:, :3], plain.read_accum()[:, :3])
+    binned.close()
+    plain.close()
 
 
 def test_clear_accumulate_and_spp_bookkeeping(gpu):
