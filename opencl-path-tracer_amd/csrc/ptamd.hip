@@ -1409,6 +1409,9 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #ifndef PT_SHADE_SPLIT
 #define PT_SHADE_SPLIT 1
 #endif
+#ifndef PT_LAST_SHADOW_ON_MAIN
+#define PT_LAST_SHADOW_ON_MAIN 1
+#endif
 #ifndef PT_DERIVED_PRIMARIES
 #define PT_DERIVED_PRIMARIES 1
 #endif
@@ -1676,7 +1679,11 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             prof.end();
         }
         prof.begin(3);
-        if (overlap) {
+        if (overlap && b + 1u == bounces && PT_LAST_SHADOW_ON_MAIN) {
+            // the last bounce's shadow rays have no extension pass to run beside: on the render stream itself, behind their shade launch -- the wait for a
+            // side stream's event that has only just fired was a 17 us hole in front of k_end_sample in every frame's trace
+            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr);
+        } else if (overlap) {
             // (with a plane and a queue per bounce the shadow passes depend on nothing but their own shade launch: two side streams take them in turn, so
             // that the pass of bounce b does not queue behind the longer one of bounce b - 1 -- the side stream had become a frame's critical path)
             hipStream_t side = split && (b & 1u) ? c->sideStream2 : c->sideStream;
@@ -1690,7 +1697,13 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
         prof.end();
         std::swap(in, out);
     }
-    if (overlap) {
+    if (overlap && PT_LAST_SHADOW_ON_MAIN) { // the side streams' last passes (long done, as a rule)
+        if (split && bounces > 1)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 2], 0));
+        if (split && bounces > 2)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 3], 0));
+        // (one accumulator: the shade launch of the last bounce has waited for the shadow rays of the bounce before it already)
+    } else if (overlap) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 1], 0));
         if (split && bounces > 1)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[bounces - 2], 0)); // the other side stream's last pass
