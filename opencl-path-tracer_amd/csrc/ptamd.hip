@@ -260,7 +260,7 @@ struct pt_ctx {
     uint64_t descentLaunches = 0;
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
-    uint32_t teamRounds = 2; // ... used where the previous batch's pass held at most this many rays per team
+    float teamRounds = 1.5f; // (1 / 1.5 / 1.7 / 2 / 3 measured on four scenes, tools/r5_frames_env.sh) ... used where the previous batch's pass held at most this many rays per team
     uint32_t teamUse = 7; // bit 0: the camera rays of 1-spp frames, bit 2: their shadow rays, bit 1: later passes by the previous batch's counters (PTAMD_TEAM_USE: diagnostics)
     uint32_t batchEntries = 0; // entries of the batch being enqueued (renderSampleFixed)
     uint64_t teamLaunches = 0;
@@ -1234,7 +1234,7 @@ int ensureSpill(pt_ctx* c)
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&t1, (const void*)k_trace_team<true>, kTeamBlock, 0));
         c->teamBlocks = (uint32_t)(std::max(1, std::min(t0, t1)) * c->numCUs);
         if (const char* e = getenv("PTAMD_TEAM_ROUNDS")) // diagnostics: 0 = never use the team kernel
-            c->teamRounds = (uint32_t)std::max(0, atoi(e));
+            c->teamRounds = std::max(0.f, (float)atof(e));
         if (const char* e = getenv("PTAMD_TEAM_USE"))
             c->teamUse = (uint32_t)atoi(e);
     }
@@ -1255,7 +1255,7 @@ inline int sceneKind(const pt_ctx* c)
 // extension rays of pass b.  Scenes that are one world-space tree whose depth-first stack need fits the team's stack; never in parity mode.
 bool teamLaunch(const pt_ctx* c, uint32_t pass, bool anyHit = false)
 {
-    if (!c->teamRounds || !c->teamBlocks || parityMode(c) || c->dyn[c->active].hasInstances || c->dyn[c->active].stackNeed > kTeamStackNeedMax)
+    if (!(c->teamRounds > 0.f) || !c->teamBlocks || parityMode(c) || c->dyn[c->active].hasInstances || c->dyn[c->active].stackNeed > kTeamStackNeedMax)
         return false;
     if (c->cfg.flags & PT_FLAG_TEAM_INTERSECT)
         return true; // the pt_intersect hook (tests)
@@ -1268,7 +1268,7 @@ bool teamLaunch(const pt_ctx* c, uint32_t pass, bool anyHit = false)
     if (c->passCountsEntries != c->batchEntries || !(c->teamUse & 2u))
         return false;
     const uint64_t teams = (uint64_t)c->teamBlocks * (kTeamBlock / 4);
-    return (uint64_t)c->passCountsHint[pass] <= teams * c->teamRounds;
+    return (double)c->passCountsHint[pass] <= (double)teams * c->teamRounds;
 }
 
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stream = nullptr)
