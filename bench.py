@@ -311,8 +311,7 @@ def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=
                "packet_kernel_for_primary_rays": ps["packet_launches"] > 0, "scene_upload_s": round(upload_s, 3),
                "kernel_ms_per_step": {"gen": round(ps["ms_gen"], 2), "closest_hit": round(ps["ms_intersect"], 2),
                                       "of_which_packet": round(ps["ms_packet"], 2), "shade": round(ps["ms_shade"], 2),
-                                      "any_hit": round(ps["ms_shadow"], 2),
-                                      "of_which_shared_descent": round(ps["ms_descend"], 2)},
+                                      "any_hit": round(ps["ms_shadow"], 2)},
                "shade_ns_per_entry": round(ps["ms_shade"] * 1e6 / max(ps["shade_hits"], 1), 3),
                "mrays_per_s_profiled_step": round(pr / max(ps["ms_last_render"], 1e-6) / 1e3, 1)}
         return out

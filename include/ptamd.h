@@ -149,10 +149,7 @@ typedef struct {
                                      divergent BSDF code: DESIGN.md section 6 -- hence opt-in) */
 #define PT_FLAG_QUEUE_PRIMARY_RAYS 256u /* always write the primary rays to the queue (k_gen), also where the packet kernel could
                                           regenerate them from the entry index (diagnostics; the image is the same) */
-#define PT_FLAG_SHARED_DESCENT 1024u /* the rays that leave the primary hits (their shadow rays, the first bounce's extension rays) walk from the root to their
-                                        origin together, packet by packet, ahead of the per-ray traversal (pt_descend.h; measured no faster on MI355X --
-                                        DESIGN.md section 6 -- hence opt-in; the image differs at most in exact-t ties) */
-#define PT_FLAG_DESCENT_INTERSECT 2048u /* pt_intersect (test hook): packets of 64 consecutive rays take the shared descent, then the per-ray kernel */
+/* 1024u, 2048u: retired (rounds 4-5: an opt-in shared descent ahead of the per-ray traversal, measured no faster; EXPERIMENTS.md) -- ignored */
 #define PT_FLAG_PARKED_INSTANCES 4096u /* every instance that is entered takes the general route (ray transformed into the instance's space, lane parked for entry and exit:
                                          rounds 2-4).  Default since round 5: instances whose transform is a translation + uniform scale are walked by the per-ray
                                          kernels without parking (entry nodes, the ray taken into the instance's space on the fly; csrc/pt_trace.h); rotated /
@@ -185,8 +182,6 @@ typedef struct {
                                  kernel.cl:132-135); the rest are emissive hits and sky misses in shade */
     uint64_t gen_launches; /* launches of the primary-ray kernel (generatePrimaryRays); 0 where the packet traversal kernel generates the camera rays itself */
     uint64_t bundle_launches; /* of packet_launches: those that walked the tree once per bundle of several packets (camera rays of a pinhole, generated in the kernel) */
-    uint64_t descent_launches; /* launches of the shared-descent kernel (rays that leave one pixel's footprint walk from the root to their origin together) */
-    double ms_descend; /* its device ms in the last pt_render (already counted in ms_shadow / ms_intersect) */
     uint32_t stack_need; /* worst-case traversal stack entries of the active scene state (packet kernels need <= 64) */
     uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk without parking (translation + uniform scale, not copied to world space) */
     uint64_t team_launches; /* traversal launches served by the team kernel (four lanes per ray: launches that do not fill the machine, csrc/pt_team.h) */

@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
         if (__ballot(active) == 0ull)
             break; // no team of the wave has a ray, and none is left for any of them
         // ---- pop: member m takes entry sp - 1 - m (breadth), or member 0 alone the top (depth first) ---------------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int take = active ? min(sp, sp > kTeamDfsAbove ? 1 : 4) : 0;
         const bool mine = (int)m < take;
         const uint32_t cur = mine ? ldsStack[wave][sp - 1 - (int)m][team] : kRefFinish;
@@ -196,6 +197,10 @@ __global__ void __launch_bounds__(kTeamBlock, PT_TEAM_MIN_WAVES) k_trace_team(Tr
                     ldsStack[wave][at + (int)nPush - 1 - k][team] = ref[k]; // ref[0] = the nearest: on top of this member's run
         }
         sp += (int)total;
+        // the pushes above are read by OTHER lanes of the team at the next pop: a wave-level release fence + barrier here, an acquire fence at the pop (no
+        // instruction on a wave -- LDS operations of one wave complete in order -- but the compiler may no longer cache or move the accesses across the back-edge)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- done?  (any hit: an occluder ends the ray at once) ----------------------------------------------------------------------------------
         if (active && (sp == 0 || teamOccluded)) {
             if (ANY_HIT) {

@@ -80,8 +80,6 @@ constexpr int kTraversalStackMax = (kLdsStackTL < kLdsStack ? kLdsStackTL : kLds
 constexpr uint32_t kInstFoldTable = 96; // entries of the per-workgroup table of folded instance transforms (entry 0: the identity): scenes of up to 95 instances.  (20 B
                                         // each beside 20.5 KB of stacks and staged rays: 7 workgroups per CU must stay within 160 KB -- at 128 entries the any-hit
                                         // instantiation's 23 056 B round up past a seventh of it and the kernel runs at 6 waves per SIMD: 89.1 -> 94.6 ms per batch)
-constexpr int kDescentStack = 3; // entries of a START stack (pt_descend.h: rays that leave one pixel's footprint take the way from the root to their origin together)
-static_assert(kDescentStack <= kLdsStack, "the hand-out copies a start stack into the LDS part of the lane's stack");
 constexpr int kSpillStack = 100; // further entries in global memory
 constexpr int kTraceBlock = 256;
 #ifndef PT_PARKED_BREAK_ANY
@@ -130,9 +128,6 @@ struct TraceArgs {
     // route), entry 0 = the identity; instFoldCount 0: nothing is folded (more instances than the table holds, parity mode, PT_FLAG_PARKED_INSTANCES)
     const float4* instFold;
     uint32_t instFoldCount;
-    // k_trace<., ., true>: the start state of every queue entry, made by k_descend (pt_descend.h): x = the reference to continue with,
-    // y z w = up to three stacked entries in stack order (kRefNone: unused)
-    const uint4* start;
 };
 
 #ifdef PT_TRACE_STATS
@@ -252,9 +247,7 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 #ifndef PT_TRACE_MIN_WAVES_TL
 #define PT_TRACE_MIN_WAVES_TL 7
 #endif
-// DESCENT: rays do not start at the root but where k_descend (pt_descend.h) left them -- a reference and up to kDescentStack stacked
-// entries per queue slot, taken at the hand-out; everything else is the same kernel.
-template <bool ANY_HIT, bool TWO_LEVEL, bool DESCENT = false>
+template <bool ANY_HIT, bool TWO_LEVEL>
 __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
 {
     constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
@@ -444,12 +437,6 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                             hu = hv = 0.f;
                             cur = sc.rootRef;
                             sp = 0;
-                            if constexpr (DESCENT) { // the way from the root to the ray's origin has been walked already (pt_descend.h)
-                                const uint4 ss = a.start[idx];
-                                cur = ss.x;
-                                sp = (ss.y != kRefNone ? 1 : 0) + (ss.z != kRefNone ? 1 : 0) + (ss.w != kRefNone ? 1 : 0);
-                                ldsStack[wave][0][lane] = ss.y, ldsStack[wave][1][lane] = ss.z, ldsStack[wave][2][lane] = ss.w; // (beyond sp: never read)
-                            }
                             active = true;
                         }
                     }

@@ -8,7 +8,6 @@
 #include "pt_packet.h"
 #include "pt_packet_multi.h"
 #include "pt_bake.h"
-#include "pt_descend.h"
 #include "pt_team.h"
 #ifndef PT_PACK_WIDE
 #define PT_PACK_WIDE 1
@@ -252,12 +251,6 @@ struct pt_ctx {
     DevBuf<Totals> totals;
     DevBuf<uint32_t> spill;
     size_t spillHalf = 0;
-    // shared descent (pt_descend.h): start states of one queue (the shadow rays of the primary hits, then the first bounce's extension rays).
-    // bit 0: shadow rays of pass 0, bit 1: extension rays of pass 1, bit 2: the pt_intersect test hook
-    DevBuf<uint4> startState;
-    uint32_t descentUse = 0;
-    uint32_t descendBlocks = 0;
-    uint64_t descentLaunches = 0;
     uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
     uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
     float teamRounds = 1.5f; // (1 / 1.5 / 1.7 / 2 / 3 measured on four scenes, tools/r5_frames_env.sh) ... used where the previous batch's pass held at most this many rays per team
@@ -267,7 +260,7 @@ struct pt_ctx {
     uint32_t foldPlanes = 0; // extra accumulator planes written since the last fold (folded at the end of pt_render)
     bool queuesReady = false;
 
-    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0, msDescend = 0;
+    double msLastRender = 0, msIntersect = 0, msShade = 0, msShadow = 0, msGen = 0, msPacket = 0;
 };
 
 namespace {
@@ -1111,16 +1104,12 @@ int ensureQueues(pt_ctx* c)
             q.o.release(), q.d.release(), q.c.release();
         c->stagedRays.o.release(), c->stagedRays.d.release(), c->stagedRays.thr.release();
         c->stagedShadow.o.release(), c->stagedShadow.d.release(), c->stagedShadow.c.release(), c->activeFlag.release();
-        c->startState.release();
         c->foldPlanes = 0;
         // Memory budget, checked before anything is allocated so that an oversized configuration fails HERE with a
         // message instead of somewhere in a later hipMalloc: per queue entry two extension queues (3 x 16 B each), the
         // shadow queue (3 x 16 B) and the hit records (20 B); per owned pixel one 16-byte accumulator plane for every
         // extra sample in flight.  (BASELINE config 5 -- 4K, 8 ranks -- at 2 048 samples in flight would be 2.1 G entries.)
-        // ... and, where the shared descent serves the first bounce (>= 16 samples of a pixel next to each other in the queue), a start state
-        // per entry: one 16-byte record
-        const bool descent = (c->descentUse & 3u) != 0u && c->planes >= 16u;
-        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0) + (descent ? sizeof(uint4) : 0);
+        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0);
         // one sample in flight and a small queue (the 1-spp frames of RayTracer::rayTrace): the shadow rays' own accumulator (16 B per pixel of the
         // image) and a shadow queue per bounce (48 B per entry and bounce), renderSampleFixed -- set aside HERE, not in the first frame
         const bool split = splitShadowAccum(c, cap);
@@ -1150,8 +1139,6 @@ int ensureQueues(pt_ctx* c)
     HIPCHK(c, c->shadow.c.alloc(cap));
     HIPCHK(c, c->hitH.alloc(cap));
     HIPCHK(c, c->hitInst.alloc(cap));
-    if ((c->descentUse & 3u) != 0u && c->planes >= 16u)
-        HIPCHK(c, c->startState.alloc(cap));
     if (parityMode(c)) {
         HIPCHK(c, c->stagedRays.o.alloc(cap));
         HIPCHK(c, c->stagedRays.d.alloc(cap));
@@ -1188,8 +1175,7 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     // persistent grids sized to the machine, per instantiation pair ([0]: scenes that are one world-space tree, [1]: scenes with
     // instance references -- pt_trace.h, TWO_LEVEL)
-    const void* variants[2][4] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false>, (const void*)k_trace<false, false, true>, (const void*)k_trace<true, false, true> },
-        { (const void*)k_trace<false, true>, (const void*)k_trace<true, true>, (const void*)k_trace<false, true, true>, (const void*)k_trace<true, true, true> } };
+    const void* variants[2][2] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false> }, { (const void*)k_trace<false, true>, (const void*)k_trace<true, true> } };
     const void* packetVariants[2][2] = { { (const void*)k_trace_packet<false, false>, (const void*)k_trace_packet<true, false> },
         { (const void*)k_trace_packet<false, true>, (const void*)k_trace_packet<true, true> } };
     for (int tl = 0; tl < 2; tl++) {
@@ -1223,10 +1209,6 @@ int ensureSpill(pt_ctx* c)
         if (const char* e = getenv("PTAMD_PACKET_BLOCKS_PER_CU")) // the documented knob reaches the bundle kernel too
             for (uint32_t& mb : c->multiBlocks)
                 mb = std::max(1u, std::min(mb, (uint32_t)std::max(1, atoi(e)) * (uint32_t)c->numCUs));
-        int d0 = 0, d1 = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&d0, (const void*)k_descend<false>, kDescendBlock, 0));
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&d1, (const void*)k_descend<true>, kDescendBlock, 0));
-        c->descendBlocks = (uint32_t)(std::max(1, std::min(d0, d1)) * c->numCUs);
     }
     {
         int t0 = 0, t1 = 0;
@@ -1273,7 +1255,7 @@ bool teamLaunch(const pt_ctx* c, uint32_t pass, bool anyHit = false)
 
 void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stream = nullptr)
 {
-    if (teamLaunch(c, args.pass, anyHit) && !args.start) {
+    if (teamLaunch(c, args.pass, anyHit)) {
         c->teamLaunches++;
         if (anyHit)
             hipLaunchKernelGGL(k_trace_team<true>, dim3(c->teamBlocks), dim3(kTeamBlock), 0, stream ? stream : c->stream, args);
@@ -1284,27 +1266,13 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stre
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
     TraceArgs a = args;
-    if (twoLevel) { // the per-ray kernels walk the top level in which folded instances are plain inner references (the packet kernels and k_descend: the one with instance references)
+    if (twoLevel) { // the per-ray kernels walk the top level in which folded instances are plain inner references (the packet kernels: the one with instance references)
         a.sc.rootRef = c->dyn[c->active].rootRefFolded;
         a.instFold = c->dyn[c->active].instFold.p, a.instFoldCount = c->dyn[c->active].instFoldCount;
     }
     const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
     if (!stream)
         stream = c->stream;
-    if (a.start) { // the rays start where k_descend left them (pt_descend.h)
-        if (anyHit) {
-            if (twoLevel)
-                hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, stream, a);
-            else
-                hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, stream, a);
-        } else {
-            if (twoLevel)
-                hipLaunchKernelGGL((k_trace<false, true, true>), grid, block, 0, stream, a);
-            else
-                hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, stream, a);
-        }
-        return;
-    }
     if (anyHit) {
         if (twoLevel)
             hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
@@ -1326,19 +1294,6 @@ TraceArgs traceArgsBase(pt_ctx* c)
     a.totalThreads = c->traceBlocks[sceneKind(c)] * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
     return a;
-}
-
-// the way from the root to the rays' origins, taken once per packet of 64 consecutive queue entries (pt_descend.h); `count` = the queue's device word
-void launchDescend(pt_ctx* c, bool anyHit, const float4* rayO, const float4* rayD, const uint32_t* count, uint4* start, hipStream_t stream = nullptr)
-{
-    DescendArgs d {};
-    d.sc = c->scene;
-    d.rayO = rayO, d.rayD = rayD, d.count = count, d.start = start;
-    c->descentLaunches++;
-    if (anyHit)
-        hipLaunchKernelGGL(k_descend<true>, dim3(c->descendBlocks), dim3(kDescendBlock), 0, stream ? stream : c->stream, d);
-    else
-        hipLaunchKernelGGL(k_descend<false>, dim3(c->descendBlocks), dim3(kDescendBlock), 0, stream ? stream : c->stream, d);
 }
 
 FrameParams frameParams(const pt_ctx* c, uint32_t sample)
@@ -1422,10 +1377,6 @@ void launchGen(pt_ctx* c, const FrameParams& fp, int q, uint32_t first, uint32_t
 #define PT_PACKET_USE 1 // primary rays only: shadow rays towards random light points are not coherent enough (2.6x slower)
 #endif
 constexpr uint32_t kPacketUseDefault = PT_PACKET_USE;
-#ifndef PT_DESCENT_USE
-#define PT_DESCENT_USE 0 // bit 0: the shadow rays of the primary hits, bit 1: the first bounce's extension rays.  Off: measured no faster
-#endif
-constexpr uint32_t kDescentUseDefault = PT_DESCENT_USE;
 
 void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
 {
@@ -1452,12 +1403,10 @@ inline bool primaryBundles(const pt_ctx* c) { return PT_MULTI_RAYS > 1 && !c->ca
 inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
 
 // `coherent`: consecutive queue entries are samples of one pixel (first pass of the fixed schedule)
-void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr, bool descent = false, bool noOrigins = false)
+void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, const FrameParams* fused = nullptr, bool noOrigins = false)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
-    if (descent) // the caller has launched k_descend on this queue
-        a.start = c->startState.p;
     if (fused) {
         a.fused = 1u;
         a.fp = *fused;
@@ -1489,12 +1438,10 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
 }
 
 // `own`: the pass's own shadow queue and the shadow rays' own accumulator (one sample in flight, renderSampleFixed)
-void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr, const ShadowQueueBuf* own = nullptr, bool descent = false)
+void launchShadow(pt_ctx* c, uint32_t pass, bool coherent = false, hipStream_t side = nullptr, const ShadowQueueBuf* own = nullptr)
 {
     Control* ctl = c->control.p;
     TraceArgs a = traceArgsBase(c);
-    if (descent) // the caller has launched k_descend on this queue
-        a.start = c->startState.p;
     if (side) // runs beside the closest-hit traversal of the next bounce (and, with two side streams, beside another shadow pass): a spill region of its own
         a.spill = c->spill.p + c->spillHalf * (side == c->sideStream2 ? 2u : 1u);
     const ShadowQueueBuf& q = own ? *own : c->shadow;
@@ -1650,35 +1597,19 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             return fail(c, PT_ERR_STATE, "the buffers of the one-sample-in-flight schedule are missing");
         c->mergePending = true;
     }
-    // Shared descent (pt_descend.h) for the rays that leave the primary hits -- their shadow rays (pass 0) and the first bounce's extension rays
-    // (pass 1): with >= 16 samples of a pixel next to each other in the first queue, k_shade's compaction (order kept inside a 512-entry
-    // tile) leaves the 64 consecutive entries of a packet within a pixel's footprint of each other.  Large batches only: the small launches of
-    // an interactive frame are latency-bound, a kernel more in their chain costs more than it saves.
-    const bool descent = c->startState.p && fp.interleave >= 16u && !overlap && !split;
     int in = 0, out = 1;
     for (uint32_t b = 0; b < bounces; b++) {
-        const bool descentExt = descent && b == 1 && (c->descentUse & 2u), descentShadow = descent && b == 0 && (c->descentUse & 1u);
-        if (descentExt) {
-            prof.begin(6);
-            launchDescend(c, false, c->rays[in].o.p, c->rays[in].d.p, &c->control.p->extCount[b], c->startState.p);
-            prof.end();
-        }
         prof.begin(1);
         const bool coherent = b == 0 && coherentFirst;
         if (c->profile && coherent && c->dyn[c->active].packetOk && (c->packetUse & 1u))
             prof.marks.back().first = 4; // timed apart from the per-ray kernel (ms_packet)
-        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr, descentExt, derived && b == 0);
+        launchIntersect(c, in, b, coherent, fused && b == 0 ? &fp : nullptr, derived && b == 0);
         prof.end();
         if (overlap && !split && b > 0)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr, derived && b == 0);
         prof.end();
-        if (descentShadow) {
-            prof.begin(5);
-            launchDescend(c, true, c->shadow.o.p, c->shadow.d.p, &c->control.p->shadowCount[b], c->startState.p);
-            prof.end();
-        }
         prof.begin(3);
         if (overlap && b + 1u == bounces && PT_LAST_SHADOW_ON_MAIN) {
             // the last bounce's shadow rays have no extension pass to run beside: on the render stream itself, behind their shade launch -- the wait for a
@@ -1693,7 +1624,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             launchShadow(c, b, coherent, side, split ? &c->shadowQ[b] : nullptr);
             HIPCHK(c, hipEventRecord(c->evShadowed[b], side));
         } else {
-            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr, descentShadow);
+            launchShadow(c, b, coherent, nullptr, split ? &c->shadowQ[b] : nullptr);
         }
         prof.end();
         std::swap(in, out);
@@ -1809,17 +1740,6 @@ int pt_debug_trace_stats(unsigned long long* out, unsigned int n) // n <= 64 cou
 }
 #endif
 
-#ifdef PT_TRACE_STATS
-int pt_debug_descend_stats(unsigned long long* out, unsigned int n) // n <= 16 counters (pt_descend.h, g_descendStats); read and cleared
-{
-    n = std::min(n, 16u);
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_descendStats), sizeof(unsigned long long) * n) != hipSuccess)
-        return -1;
-    unsigned long long zero[16] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_descendStats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
-}
-#endif
-
 const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
 // Test hook, no device needed: the host side of quantiseWideNode (pt_bake.h) -- up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
@@ -1862,13 +1782,6 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
     c->packetUse = (cfg->flags & PT_FLAG_NO_PACKETS) ? 0u : kPacketUseDefault;
     if (cfg->flags & PT_FLAG_PACKET_INTERSECT)
         c->packetUse |= 4u;
-    c->descentUse = (cfg->flags & PT_FLAG_SHARED_DESCENT) ? 3u : kDescentUseDefault;
-    if (const char* de = getenv("PTAMD_DESCENT")) // diagnostics: which launches take the shared descent (bit 0 shadow rays of pass 0, bit 1 extension rays of pass 1)
-        c->descentUse = (uint32_t)atoi(de) & 3u;
-    if (parityMode(c))
-        c->descentUse = 0u; // parity mode follows the reference to the letter (and keeps finished entries in its queues)
-    if (cfg->flags & PT_FLAG_DESCENT_INTERSECT)
-        c->descentUse |= 4u;
     if (const char* hs = getenv("PTAMD_SHADE_HEAD_SHIFT"))
         c->shadeHeadShift = (uint32_t)std::max(0, atoi(hs));
     if (const char* pk = getenv("PTAMD_PACKET")) // diagnostics: which launches may use k_trace_packet (bit 0 primary, 1 shadow, 2 pt_intersect)
@@ -1942,7 +1855,6 @@ void pt_destroy(pt_ctx* c)
     if (c->sideStream2)
         (void)hipStreamSynchronize(c->sideStream2);
     c->accumShadow.release();
-    c->startState.release();
     for (ShadowQueueBuf& q : c->shadowQ)
         q.o.release(), q.d.release(), q.c.release();
     DevBuf<float4>* f4[] = { &c->accumOwn, &c->hitH, &c->rays[0].o, &c->rays[0].d, &c->rays[0].thr, &c->rays[1].o,
@@ -2290,6 +2202,8 @@ int pt_update_geometry(pt_ctx* c, const pt_vertex* verts, uint32_t nV, const pt_
             return PT_ERR_INVALID;
         if (!c->haveStatic)
             return fail(c, PT_ERR_STATE, "pt_update_geometry: call pt_upload_static first");
+        if (c->statPending >= 0) // (the caller's offsets and counts are those of the rebuilt scene already; the scene that still renders is the old one)
+            return fail(c, PT_ERR_STATE, "pt_update_geometry: a rebuilt scene (pt_upload_static_async) is waiting for pt_frame_tick: refit after the tick");
         if (!verts || !nodes || nV != c->st->numVerts || nN != c->st->numRefNodes)
             return fail(c, PT_ERR_INVALID, "pt_update_geometry: the vertex and node counts must be the uploaded ones (%u, %u)", c->st->numVerts, c->st->numRefNodes);
         for (uint32_t i = 0; i < nN; i++)
@@ -2419,6 +2333,8 @@ int pt_refit_vertices(pt_ctx* c, uint32_t firstVertex, const pt_vertex* verts, u
             return PT_ERR_INVALID;
         if (!c->haveStatic)
             return fail(c, PT_ERR_STATE, "pt_refit_vertices: call pt_upload_static first");
+        if (c->statPending >= 0) // (a refit between a rebuild and its tick addressed the OLD scene with the NEW scene's offsets)
+            return fail(c, PT_ERR_STATE, "pt_refit_vertices: a rebuilt scene (pt_upload_static_async) is waiting for pt_frame_tick: refit after the tick");
         if (!verts || nV == 0 || (uint64_t)firstVertex + nV > c->st->numVerts)
             return fail(c, PT_ERR_INVALID, "pt_refit_vertices: [%u, %u + %u) is not a range of the %u uploaded vertices", firstVertex, firstVertex, nV, c->st->numVerts);
         HIPCHK(c, hipSetDevice(c->device));
@@ -3199,14 +3115,13 @@ int pt_render(pt_ctx* c, uint32_t spp)
     HIPCHK(c, hipEventRecord(c->evStop, c->stream));
     if (c->profile) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        double fam[7] = { 0, 0, 0, 0, 0, 0, 0 }; // [5], [6]: k_descend ahead of the shadow rays / the extension rays (counted with their family AND apart)
+        double fam[5] = { 0, 0, 0, 0, 0 };
         for (auto& m : prof.marks) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, c->profEvents[m.second], c->profEvents[m.second + 1]);
             fam[m.first] += ms;
         }
-        c->msGen = fam[0], c->msIntersect = fam[1] + fam[4] + fam[6], c->msShade = fam[2], c->msShadow = fam[3] + fam[5], c->msPacket = fam[4];
-        c->msDescend = fam[5] + fam[6];
+        c->msGen = fam[0], c->msIntersect = fam[1] + fam[4], c->msShade = fam[2], c->msShadow = fam[3], c->msPacket = fam[4];
     }
     return PT_OK;
     });
@@ -3319,8 +3234,6 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->gen_launches = c->genLaunches;
     out->bundle_launches = c->bundleLaunches;
     out->ms_packet = c->msPacket;
-    out->descent_launches = c->descentLaunches;
-    out->ms_descend = c->msDescend;
     out->stack_need = c->dyn[c->active].stackNeed;
     out->folded_instances = c->dyn[c->active].foldedInstances;
     out->team_launches = c->teamLaunches;
@@ -3333,7 +3246,7 @@ int pt_stats_reset(pt_ctx* c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream));
-    c->packetLaunches = c->genLaunches = c->bundleLaunches = c->descentLaunches = c->teamLaunches = 0;
+    c->packetLaunches = c->genLaunches = c->bundleLaunches = c->teamLaunches = 0;
     return PT_OK;
 }
 
@@ -3407,7 +3320,6 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     DevBuf<float4> dO, dD, dC, dH, dAcc;
     DevBuf<int32_t> dI;
     DevBuf<uint32_t> dOcc;
-    DevBuf<uint4> dStart;
     DevBuf<Control> dCtl;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) {
@@ -3415,8 +3327,6 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
             e = x;
     };
     chk(dO.alloc(n)), chk(dD.alloc(n)), chk(dC.alloc(n)), chk(dH.alloc(n)), chk(dI.alloc(n)), chk(dOcc.alloc(n)), chk(dAcc.alloc(1)), chk(dCtl.alloc(1));
-    if (c->descentUse & 4u)
-        chk(dStart.alloc(n));
     if (e == hipSuccess) {
         chk(hipMemcpy(dO.p, hO.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         chk(hipMemcpy(dD.p, hD.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -3439,11 +3349,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
         a.hit = dH.p, a.inst = dI.p, a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u }, a.occluded = dOcc.p;
         a.ctl = dCtl.p, a.pass = 0;
         chk(hipEventRecord(e0, c->stream));
-        if (c->descentUse & 4u) { // consecutive rays in packets of 64 take the way to their origins together (pt_descend.h), then the per-ray kernel
-            launchDescend(c, any_hit != 0, dO.p, dD.p, any_hit ? &dCtl.p->shadowCount[0] : &dCtl.p->extCount[0], dStart.p);
-            a.start = dStart.p;
-            launchTrace(c, any_hit != 0, a);
-        } else if (c->dyn[c->active].packetOk && (c->packetUse & 4u))
+        if (c->dyn[c->active].packetOk && (c->packetUse & 4u))
             launchPacket(c, any_hit != 0, a);
         else
             launchTrace(c, any_hit != 0, a);
@@ -3476,7 +3382,7 @@ int pt_intersect(pt_ctx* c, const pt_rays_soa* rays, uint32_t n, int any_hit, pt
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    dO.release(), dD.release(), dC.release(), dH.release(), dI.release(), dOcc.release(), dAcc.release(), dCtl.release(), dStart.release();
+    dO.release(), dD.release(), dC.release(), dH.release(), dI.release(), dOcc.release(), dAcc.release(), dCtl.release();
     if (ms_out)
         *ms_out = msTotal / (float)repeat;
     HIPCHK(c, e);

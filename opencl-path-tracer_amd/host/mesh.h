@@ -29,8 +29,11 @@ public:
     virtual uint32_t maxNumBvhNodes() const = 0;
     virtual void buildBvh() = 0;
     virtual uint32_t getBvhRootNode() const = 0;
-    // bumped whenever the arrays above change (a refit, a rebuild): what a flattened copy of them is held against
-    virtual uint64_t generation() const { return 0; }
+    // bumped whenever the arrays above change (a refit, a rebuild): what a flattened copy of them is held against.  An implementation that does not keep
+    // count returns kUntracked: RayTracer::updateGeometry then takes such a mesh for changed whenever it isDynamic() (the reference's MeshSequence is such
+    // a class: its arrays change under goToNextFrame, src/model/mesh_sequence.cpp:81-97) and hands the re-flattened arrays over as the reference does.
+    static constexpr uint64_t kUntracked = ~0ull;
+    virtual uint64_t generation() const { return kUntracked; }
 };
 
 class Mesh : public IMesh {

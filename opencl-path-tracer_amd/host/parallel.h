@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstddef>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -23,7 +24,8 @@ public:
         // stops its workers at exit (Stopper); a child leaves the copy alone.
         static WorkerPool* pool = new WorkerPool;
         static Stopper stopper { pool };
-        return *pool;
+        (void)stopper;
+        return *pool; // (never deleted: a static destructor that runs later may still come here -- see Stopper)
     }
     // fn(begin, end) on disjoint ranges covering [0, count); below `minPerThread` items per thread the caller does it alone
     void parallelFor(size_t count, size_t minPerThread, const std::function<void(size_t, size_t)>& fn)
@@ -43,12 +45,25 @@ public:
             m_fn = &fn, m_count = count, m_chunk = chunk, m_parts = parts, m_pending = parts - 1, m_generation++;
         }
         m_wake.notify_all();
+        // An exception out of fn -- on this thread or on a worker (std::bad_alloc from a builder's vectors) -- is kept, every range is still waited
+        // for (the workers hold a pointer to the caller's `fn`, which captures the caller's stack), and the first one is rethrown HERE, on the
+        // calling thread, where the C ABI's guarded() turns it into an error code.
+        std::exception_ptr mine;
         insideTask() = true;
-        fn(0, std::min(chunk, count));
+        try {
+            fn(0, std::min(chunk, count));
+        } catch (...) {
+            mine = std::current_exception();
+        }
         insideTask() = false;
         std::unique_lock<std::mutex> lock(m_mutex);
         m_done.wait(lock, [&] { return m_pending == 0; });
         m_fn = nullptr;
+        std::exception_ptr first = mine ? mine : m_error;
+        m_error = nullptr;
+        lock.unlock();
+        if (first)
+            std::rethrow_exception(first);
     }
     size_t threads() const { return getpid() == m_pid ? m_threads.size() + 1 : 1; }
     static bool& insideTask()
@@ -65,15 +80,17 @@ private:
         for (unsigned i = 0; i < n; i++)
             m_threads.emplace_back([this, i] { run(i + 1); });
     }
+    // at exit the process that made the pool stops and joins its workers; the object itself stays (a static destructor that runs after this one may
+    // still call get(): it finds a pool without workers, whose loops run on the caller)
     struct Stopper {
         WorkerPool* pool;
         ~Stopper()
         {
             if (getpid() == pool->m_pid)
-                delete pool;
+                pool->stop();
         }
     };
-    ~WorkerPool()
+    void stop()
     {
         {
             std::lock_guard<std::mutex> lock(m_mutex);
@@ -82,7 +99,9 @@ private:
         m_wake.notify_all();
         for (std::thread& t : m_threads)
             t.join();
+        m_threads.clear();
     }
+    ~WorkerPool() = delete; // (see get())
     void run(size_t part)
     {
         size_t seen = 0;
@@ -99,13 +118,20 @@ private:
                     continue; // fewer parts than threads this time
                 fn = m_fn, begin = std::min(part * m_chunk, m_count), end = std::min(begin + m_chunk, m_count);
             }
+            std::exception_ptr err;
             if (begin < end) {
                 insideTask() = true;
-                (*fn)(begin, end);
+                try {
+                    (*fn)(begin, end);
+                } catch (...) {
+                    err = std::current_exception();
+                }
                 insideTask() = false;
             }
             {
                 std::lock_guard<std::mutex> lock(m_mutex);
+                if (err && !m_error)
+                    m_error = err;
                 if (--m_pending == 0)
                     m_done.notify_one();
             }
@@ -118,6 +144,7 @@ private:
     const std::function<void(size_t, size_t)>* m_fn = nullptr;
     size_t m_count = 0, m_chunk = 0, m_parts = 0, m_pending = 0, m_generation = 0;
     bool m_quit = false;
+    std::exception_ptr m_error; // the first exception a worker's range threw in the current loop
 };
 
 } // namespace raytracer

@@ -74,6 +74,13 @@ void RayTracer::updateGeometry()
     bool hostRoute = false;
     for (MeshBvhPair& pair : m_scene->getMeshes()) {
         const uint64_t gen = pair.meshPtr->generation();
+        if (gen == IMesh::kUntracked) { // the mesh does not say when it changes: a dynamic one has changed, a static one never does
+            if (pair.meshPtr->isDynamic()) {
+                hostRoute = true;
+                break;
+            }
+            continue;
+        }
         if (gen == pair.uploadedGeneration)
             continue;
         const auto& verts = pair.meshPtr->getVertices();

@@ -78,7 +78,8 @@ public:
 
     void rayTrace(const Camera& camera); // one sample per pixel; resets the accumulation when the camera changed
     void frameTick(); // re-flatten lights + top-level BVH after scene-graph transforms changed (asynchronous upload + flip)
-    void updateGeometry(); // after Mesh::refit: new vertices (the device refits its trees); takes effect with the next frameTick
+    void updateGeometry(); // after Mesh::refit: new vertices (the device refits its trees); takes effect with the next frameTick.  Not between rebuildGeometry() and
+                           // its frameTick(): the device library refuses a refit while a rebuilt scene waits to be adopted (PT_ERR_STATE -> std::runtime_error)
     void rebuildGeometry(); // after meshes of the scene were REPLACED (a new tree per frame, MeshSequence's other branch): converted and copied beside the scene that is rendering; adopted by the next frameTick
     int getSamplesPerPixel() const;
     int getMaxSamplesPerPixel() const { return 20000000; } // MAX_SAMPLES_PER_PIXEL, src/raytracer.cpp:38

@@ -91,6 +91,10 @@ def build_raytracer(force=False):
     if force or _newer(exe2, [os.path.join(ex_dir, "deform_loop.cpp"), out]):
         subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "deform_loop.cpp", "-o", "deform_loop", "-L" + HOST_DIR, "-lptamd_raytracer",
                         "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
+    exe3 = os.path.join(ex_dir, "untracked_mesh")
+    if force or _newer(exe3, [os.path.join(ex_dir, "untracked_mesh.cpp"), out]):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "untracked_mesh.cpp", "-o", "untracked_mesh", "-L" + HOST_DIR, "-lptamd_raytracer",
+                        "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
     return out, exe
 
 

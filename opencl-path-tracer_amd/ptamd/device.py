@@ -19,8 +19,6 @@ FLAG_INTEGRATOR_MIS = 32  # neeMisShading instead of neeIsShading
 FLAG_COMPARE_SHADING = 64  # the reference's COMPARE_SHADING build: MIS on the left half of the image, IS on the right, same view
 FLAG_SOLID_ANGLE_LIGHTS = 128  # NEE picks lights by weightedRandomPointOnLight
 FLAG_MATERIAL_BINS = 512  # k_shade walks its tiles in material order (scenes with several material types; measured slower: opt-in)
-FLAG_SHARED_DESCENT = 1024  # shared descent ahead of the per-ray traversal for the rays that leave the primary hits (opt-in)
-FLAG_DESCENT_INTERSECT = 2048  # the pt_intersect hook: packets of 64 consecutive rays take the shared descent first
 FLAG_PARKED_INSTANCES = 4096  # entered instances always take the general (parked) route; default: translation + uniform scale is walked through entry nodes
 FLAG_TEAM_INTERSECT = 8192  # the pt_intersect hook runs the team kernel (four lanes per ray) where the scene allows it
 FLAG_QUEUE_PRIMARY_RAYS = 256  # k_gen writes the primary rays even where the packet kernel could regenerate them
@@ -42,7 +40,7 @@ class Stats(C.Structure):
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
                 ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double),
                 ("deposits_shadow", C.c_uint64), ("gen_launches", C.c_uint64), ("bundle_launches", C.c_uint64),
-                ("descent_launches", C.c_uint64), ("ms_descend", C.c_double), ("stack_need", C.c_uint32), ("folded_instances", C.c_uint32), ("team_launches", C.c_uint64)]
+                ("stack_need", C.c_uint32), ("folded_instances", C.c_uint32), ("team_launches", C.c_uint64)]
 
 
 class RaysSoA(C.Structure):

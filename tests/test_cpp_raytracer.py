@@ -46,3 +46,14 @@ def test_cpp_deforming_mesh_loop(gpu):
     assert int(fields["triangles"]) == 36450 and int(fields["spp"]) == 13
     assert 0 < float(fields["until_adopted_ms"]) < 40.0, fields  # measured 0.8 ms; the reference publishes 4.1-6.3 per frame
     assert 0 < float(fields["mean_first"]) and abs(float(fields["mean_last"]) - float(fields["mean_first"])) > 1e-6
+
+
+@pytest.mark.gpu
+def test_a_dynamic_mesh_that_does_not_count_generations_is_uploaded_every_time(gpu):
+    """examples/untracked_mesh.cpp: an IMesh that is not raytracer::Mesh (the reference's MeshSequence is such a class: isDynamic(), no generation
+    counter).  RayTracer::updateGeometry takes it for changed and hands the re-flattened arrays over (pt_update_geometry); the frames after the tick are
+    bit for bit those of a RayTracer built on the deformed state (the mesh was skipped and the old geometry rendered)."""
+    exe = os.path.join(ROOT, "examples", "untracked_mesh")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "stale_differs=1 same_as_fresh=1" in r.stdout

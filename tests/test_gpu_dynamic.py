@@ -475,6 +475,11 @@ def test_a_rebuilt_tree_per_frame_is_adopted_at_the_tick_while_the_old_one_rende
     ctx.upload_dynamic_async(flat_a)
     ctx.upload_static_async(flat_b)
     ctx.upload_dynamic_async(flat_b)
+    # a refit between a rebuild and its tick would address the scene that still renders with the rebuilt scene's offsets: refused, nothing changes
+    with pytest.raises(gpu.PtError, match="waiting for pt_frame_tick"):
+        ctx.refit_vertices(sck.mesh_offsets(meshk)[0], meshk.vertices_view())
+    with pytest.raises(gpu.PtError, match="waiting for pt_frame_tick"):
+        ctx.update_geometry(flat_r)
     ctx.frame_tick()
     ctx.clear()
     ctx.render(8)

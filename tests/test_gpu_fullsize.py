@@ -90,7 +90,6 @@ def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_
     st = ctx.stats()
     assert st["packet_launches"] == 1 and st["gen_launches"] == 0, "the batch must take the path the benchmark times"
     assert st["bundle_launches"] == (0 if flags_name == "thin_lens" else 1)  # pinhole: bundles of 4 x 64 (k_trace_multi); thin lens: packets of 64
-    assert st["descent_launches"] == 0  # (the shared descent is opt-in)
     assert st["rays_generated"] == W * H * n and ctx.samples_per_pixel == n
     a = ctx.read_accum()[:, :3]
     ctx.close()

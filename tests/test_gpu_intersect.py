@@ -12,7 +12,7 @@ from ptamd import host as H, layout as L, scenes
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "descent", "unbaked_descent", "two_level_parked", "unbaked_parked", "team"]
+MODES = ["two_level", "baked", "packet", "two_level_packet", "unbaked", "unbaked_packet", "two_level_parked", "unbaked_parked", "team"]
 
 
 def _flags(gpu, mode):
@@ -22,8 +22,6 @@ def _flags(gpu, mode):
     return {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "baked": 0, "packet": gpu.FLAG_PACKET_INTERSECT,
             "two_level_packet": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PACKET_INTERSECT, "unbaked": gpu.FLAG_NO_BAKED_INSTANCES,
             "unbaked_packet": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PACKET_INTERSECT,
-            # *descent: packets of 64 consecutive rays walk from the root towards their origins together (pt_descend.h), then the per-ray kernel
-            "descent": gpu.FLAG_DESCENT_INTERSECT, "unbaked_descent": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_DESCENT_INTERSECT,
             # *parked: the general route into an instance for every instance (rounds 2-4); without it (round 5) the per-ray kernels walk instances that are a
             # translation + uniform scale through entry nodes, the ray taken into the instance's space on the fly
             "two_level_parked": gpu.FLAG_TWO_LEVEL_ONLY | gpu.FLAG_PARKED_INSTANCES, "unbaked_parked": gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PARKED_INSTANCES,
@@ -40,7 +38,6 @@ def _check_kernel_used(ctx, mode, folded=None):
     assert (ctx.stats()["team_launches"] > 0) == (mode == "team"), "the team kernel did not run where it should (or ran where it should not)"
     if folded is not None:  # how many instances of the scene the per-ray kernels walk through entry nodes
         assert ctx.stats()["folded_instances"] == folded, (ctx.stats()["folded_instances"], folded)
-    assert (ctx.stats()["descent_launches"] > 0) == mode.endswith("descent"), "the shared descent did not run where it should (or ran where it should not)"
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -221,44 +218,6 @@ def _rays_leaving_surfaces(ctx, W, Hh, per_pixel, seed, towards=None):
     nd /= length[:, None]
     p = p + 1e-3 * nd
     return p.astype(np.float32), nd.astype(np.float32), (length - 2e-3).astype(np.float32)
-
-
-@pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated"])
-def test_shared_descent_finds_the_hits_of_the_per_ray_kernel(gpu, kind):
-    """k_descend (pt_descend.h) walks a packet of 64 consecutive rays from the root towards their origins as ONE walk -- every lane
-    testing the uniform node's child boxes for its own ray with the per-ray kernel's arithmetic -- and hands every ray to the per-ray
-    kernel with a start state (reference + stacked siblings) instead of (root, empty stack).  The set of subtrees a ray visits is the
-    same, only the order differs: every hit record must be the per-ray kernel's (same triangle, same t / u / v bits) except at exact-t
-    ties, every occlusion verdict identical.  Packet shapes: rays that leave one pixel's footprint in random directions / towards a
-    small light (what the descent is for), the same rays shuffled (nothing shared: every lane drops out at the root), camera rays."""
-    W, Hh = 160, 90
-    b = scenes.instanced_grid(W, Hh, level=4, sky_size=(16, 8), rotate=kind == "unbaked_rotated")
-    base = {"baked": 0, "two_level": gpu.FLAG_TWO_LEVEL_ONLY, "unbaked_rotated": gpu.FLAG_NO_BAKED_INSTANCES}[kind]
-    shared = U.make_ctx(gpu, b, W, Hh, flags=base | gpu.FLAG_DESCENT_INTERSECT)
-    per_ray = U.make_ctx(gpu, b, W, Hh, flags=base)
-    o_b, d_b, _ = _rays_leaving_surfaces(per_ray, W, Hh, 16, 7)
-    o_s, d_s, len_s = _rays_leaving_surfaces(per_ray, W, Hh, 16, 8, towards=((0.0, 4.0, 0.0), (1.2, 0.0, 1.2)))
-    o_c, d_c, _ = per_ray.gen_rays(1, W * Hh)
-    perm = np.random.default_rng(5).permutation(len(o_b))[:30000]
-    assert len(o_b) > 50000 and len(o_s) > 50000
-    for name, o, d in (("bounce", o_b, d_b), ("shuffled", o_b[perm], d_b[perm]), ("camera", o_c, d_c), ("ragged", o_b[:1000 * 64 + 17], d_b[:1000 * 64 + 17])):
-        got, want = shared.intersect(o, d), per_ray.intersect(o, d)
-        same = (got["prim"] == want["prim"]) & (got["inst"] == want["inst"])
-        diff = ~same
-        assert diff.mean() < 1e-3, (name, diff.sum())
-        assert np.allclose(got["t"][diff], want["t"][diff], rtol=1e-6), name
-        for k in ("t", "u", "v"):
-            assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), (name, k)
-        assert (got["prim"] >= 0).mean() > 0.2, name
-    for name, o, d, tmax in (("shadow", o_s, d_s, len_s), ("shadow shuffled", o_s[perm], d_s[perm], len_s[perm]),
-                             ("short", o_b, d_b, np.random.default_rng(2).uniform(0.02, 3.0, len(o_b)).astype(np.float32))):
-        got = shared.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
-        want = per_ray.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
-        assert np.array_equal(got, want), (name, int((got != want).sum()))
-        assert 0.02 < want.mean() < 0.98, (name, want.mean())
-    assert shared.stats()["descent_launches"] > 0 and per_ray.stats()["descent_launches"] == 0
-    shared.close()
-    per_ray.close()
 
 
 @pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated", "baked_thin_lens"])

@@ -479,34 +479,6 @@ def test_beam_packets_render_like_the_per_ray_kernel_from_random_viewpoints(gpu,
     assert total_diff <= 16
 
 
-@pytest.mark.parametrize("instances", ["copied", "entered"])
-def test_shared_descent_renders_like_the_per_ray_kernels_alone(gpu, instances):
-    """PT_FLAG_SHARED_DESCENT: ahead of the per-ray traversal, the shadow rays of the primary hits and the first bounce's extension rays
-    walk from the root to their origins packet by packet (pt_descend.h) and start where that walk left them.  Every ray still visits
-    every box it passes, only in another order: occlusion verdicts are identical, closest hits differ at most where two triangles are
-    hit at exactly the same distance -- so the image is the per-ray kernels' image except for those paths.  A batch large enough for
-    the fixed, non-overlapped schedule (> 4 M entries), twice (the second batch reuses the start-state buffer)."""
-    W, Hh, spp = 512, 288, 32
-    b = scenes.instanced_grid(W, Hh, level=4, sky_size=(32, 16))
-    base = gpu.FLAG_NO_BAKED_INSTANCES if instances == "entered" else 0
-    images, stats = [], []
-    for flags in (base, base | gpu.FLAG_SHARED_DESCENT):
-        ctx = U.make_ctx(gpu, b, W, Hh, seed=5, flags=flags, samples_in_flight=spp)
-        ctx.render(2 * spp)
-        images.append(ctx.read_accum()[:, :3])
-        stats.append(ctx.stats())
-        ctx.close()
-    plain, shared = stats
-    assert plain["descent_launches"] == 0 and shared["descent_launches"] == 4  # two batches x (shadow rays of pass 0, extension rays of pass 1)
-    for k in ("rays_generated", "rays_extension"):
-        assert plain[k] == shared[k], k
-    # a tie decided the other way shades another triangle: the path goes on differently from there (a handful of paths per million)
-    assert abs(plain["rays_shadow"] - shared["rays_shadow"]) <= 1e-5 * plain["rays_shadow"]
-    same = np.all(images[0] == images[1], axis=1)
-    assert same.mean() > 0.999, f"{(~same).sum()} of {len(same)} pixels differ"
-    assert np.allclose(images[0].mean(0), images[1].mean(0), rtol=1e-5)
-
-
 @pytest.mark.parametrize("in_flight", [48, 100])
 def test_batches_that_are_not_a_power_of_two(gpu, in_flight):
     """pt_render cuts a batch at the largest multiple of the interleave it can hold (48 -> 32 + 16, 100 -> 64 + 32 + 4: up to 256 samples of a
