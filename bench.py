@@ -305,6 +305,8 @@ def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=
         ps = ctx.stats()
         ctx.profile_kernels(False)
         pr = ps["rays_extension"] + ps["rays_shadow"]
+        primary = ps["rays_generated"] if ps["packet_launches"] > 0 else 0  # (camera rays through the packet / bundle kernel; otherwise they are per-ray kernel work)
+        per_ray_ms = ps["ms_intersect"] - ps["ms_packet"]
         out = {"what": what, "mrays_per_s": round(rays / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                "spp_per_step": spp, "samples_in_flight": in_flight, "rays_per_step": int(rays / steps),
                "rays_per_primary": round(rays / max(st["rays_generated"], 1), 3),
@@ -312,11 +314,31 @@ def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=
                "kernel_ms_per_step": {"gen": round(ps["ms_gen"], 2), "closest_hit": round(ps["ms_intersect"], 2),
                                       "of_which_packet": round(ps["ms_packet"], 2), "shade": round(ps["ms_shade"], 2),
                                       "any_hit": round(ps["ms_shadow"], 2)},
+               # rays per class and the rate INSIDE the kernels that trace them (device ms of the profiled step): the whole-job figure above is a mix of these
+               "rays_by_class": rays_by_class(ps),
+               "instances": {"entered": ps["entered_instances"], "folded": ps["folded_instances"], "general_route": bool(ps["general_route"])},
+               "per_ray_kernels_mrays_per_s": round((pr - primary) / max(per_ray_ms + ps["ms_shadow"], 1e-9) / 1e3, 1),  # bounce + shadow rays over their two kernels' time
                "shade_ns_per_entry": round(ps["ms_shade"] * 1e6 / max(ps["shade_hits"], 1), 3),
                "mrays_per_s_profiled_step": round(pr / max(ps["ms_last_render"], 1e-6) / 1e3, 1)}
         return out
     finally:
         ctx.close()
+
+
+def rays_by_class(ps):
+    """{camera, bounce, shadow}: rays of a profiled step and the rate inside the kernel family that traces them (pt_stats of a pass with per-kernel events)."""
+    packets = ps["packet_launches"] > 0
+    camera = ps["rays_generated"]
+    bounce = ps["rays_extension"] - camera
+    ms_cam = ps["ms_packet"] if packets else 0.0
+    ms_bounce = ps["ms_intersect"] - ms_cam
+    out = {"camera": {"rays": int(camera), "kernel": "k_trace_multi / k_trace_packet" if packets else "k_trace<false> (with the bounce rays)",
+                      "in_kernel_mrays_per_s": round(camera / ms_cam / 1e3, 1) if ms_cam > 0 else None},
+           "bounce": {"rays": int(bounce), "kernel": "k_trace<false>",
+                      "in_kernel_mrays_per_s": round((bounce if packets else bounce + camera) / ms_bounce / 1e3, 1) if ms_bounce > 0 else None},
+           "shadow": {"rays": int(ps["rays_shadow"]), "kernel": "k_trace<true>",
+                      "in_kernel_mrays_per_s": round(ps["rays_shadow"] / ps["ms_shadow"] / 1e3, 1) if ps["ms_shadow"] > 0 else None}}
+    return out
 
 
 def _torus_mesh(H, L, nu, nv, material, builder):
@@ -546,6 +568,47 @@ def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
     return out
 
 
+def two_level_general_times(D, scenes, W, Hh, level, device, in_flight, only=None, ways=("entered", "entered_parked", "default_flags", "copied")):
+    """traceRay's GENERAL case (scene.cl:116-139 enters any 4 x 4 inverse transform, any number of instances) timed, not only tested.
+    320 instances of the two 82 k-triangle meshes (26 M instanced triangles; 2.6 GB as world-space copies: over the library's 2 GB copy budget)
+    under config 4's camera, each turned about the vertical axis and scaled by three different factors; and 208 translated + uniformly scaled
+    ones (more than the 95 the fold table holds).  Each scene four ways: every instance entered by the round-6 route (leaf-kind entry steps,
+    nothing parked), by the parked route of rounds 2-5 (PT_FLAG_PARKED_INSTANCES), the library's default (copies while the budget lasts), and
+    every instance copied to world space with the budget raised (PTAMD_BAKE_BUDGET_GB: what instancing exists to avoid -- the per-ray rate it
+    reaches is the yardstick)."""
+    res = {}
+    for name, kw, n_inst in (("general_320", dict(nx=20, nz=16, transform="general"), 320), ("uniform_208", dict(nx=16, nz=13, transform="uniform"), 208)):
+        if only and name not in only:
+            continue
+        crowd = scenes.instanced_crowd(W, Hh, level=level, **kw)
+        what = (f"{n_inst} instances of the two {crowd.flat.instanced_triangles // n_inst}-triangle meshes = {crowd.flat.instanced_triangles} instanced triangles, config 4's "
+                "camera / materials / sky; " + ("each turned about the vertical axis by a random angle and scaled by three different factors"
+                                                if name.startswith("general") else "translated + uniformly scaled (configs 4 / 5's kind of transform)"))
+        r = {"what": what}
+        if "entered" in ways:
+            r["entered"] = measure_scene(D, crowd, W, Hh, device, in_flight, flags=D.FLAG_NO_BAKED_INSTANCES, steps=2,
+                                         what="every instance entered (PT_FLAG_NO_BAKED_INSTANCES): the general route of round 6, pt_trace.h LEVELS 2")
+        if "entered_parked" in ways:
+            r["entered_parked"] = measure_scene(D, crowd, W, Hh, device, in_flight, flags=D.FLAG_NO_BAKED_INSTANCES | D.FLAG_PARKED_INSTANCES, steps=2,
+                                                what="every instance entered by the parked route of rounds 2-5 (PT_FLAG_PARKED_INSTANCES)")
+        if "default_flags" in ways:
+            r["default_flags"] = measure_scene(D, crowd, W, Hh, device, in_flight, flags=0, steps=2,
+                                               what="the library's default: instances copied to world space while the 2 GB budget lasts, the rest entered")
+        if "copied" in ways:
+            os.environ["PTAMD_BAKE_BUDGET_GB"] = "16"
+            try:
+                r["copied"] = measure_scene(D, crowd, W, Hh, device, in_flight, flags=0, steps=2,
+                                            what="every instance copied to world space (copy budget raised to 16 GB through PTAMD_BAKE_BUDGET_GB): the yardstick")
+            finally:
+                del os.environ["PTAMD_BAKE_BUDGET_GB"]
+            for key in ("entered", "entered_parked", "default_flags"):
+                if key in r:
+                    r[f"{key}_over_copied"] = round(r[key]["mrays_per_s"] / r["copied"]["mrays_per_s"], 4)
+                    r[f"{key}_over_copied_per_ray_kernels"] = round(r[key]["per_ray_kernels_mrays_per_s"] / r["copied"]["per_ray_kernels_mrays_per_s"], 4)
+        res[name] = r
+    return res
+
+
 def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
     """The N = 1 line's secondary objects.  Every entry is guarded: a failure is reported in place and never takes the headline down."""
     W, Hh = args.width, args.height
@@ -565,6 +628,8 @@ def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
                                                    what="PT_FLAG_TWO_LEVEL_ONLY: the 12 mesh instances are entered; the two quads (single-leaf meshes) "
                                                         "hang off the top level as world-space leaves"),
         "instances_copied_to_world_space": measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, what="the headline's configuration, measured the same way")})
+    guarded("two_level_general", lambda: two_level_general_times(D, scenes, W, Hh, args.level, device, in_flight))
+
     def dynamic():
         d = dynamic_update_times(D, H, L, scenes, bundle, W, Hh, device)
         d["refit"] = dynamic_refit_times(D, H, L, scenes, W, Hh, device)

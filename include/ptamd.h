@@ -185,6 +185,9 @@ typedef struct {
     uint32_t stack_need; /* worst-case traversal stack entries of the active scene state (packet kernels need <= 64) */
     uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk without parking (translation + uniform scale, not copied to world space) */
     uint64_t team_launches; /* traversal launches served by the team kernel (four lanes per ray: launches that do not fill the machine, csrc/pt_team.h) */
+    uint32_t entered_instances; /* instances of the active scene state that are entered at traversal (scene.cl:116-139) rather than copied to world space */
+    uint32_t general_route; /* 1: the per-ray kernels enter instances of ANY transform as leaf-kind steps, nothing parked (csrc/pt_trace.h, LEVELS 2: scenes with a rotated /
+                               non-uniformly scaled instance, or with more instances than the fold table holds) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

@@ -247,12 +247,35 @@ __device__ inline void rayIntoInstance(const float4 r0, const float4 r1, const f
 #ifndef PT_TRACE_MIN_WAVES_TL
 #define PT_TRACE_MIN_WAVES_TL 7
 #endif
-template <bool ANY_HIT, bool TWO_LEVEL>
-__global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES) k_trace(TraceArgs a)
+// LEVELS 2 (round 6): ANY instance transform, any number of instances, nothing parked but the end of a ray (scene.cl:116-139 in full).
+//  * Entering an instance is a LEAF-KIND step: the top-level leaf of an instance is its instance reference, a lane that stands on one votes with the lanes
+//    that stand on triangle leaves, and in the leaf iteration it fetches the 3 x 4 inverse transform (48 bytes: the size of a triangle record) instead of
+//    triangles, takes its ray into the instance's space (rayIntoInstance: the arithmetic of the parked route, bit for bit) and continues at the mesh's
+//    root.  Per visit that is one triangle test's worth of instructions shared by the lanes that enter in the same iteration -- no waiting for a quorum
+//    of parked lanes, no pass outside the hot loop.
+//  * Leaving an instance is NOTHING: the lane keeps the WORLD-space ray in its registers for the whole traversal; the instance-space ray (origin,
+//    1 / direction, direction: nine floats) lives in a per-lane LDS slot written at the entry.  Every step reads its ray through an ADDRESS select --
+//    object-space references (known from the reference's index alone, as in the folded route) read the lane's slot, world-space references a shared
+//    all-zero entry -- and one multiply-add per component, ray = world * m + slot with m = 0 / 1: no vector select per component, no sentinel on
+//    the stack, no re-read of the queue, no second pass.  An LDS read costs the vector ALU nothing (the kernel is vector-issue bound).
+//  * LDS per wave: the slots (9 x 65 floats) take the place of the staged ray packet, which this instantiation does without (the hand-out reads
+//    the queue itself: round 1's way, ~1.5 % slower on the flat scene): 12 stack entries + slots = 5.4 KB, 7 waves per SIMD.
+#ifndef PT_TRACE_MIN_WAVES_GEN
+#define PT_TRACE_MIN_WAVES_GEN 7
+#endif
+#ifndef PT_LDS_STACK_GEN
+#define PT_LDS_STACK_GEN PT_LDS_STACK
+#endif
+constexpr int kObjPlanes = 9; // origin xyz, 1 / direction xyz, direction xyz
+template <bool ANY_HIT, int LEVELS>
+__global__ void __launch_bounds__(kTraceBlock, LEVELS == 2 ? PT_TRACE_MIN_WAVES_GEN : (LEVELS == 1 ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES)) k_trace(TraceArgs a)
 {
-    constexpr int kLdsStack = TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack; // (shadows the namespace constant inside this kernel)
+    constexpr bool TWO_LEVEL = LEVELS == 1, GENERAL = LEVELS == 2;
+    constexpr bool STAGED = !GENERAL; // the next 64 queue entries of the wave copied into LDS ahead of the hand-out
+    constexpr int kLdsStack = GENERAL ? PT_LDS_STACK_GEN : (TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack); // (shadows the namespace constant inside this kernel)
     __shared__ uint32_t ldsStack[kTraceBlock / 64][kLdsStack][64];
-    __shared__ float4 ldsRays[kTraceBlock / 64][2][64]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
+    __shared__ float4 ldsRays[STAGED ? kTraceBlock / 64 : 1][2][STAGED ? 64 : 1]; // the claimed packet: origins, directions (entry e of the packet at [.][e])
+    __shared__ float ldsObj[GENERAL ? kTraceBlock / 64 : 1][GENERAL ? kObjPlanes : 1][GENERAL ? 65 : 1]; // [.][plane][lane]; [.][plane][64] = 0: what world-space steps read
     // TWO_LEVEL, round 5: instances whose transform is a translation + uniform scale are traversed WITHOUT parking and without an entry step.
     // The lane keeps the WORLD-space ray in its registers; while it walks object-space nodes / triangles -- known from the reference alone:
     // node indices below the first top-level node or in the run of per-instance root copies, triangle indices of the caller's numbering --
@@ -285,6 +308,10 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
         __syncthreads();
     }
     const bool fold = TWO_LEVEL && a.instFoldCount != 0u; // wave-uniform
+    if constexpr (GENERAL) {
+        if (lane < (uint32_t)kObjPlanes)
+            ldsObj[wave][lane][64] = 0.f; // (read by this wave alone, LDS operations of a wave complete in order: no barrier)
+    }
 
     auto push = [&](int slot, uint32_t v) {
         if (slot < kLdsStack)
@@ -371,7 +398,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
         poolBase = base;
         poolNext = 0;
         poolEnd = base < count ? min(64u, count - base) : 0u;
-        if (poolEnd) { // wave-uniform.  Lane l copies entry l (clamped: the tail of the last packet is never handed out)
+        if (STAGED && poolEnd) { // wave-uniform.  Lane l copies entry l (clamped: the tail of the last packet is never handed out)
             const uint32_t e = base + min(lane, poolEnd - 1u);
             // every lane has read its ray of the previous packet (the reads were waited for before the rays were used)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rayO + e), (__attribute__((address_space(3))) void*)&ldsRays[wave][0][0], 16, 0, 0);
@@ -398,10 +425,15 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     // the packet is only claimed; the lanes that take a ray read it straight from the queue
                     // (consecutive entries for consecutive idle lanes) -- no packet registers, no shuffles
                     ro = rd = make_float4(0, 0, 0, 0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the packet's copy into LDS has landed
-                    if (!active && rank < avail) {
-                        ro = ldsRays[wave][0][e];
-                        rd = ldsRays[wave][1][e];
+                    if constexpr (STAGED) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the packet's copy into LDS has landed
+                        if (!active && rank < avail) {
+                            ro = ldsRays[wave][0][e];
+                            rd = ldsRays[wave][1][e];
+                        }
+                    } else if (!active && rank < avail) {
+                        ro = a.rayO[poolBase + (uint32_t)e];
+                        rd = a.rayD[poolBase + (uint32_t)e];
                     }
                     PT_TOC(16, tShfl);
                     PT_TIC(tAssign);
@@ -537,7 +569,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
             // of them are served here at once.  The hot loop thus only ever changes (cur, sp, closest hit) and
             // the ray-space registers stay loop-invariant in it.
             while (true) {
-                const bool wantSpecial = active && refCount(cur) == kRefSpecial;
+                const bool wantSpecial = active && (GENERAL ? cur == kRefFinish : refCount(cur) == kRefSpecial); // (GENERAL: an instance reference is a leaf-kind step of the hot loop)
                 const unsigned long long m = __ballot(wantSpecial);
                 if (m == 0ull)
                     break;
@@ -616,13 +648,13 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
             const uint32_t stackTop = ldsStack[wave][min(max(sp - 1, 0), kLdsStack - 1)][lane];
             const uint32_t kindBits = refCount(cur);
             const bool wantInner = active && kindBits == 0u;
-            const bool wantLeaf = active && kindBits != 0u && kindBits != kRefSpecial;
+            const bool wantLeaf = active && kindBits != 0u && (GENERAL ? cur != kRefFinish : kindBits != kRefSpecial);
             const int nInner = __popcll(__ballot(wantInner)), nLeaf = __popcll(__ballot(wantLeaf));
             PT_STAT(0, 1);
             PT_STAT(1, nInner + nLeaf);
             // leave when nothing is left to do here, when enough lanes are parked on a special step, or when
             // enough lanes are idle for a hand-out (and the queue still has rays)
-            const int nSpecial = __popcll(__ballot(active && kindBits == kRefSpecial));
+            const int nSpecial = __popcll(__ballot(active && (GENERAL ? cur == kRefFinish : kindBits == kRefSpecial)));
             const int nWork = nInner + nLeaf;
             constexpr int parkedBreak = TWO_LEVEL ? (ANY_HIT ? PT_PARKED_BREAK_ANY_TL : PT_PARKED_BREAK_TL) : (ANY_HIT ? kParkedBreakAny : kParkedBreak);
             if (nWork == 0 || nSpecial >= parkedBreak || (!exhausted && 64 - nWork - nSpecial >= (TWO_LEVEL ? PT_REFILL_IDLE_TL : kRefillIdleLanes)))
@@ -649,6 +681,15 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                         foldIs = ldsInstFold[slot];
                         foldScale = ldsInstScale[slot];
                     }
+                    float genM = 1.f;
+                    V3 genO = mk(0.f), genI = mk(0.f);
+                    if constexpr (GENERAL) { // the LDS reads ahead of the node fetch: their latency hides under it
+                        const bool object = refIndex(cur) < sc.firstWorldNode; // a node of a mesh tree (the top level and the world-space copies come behind them)
+                        const uint32_t slot = object ? lane : 64u;
+                        genM = object ? 0.f : 1.f;
+                        genO = mk(ldsObj[wave][0][slot], ldsObj[wave][1][slot], ldsObj[wave][2][slot]);
+                        genI = mk(ldsObj[wave][3][slot], ldsObj[wave][4][slot], ldsObj[wave][5][slot]);
+                    }
 #if PT_OFFSET32
                     // base (scalar registers) + 32-bit byte offset: one shift instead of two 64-bit vector operations per step (nodes < 4 GB: checked at upload)
                     const uint4* wp = (const uint4*)((const char*)sc.wide + (size_t)(uint32_t)(refIndex(cur) << 6));
@@ -674,6 +715,10 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                     if constexpr (TWO_LEVEL) {
                         no = mk(fmaf(co.x, foldIs.x, foldIs.y), fmaf(co.y, foldIs.x, foldIs.z), fmaf(co.z, foldIs.x, foldIs.w));
                         nid = mk(cid.x * foldScale, cid.y * foldScale, cid.z * foldScale);
+                    }
+                    if constexpr (GENERAL) { // world * m + slot: the lane's instance-space ray at object-space nodes (m = 0), the world-space ray elsewhere (slot = 0)
+                        no = mk(fmaf(co.x, genM, genO.x), fmaf(co.y, genM, genO.y), fmaf(co.z, genM, genO.z));
+                        nid = mk(fmaf(cid.x, genM, genI.x), fmaf(cid.y, genM, genI.y), fmaf(cid.z, genM, genI.z));
                     }
                     // box plane = origin + scale * q  =>  t = q * (scale / d) + (origin - o) / d : one FMA per plane
                     const float ax = asF(A.w) * nid.x, ay = asF(C.z) * nid.y, az = asF(C.w) * nid.z;
@@ -781,11 +826,33 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
 #ifdef PT_TRACE_STATS
                 bool stOcc = false, stLane = false, stWave = false, stTri = false, stWave4 = false;
 #endif
-                if (wantLeaf) {
+                if (GENERAL && wantLeaf && kindBits == kRefSpecial) {
+                    // -------- enter instance refIndex(cur) (scene.cl:116-139): a leaf-kind step.  The lane's registers keep the world-space ray; the
+                    // instance-space ray goes into the lane's LDS slot, where the steps on the instance's nodes and triangles read it
+                    const uint32_t what = refIndex(cur);
+                    const Instance* ip = (const Instance*)((const char*)sc.instances + (size_t)(what << 6));
+                    static_assert(sizeof(Instance) == 64, "an instance record is addressed by index << 6");
+                    const float4 r0 = ip->r0, r1 = ip->r1, r2 = ip->r2;
+                    const uint32_t root = ip->rootRef;
+                    V3 to, td;
+                    rayIntoInstance(r0, r1, r2, co, cd, &to, &td);
+                    ldsObj[wave][0][lane] = to.x, ldsObj[wave][1][lane] = to.y, ldsObj[wave][2][lane] = to.z;
+                    ldsObj[wave][3][lane] = rcpSlab(td.x), ldsObj[wave][4][lane] = rcpSlab(td.y), ldsObj[wave][5][lane] = rcpSlab(td.z);
+                    ldsObj[wave][6][lane] = td.x, ldsObj[wave][7][lane] = td.y, ldsObj[wave][8][lane] = td.z;
+                    curInst = (int)what;
+                    cur = root; // nothing pushed: what lies below on the stack are world-space references, which read the world-space ray
+                } else if (wantLeaf) {
                     // -------- leaf (scene.cl:168-195) with Moeller-Trumbore (shapes.cl:20-72) -----------------
                     const uint32_t first = refIndex(cur), n = kindBits;
                     V3 lo_ = co, ld_ = cd; // the ray in the triangles' space
                     bool inObject = false;
+                    if constexpr (GENERAL) {
+                        inObject = first < sc.numTriangles + 1u; // the caller's (object-space) triangles; world-space copies come behind them
+                        const uint32_t slot = inObject ? lane : 64u;
+                        const float m = inObject ? 0.f : 1.f;
+                        lo_ = mk(fmaf(co.x, m, ldsObj[wave][0][slot]), fmaf(co.y, m, ldsObj[wave][1][slot]), fmaf(co.z, m, ldsObj[wave][2][slot]));
+                        ld_ = mk(fmaf(cd.x, m, ldsObj[wave][6][slot]), fmaf(cd.y, m, ldsObj[wave][7][slot]), fmaf(cd.z, m, ldsObj[wave][8][slot]));
+                    }
                     if constexpr (TWO_LEVEL) {
                         inObject = first < sc.numTriangles + 1u; // the caller's (object-space) triangles; world-space copies come behind them
                         const float4 is = ldsInstFold[fold && inObject ? (uint32_t)curInst + 1u : 0u];
@@ -823,7 +890,7 @@ __global__ void __launch_bounds__(kTraceBlock, TWO_LEVEL ? PT_TRACE_MIN_WAVES_TL
                             hu = u;
                             hv = v;
                             hprim = (int)(first + k);
-                            hinst = TWO_LEVEL ? (inObject ? curInst : -1) : curInst;
+                            hinst = (TWO_LEVEL || GENERAL) ? (inObject ? curInst : -1) : curInst;
                         }
                     }
 #ifdef PT_TRACE_STATS

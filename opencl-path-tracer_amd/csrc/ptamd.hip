@@ -186,6 +186,8 @@ struct pt_ctx {
         bool packetOk = false;
         uint32_t stackNeed = 0; // worst-case traversal stack of this state (pt_stats.stack_need)
         bool hasInstances = false; // the tree holds instance references (instances that were not copied to world space)
+        bool generalRoute = false; // ... and the per-ray kernels enter them as leaf-kind steps (pt_trace.h, LEVELS 2): some transform is not a translation + uniform scale, or there are more than the fold table holds
+        uint32_t enteredInstances = 0; // instances that are entered at traversal (not copied to world space)
         std::vector<uint32_t> instanceTopNode; // instance index -> top-level leaf node index
         hipEvent_t uploaded = nullptr; // recorded on the copy stream after the set's last upload
         hipEvent_t lastUse = nullptr; // recorded on the render stream when the set stopped being the active one
@@ -251,7 +253,7 @@ struct pt_ctx {
     DevBuf<Totals> totals;
     DevBuf<uint32_t> spill;
     size_t spillHalf = 0;
-    uint32_t traceBlocks[2] = { 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references
+    uint32_t traceBlocks[3] = { 0, 0, 0 }; // persistent grids: [0] one world-space tree, [1] trees with instance references (folded / parked), [2] the general route (pt_trace.h, LEVELS 2)
     uint32_t teamBlocks = 0; // grid of k_trace_team (pt_team.h: four lanes per ray, for launches that do not fill the machine)
     float teamRounds = 1.5f; // (1 / 1.5 / 1.7 / 2 / 3 measured on four scenes, tools/r5_frames_env.sh) ... used where the previous batch's pass held at most this many rays per team
     uint32_t teamUse = 7; // bit 0: the camera rays of 1-spp frames, bit 2: their shadow rays, bit 1: later passes by the previous batch's counters (PTAMD_TEAM_USE: diagnostics)
@@ -1175,10 +1177,11 @@ int ensureSpill(pt_ctx* c)
         return PT_OK;
     // persistent grids sized to the machine, per instantiation pair ([0]: scenes that are one world-space tree, [1]: scenes with
     // instance references -- pt_trace.h, TWO_LEVEL)
-    const void* variants[2][2] = { { (const void*)k_trace<false, false>, (const void*)k_trace<true, false> }, { (const void*)k_trace<false, true>, (const void*)k_trace<true, true> } };
+    const void* variants[3][2] = { { (const void*)k_trace<false, 0>, (const void*)k_trace<true, 0> }, { (const void*)k_trace<false, 1>, (const void*)k_trace<true, 1> },
+        { (const void*)k_trace<false, 2>, (const void*)k_trace<true, 2> } };
     const void* packetVariants[2][2] = { { (const void*)k_trace_packet<false, false>, (const void*)k_trace_packet<true, false> },
         { (const void*)k_trace_packet<false, true>, (const void*)k_trace_packet<true, true> } };
-    for (int tl = 0; tl < 2; tl++) {
+    for (int tl = 0; tl < 3; tl++) {
         int blocksPerCU = 8;
         for (const void* fn : variants[tl]) {
             int b = 0;
@@ -1189,6 +1192,8 @@ int ensureSpill(pt_ctx* c)
         if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) // diagnostics: a smaller persistent grid leaves wave slots to kernels of other streams / processes
             blocksPerCU = std::max(1, std::min(blocksPerCU, atoi(e)));
         c->traceBlocks[tl] = (uint32_t)(blocksPerCU * c->numCUs);
+        if (tl == 2)
+            break; // (the packet kernels know two kinds of scene)
         int pb = 8;
         for (const void* fn : packetVariants[tl]) {
             int b = 0;
@@ -1220,7 +1225,7 @@ int ensureSpill(pt_ctx* c)
         if (const char* e = getenv("PTAMD_TEAM_USE"))
             c->teamUse = (uint32_t)atoi(e);
     }
-    const size_t threads = (size_t)std::max(c->traceBlocks[0], c->traceBlocks[1]) * kTraceBlock;
+    const size_t threads = (size_t)std::max(std::max(c->traceBlocks[0], c->traceBlocks[1]), c->traceBlocks[2]) * kTraceBlock;
     HIPCHK(c, c->spill.alloc(3 * threads * kSpillStack)); // second and third part: the traversal kernels that run beside another one (the two side streams)
     c->spillHalf = threads * kSpillStack;
     return PT_OK;
@@ -1231,6 +1236,9 @@ inline int sceneKind(const pt_ctx* c)
     static const bool forceTwoLevel = getenv("PTAMD_FORCE_TWO_LEVEL_KERNELS") != nullptr; // diagnostics: what do the instantiations that CAN enter instances cost on a scene without any?
     return (c->dyn[c->active].hasInstances || forceTwoLevel) ? 1 : 0;
 }
+
+// which instantiation of the per-ray kernel (pt_trace.h, LEVELS): 2 = instances of ANY transform, entered as leaf-kind steps
+inline int traceKind(const pt_ctx* c) { return sceneKind(c) == 0 ? 0 : (c->dyn[c->active].generalRoute ? 2 : 1); }
 
 // Is this launch small enough for four lanes per ray (pt_team.h)?  Known only as a hint -- the live count is a device word --: what the same pass of
 // the previous batch of the same size held (its counters come back through pinned memory, renderSampleFixed); shadow rays of pass b are at most the
@@ -1265,24 +1273,29 @@ void launchTrace(pt_ctx* c, bool anyHit, const TraceArgs& args, hipStream_t stre
     }
     // the instantiation that can enter instances only where the tree holds instance references (pt_trace.h)
     const bool twoLevel = sceneKind(c) != 0;
+    const int kind = traceKind(c);
     TraceArgs a = args;
     if (twoLevel) { // the per-ray kernels walk the top level in which folded instances are plain inner references (the packet kernels: the one with instance references)
         a.sc.rootRef = c->dyn[c->active].rootRefFolded;
         a.instFold = c->dyn[c->active].instFold.p, a.instFoldCount = c->dyn[c->active].instFoldCount;
     }
-    const dim3 grid(c->traceBlocks[twoLevel ? 1 : 0]), block(kTraceBlock);
+    const dim3 grid(c->traceBlocks[kind]), block(kTraceBlock);
     if (!stream)
         stream = c->stream;
     if (anyHit) {
-        if (twoLevel)
-            hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, a);
+        if (kind == 2)
+            hipLaunchKernelGGL((k_trace<true, 2>), grid, block, 0, stream, a);
+        else if (kind == 1)
+            hipLaunchKernelGGL((k_trace<true, 1>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((k_trace<true, 0>), grid, block, 0, stream, a);
     } else {
-        if (twoLevel)
-            hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, a);
+        if (kind == 2)
+            hipLaunchKernelGGL((k_trace<false, 2>), grid, block, 0, stream, a);
+        else if (kind == 1)
+            hipLaunchKernelGGL((k_trace<false, 1>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((k_trace<false, 0>), grid, block, 0, stream, a);
     }
 }
 
@@ -1291,7 +1304,7 @@ TraceArgs traceArgsBase(pt_ctx* c)
     TraceArgs a {};
     a.sc = c->scene;
     a.spill = c->spill.p;
-    a.totalThreads = c->traceBlocks[sceneKind(c)] * kTraceBlock;
+    a.totalThreads = c->traceBlocks[traceKind(c)] * kTraceBlock;
     a.parityShadow = parityMode(c) ? 1u : 0u;
     return a;
 }
@@ -2414,8 +2427,8 @@ struct DynamicHost {
     uint32_t instRootBase = 0;
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
     uint32_t bakedNodes = 0, bakedTris = 0;
-    bool packetOk = false, hasInstances = false;
-    uint32_t stackNeed = 0;
+    bool packetOk = false, hasInstances = false, generalRoute = false;
+    uint32_t stackNeed = 0, enteredInstances = 0;
 };
 
 int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
@@ -2496,7 +2509,9 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     // renormalises the transformed direction, scene.cl:118-121); the traversal kernels map a hit on a copy back to (original
     // triangle, instance).  The copies themselves are made on the device (pt_bake.h); this only lays them out.
     {
-        const uint64_t budgetBytes = 2ull << 30;
+        uint64_t budgetBytes = 2ull << 30;
+        if (const char* e = getenv("PTAMD_BAKE_BUDGET_GB")) // diagnostics (bench.py, two_level_general: the copied scene as the yardstick of the entered one)
+            budgetBytes = (uint64_t)std::max(0.0, atof(e) * (double)(1ull << 30));
         uint64_t usedBytes = 0;
         uint32_t nextNode = staticNodes + out.topSlots, nextTri = staticTris;
         auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
@@ -2655,9 +2670,21 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
     out.instRootBase = staticNodes + out.topSlots + out.bakedNodes;
     {
         static const bool envNoFold = getenv("PTAMD_NO_FOLDED_INSTANCES") != nullptr; // diagnostics: every entered instance takes the parked route (rounds 2-4)
-        const bool noFold = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u || parityMode(c) // (parity mode follows the reference to the letter)
-            || hInst.size() + 1 > kInstFoldTable;
+        const bool parked = envNoFold || (c->cfg.flags & PT_FLAG_PARKED_INSTANCES) != 0u || parityMode(c); // (parity mode follows the reference to the letter)
         auto simple = [](const Instance& in) { return in.simple != 0u; };
+        // Which route for the instances that are entered?  Every one a translation + uniform scale and few enough for the LDS table: folded (no entry step at
+        // all).  Otherwise -- a rotation, a non-uniform scale, a shear, or instance number 96 -- the general route (round 6): every instance is entered as a
+        // leaf-kind step, nothing is parked (pt_trace.h, LEVELS 2).  PTAMD_GENERAL_ROUTE=1 / 0 (diagnostics): the general route for every scene with entered
+        // instances / never (rounds 2-5: such scenes park).
+        uint32_t entered = 0, enteredGeneral = 0;
+        for (size_t k = 0; k < hInst.size(); k++)
+            if (refCount(topRef[hInst[k].topNode]) == kRefSpecial)
+                entered++, enteredGeneral += simple(hInst[k]) ? 0u : 1u;
+        out.enteredInstances = entered;
+        static const char* envGeneral = getenv("PTAMD_GENERAL_ROUTE");
+        const bool tableHolds = hInst.size() + 1 <= kInstFoldTable;
+        out.generalRoute = !parked && entered > 0u && (envGeneral ? atoi(envGeneral) != 0 : (enteredGeneral > 0u || !tableHolds));
+        const bool noFold = parked || out.generalRoute || !tableHolds;
         std::vector<uint8_t> folded(hInst.size(), 0);
         for (size_t k = 0; k < hInst.size() && !noFold; k++)
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial && simple(hInst[k]))
@@ -2895,6 +2922,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     d.packetOk = h.packetOk;
     d.stackNeed = h.stackNeed;
     d.hasInstances = h.hasInstances;
+    d.generalRoute = h.generalRoute && h.hasInstances, d.enteredInstances = h.enteredInstances;
     d.instanceTopNode = std::move(h.instanceTopNode);
     c->pending = target;
     return PT_OK;
@@ -3236,6 +3264,8 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->ms_packet = c->msPacket;
     out->stack_need = c->dyn[c->active].stackNeed;
     out->folded_instances = c->dyn[c->active].foldedInstances;
+    out->entered_instances = c->dyn[c->active].enteredInstances;
+    out->general_route = c->dyn[c->active].generalRoute ? 1u : 0u;
     out->team_launches = c->teamLaunches;
     return PT_OK;
 }

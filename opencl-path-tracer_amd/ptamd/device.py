@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("ms_last_render", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
                 ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double),
                 ("deposits_shadow", C.c_uint64), ("gen_launches", C.c_uint64), ("bundle_launches", C.c_uint64),
-                ("stack_need", C.c_uint32), ("folded_instances", C.c_uint32), ("team_launches", C.c_uint64)]
+                ("stack_need", C.c_uint32), ("folded_instances", C.c_uint32), ("team_launches", C.c_uint64),
+                ("entered_instances", C.c_uint32), ("general_route", C.c_uint32)]
 
 
 class RaysSoA(C.Structure):

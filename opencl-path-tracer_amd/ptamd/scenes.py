@@ -291,6 +291,43 @@ def instanced_grid(width=1920, height=1080, nx=4, nz=3, level=6, builder=H.BVH_S
     return SceneBundle(scene, cam, width, height, sky=sky, name=f"instanced_grid_{nx}x{nz}")
 
 
+def instanced_crowd(width=1920, height=1080, nx=20, nz=16, level=6, builder=H.BVH_SPATIAL_SPLIT, transform="general", sky_size=(2048, 1024), seed=21):
+    """Config 4's camera, materials, sky and light over nx * nz instances of its two ~82k-triangle meshes, rows running away from the camera
+    (20 x 16 = 320 instances = 26 M instanced triangles: ~2.6 GB as world-space copies, more than the library's 2 GB copy budget -- instancing
+    exists so that this geometry is NOT copied).  `transform`: "general" = every instance turned about the vertical axis by a random angle and
+    scaled by three different factors (scene.cl:116-139 enters any 4 x 4 inverse transform); "uniform" = translation + one scale factor, as in
+    configs 4 / 5 (what the fold table of the per-ray kernels serves for up to 95 instances); "mixed" = two of three instances general."""
+    copper = L.material_pbr_metal((0.955, 0.638, 0.538), 0.8)
+    ceramic = L.material_pbr_dielectric((0.75, 0.2, 0.15), 0.7)
+    meshes = [blob_mesh(copper, level=level, seed=7, builder=builder), blob_mesh(ceramic, level=level, seed=11, builder=builder)]
+    scene = H.Scene()
+    mb = _MeshBuilder()
+    ext = 1.5 * max(nx, 2 * nz)
+    mb.add_quad((-ext, 0, -ext), (-ext, 0, ext), (ext, 0, ext), (ext, 0, -ext), 0)
+    scene.add_node(mb.build([L.material_pbr_dielectric((0.5, 0.5, 0.5), 0.3)], H.BVH_BINNED_SAH))
+    lb = _MeshBuilder()
+    lb.add_quad((-0.6, 0, -0.6), (0.6, 0, -0.6), (0.6, 0, 0.6), (-0.6, 0, 0.6), 0)  # n = -y (faces down)
+    scene.add_node(lb.build([L.material_emissive((1.0, 0.9, 0.75), 30.0)], H.BVH_BINNED_SAH), location=(0.0, 4.0, 0.0))
+    rng = np.random.default_rng(seed)
+    k = 0
+    for iz in range(nz):
+        for ix in range(nx):
+            x, z = (ix - (nx - 1) / 2) * 1.5, (iz - 1.0) * 1.5  # (the first three rows stand where config 4's do)
+            if transform == "general" or (transform == "mixed" and k % 3 != 0):
+                sx, sy, sz = (float(v) for v in rng.uniform(0.8, 1.35, 3))
+                ang = float(rng.uniform(0, 2 * np.pi))
+                q = (float(np.cos(ang / 2)), 0.0, float(np.sin(ang / 2)), 0.0)
+            else:
+                sx = sy = sz = float(1.0 + 0.35 * rng.random())
+                q = (1, 0, 0, 0)
+            scene.add_node(meshes[k % 2], location=(x, 0.62 * sy, z), orientation_wxyz=q, scale=(sx, sy, sz))
+            k += 1
+    cam = _camera(width, height, (0.0, 2.6, -5.2), (0.0, 0.5, 0.0), 60.0, focal_length_mm=50.0, aperture_fstops=8.0)
+    bundle = SceneBundle(scene, cam, width, height, sky=procedural_sky(*sky_size), name=f"instanced_crowd_{nx}x{nz}_{transform}")
+    bundle.crowd_extent = ((nx - 1) / 2 * 1.5 + 1.0, (nz - 2.0) * 1.5 + 1.0)  # half-width in x, far end in z: where tests aim their rays
+    return bundle
+
+
 def instance_field(width=1920, height=1080, n=1000, level=3, seed=9, builder=H.BVH_BINNED_SAH, sky_size=(256, 128)):
     """Many instances of a small mesh: n randomly placed, rotated and scaled copies of a 20 * 4^level-triangle blob
     (level 3: 1 280 triangles, n = 1000 -> 1.28 M instanced triangles) over a ground quad -- the top-level tree is the deep one here."""

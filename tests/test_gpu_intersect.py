@@ -33,11 +33,13 @@ def _entered(mode):
     return mode.startswith(("two_level", "unbaked"))
 
 
-def _check_kernel_used(ctx, mode, folded=None):
+def _check_kernel_used(ctx, mode, folded=None, general=None):
     assert (ctx.stats()["packet_launches"] > 0) == mode.endswith("packet"), "wrong traversal kernel ran"
     assert (ctx.stats()["team_launches"] > 0) == (mode == "team"), "the team kernel did not run where it should (or ran where it should not)"
     if folded is not None:  # how many instances of the scene the per-ray kernels walk through entry nodes
         assert ctx.stats()["folded_instances"] == folded, (ctx.stats()["folded_instances"], folded)
+    if general is not None:  # instances of any transform entered as leaf-kind steps (pt_trace.h, LEVELS 2)
+        assert ctx.stats()["general_route"] == (1 if general else 0), (ctx.stats()["general_route"], general)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -83,11 +85,11 @@ def test_random_rays_two_level(gpu, builder, mode, rotate):
     occ = ctx.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
     ref = O.intersect_batch(sc, o, d, tmax=tmax, any_hit=True, threads=8)["prim"]
     assert (occ != ref).sum() <= 3 + info["edge_flips"]
-    # translated + uniformly scaled instances that are entered go through entry nodes (12 meshes; with nothing copied also the two quads); rotated ones
-    # and the *parked modes take the general route
+    # translated + uniformly scaled instances that are entered are folded (12 meshes; with nothing copied also the two quads); a scene with a rotated
+    # instance takes the general route for every entered instance (round 6: leaf-kind entry steps, nothing parked), the *parked modes park (rounds 2-4)
     quads = 2 if mode.startswith("unbaked") else 0  # the ground and the light: single-leaf meshes, copied to world space unless nothing is
-    want_folded = 0 if (mode.endswith("parked") or not two_level) else quads + (0 if rotate else 12)
-    _check_kernel_used(ctx, mode, want_folded)
+    want_folded = 0 if (mode.endswith("parked") or not two_level or rotate) else quads + 12
+    _check_kernel_used(ctx, mode, want_folded, general=two_level and rotate and not mode.endswith("parked"))
     ctx.close()
 
 
@@ -516,3 +518,48 @@ def test_stack_bound_of_a_root_that_shares_its_subtree_with_an_earlier_root(gpu)
     assert st["stack_need"] >= n - 4, st["stack_need"]
     assert st["packet_launches"] == 0, "a tree that needs more than 64 stack entries must not reach the packet kernel"
     ctx.close()
+
+
+@pytest.mark.parametrize("scene", ["general_30", "uniform_130", "mixed_40"])
+def test_general_instance_route_finds_the_parked_routes_hits_bit_for_bit(gpu, scene):
+    """pt_trace.h, LEVELS 2 (round 6): instances of ANY transform -- turned, scaled by three different factors -- and any number of them are entered as
+    leaf-kind steps of the hot loop, the instance-space ray in a per-lane LDS slot, nothing parked.  The ray is taken into the instance's space by the
+    parked route's arithmetic (rayIntoInstance) and both walk the same tree in the same order: every hit record -- t, u, v to the bit, triangle,
+    instance -- and every occlusion verdict must be the parked route's (PT_FLAG_PARKED_INSTANCES), and the oracle's within the usual tolerances
+    (scene.cl:116-139).  general_30: 30 turned + non-uniformly scaled instances; uniform_130: 130 translated + uniformly scaled ones (more than the
+    95 the fold table holds); mixed_40: both kinds in one scene."""
+    if scene == "general_30":
+        b = scenes.instanced_crowd(64, 36, nx=6, nz=5, level=3, transform="general", sky_size=(16, 8))
+    elif scene == "uniform_130":
+        b = scenes.instanced_crowd(64, 36, nx=13, nz=10, level=2, transform="uniform", sky_size=(16, 8))
+    else:
+        b = scenes.instanced_crowd(64, 36, nx=8, nz=5, level=3, transform="mixed", sky_size=(16, 8))
+    n_inst = {"general_30": 30, "uniform_130": 130, "mixed_40": 40}[scene]
+    general = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_NO_BAKED_INSTANCES)
+    parked = U.make_ctx(gpu, b, 64, 36, flags=gpu.FLAG_NO_BAKED_INSTANCES | gpu.FLAG_PARKED_INSTANCES)
+    st = general.stats()
+    assert st["general_route"] == 1 and st["folded_instances"] == 0 and st["entered_instances"] == n_inst + 2, st
+    assert parked.stats()["general_route"] == 0
+    span = 0.75 * max(b.crowd_extent)
+    o, d = U.random_rays(120000, 17, (-span, 0.05, -3.0), (span, 3.0, b.crowd_extent[1]))
+    o_c, d_c, _ = general.gen_rays(2, 64 * 36)
+    for name, oo, dd in (("random", o, d), ("camera", o_c, d_c), ("ragged", o[:64 * 1000 + 17], d[:64 * 1000 + 17])):
+        got, want = general.intersect(oo, dd), parked.intersect(oo, dd)
+        for k in ("prim", "inst"):
+            assert np.array_equal(got[k], want[k]), (name, k, int((got[k] != want[k]).sum()))
+        for k in ("t", "u", "v"):
+            assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (name, k)
+        assert (got["prim"] >= 0).mean() > 0.2, name
+    tmax = np.random.default_rng(3).uniform(0.05, 6.0, len(o)).astype(np.float32)
+    occ_g = general.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
+    occ_p = parked.intersect(o, d, tmax=tmax, any_hit=True)["prim"]
+    assert np.array_equal(occ_g, occ_p), int((occ_g != occ_p).sum())
+    assert 0.05 < occ_g.mean() < 0.95
+    sc = U.oracle_scene(b)
+    sub = slice(0, 30000)
+    info = U.compare_hits(b.flat, {k: v[sub] for k, v in general.intersect(o, d).items()}, O.intersect_batch(sc, o[sub], d[sub], threads=8))
+    assert info["n"] > 5000 and info["flips"] == 0
+    ref = O.intersect_batch(sc, o[sub], d[sub], tmax=tmax[sub], any_hit=True, threads=8)["prim"]
+    assert (occ_g[sub] != ref).sum() <= 3
+    general.close()
+    parked.close()

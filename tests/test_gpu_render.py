@@ -87,6 +87,32 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("kind", ["general", "uniform_130"])
+def test_general_instance_route_renders_like_the_oracle(gpu, kind):
+    """The image gate of the scenes that take the general instance route (pt_trace.h, LEVELS 2: turned / non-uniformly scaled instances; more instances
+    than the fold table holds), every instance ENTERED (scene.cl:116-139): bundles for the camera rays (which rebuild their beam inside a turned
+    instance), the per-ray kernels for everything else, against the oracle path by path (counter PRNG), at the gates of every other configuration."""
+    if kind == "general":
+        b = scenes.instanced_crowd(96, 54, nx=6, nz=5, level=3, transform="general", sky_size=(64, 32))
+    else:
+        b = scenes.instanced_crowd(96, 54, nx=13, nz=10, level=2, transform="uniform", sky_size=(64, 32))
+    spp = 32
+    ctx = U.make_ctx(gpu, b, 96, 54, seed=3, samples_in_flight=16, flags=gpu.FLAG_NO_BAKED_INSTANCES)
+    ctx.render(spp)
+    a = ctx.read_accum()[:, :3]
+    st = ctx.stats()
+    assert st["general_route"] == 1 and st["packet_launches"] > 0
+    ref, cnt = O.render(U.oracle_scene(b), b.camera, 96, 54, spp, seed=3, threads=8)
+    ref = ref[:, :3]
+    for k, ck in (("rays_extension", "raysExtension"), ("rays_shadow", "raysShadow"), ("shade_hits", "shadeHits")):
+        assert abs(st[k] - cnt[ck]) <= 1e-3 * cnt[ck] + 2, (k, st[k], cnt[ck])
+    U.image_margins(f"general instance route vs the oracle path by path, {kind}, 96x54, 32 spp", a, ref, spp, b.camera, 1e-3, 1e-3)
+    close = np.isclose(a, ref, rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1)
+    U.record_margin(f"general instance route, {kind}: pixels within 1e-3 of the oracle", fraction=float(close.mean()), gate=0.97)
+    assert close.mean() > 0.97, close.mean()
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_production_render_matches_oracle(gpu, case):
     """Counter PRNG: the GPU and the oracle draw identical random numbers per (pixel, sample, depth, dim), so

@@ -6,6 +6,7 @@
 #          quick  = bench.py without the CPU / frame legs      -> gpurun_out/<tag>/bench_quick.json
 #          stats  = tools/trace_stats.py (needs variants/libptamd_stats.so)
 #          try:a,b = tools/try.sh a b (variant libraries)
+#          "cmd:NAME=command line" = any command, output -> gpurun_out/<tag>/NAME.txt (STEP_TIMEOUT seconds, default 600)
 # A step that is killed by its timeout ends the session (no further GPU work after a hang).
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -35,6 +36,9 @@ import json; d=json.load(open('$out/frame_${step#vframe:}.json')); print('${step
     stats:*) PTAMD_LIB=$PWD/opencl-path-tracer_amd/csrc/variants/libptamd_${step#stats:}.so timeout -k 10 300 python tools/trace_stats.py > $out/trace_${step#stats:}.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/trace_${step#stats:}.txt | cut -c1-330 | tail -32 ;;
     stats) timeout -k 10 300 python tools/trace_stats.py > $out/trace_stats.txt 2>&1; rc=$?; tail -30 $out/trace_stats.txt ;;
     try:*) timeout -k 10 600 tools/try.sh $(echo ${step#try:} | tr , ' ') > $out/try.txt 2>&1; rc=$?; cat $out/try.txt ;;
+    cmd:*) # cmd:NAME=command line (quote the whole step): output -> gpurun_out/<tag>/NAME.txt, the last 25 lines echoed
+      spec=${step#cmd:}; name=${spec%%=*}; line=${spec#*=}
+      timeout -k 10 ${STEP_TIMEOUT:-600} bash -c "$line" > $out/$name.txt 2>&1; rc=$?; grep -v amdgpu.ids $out/$name.txt | tail -${STEP_TAIL:-25} | cut -c1-400 ;;
     *) echo "unknown step $step"; rc=0 ;;
   esac
   echo "[$step] rc=$rc"
