@@ -570,14 +570,14 @@ def dynamic_refit_times(D, H, L, scenes, W, Hh, device, ticks=10):
 
 def two_level_general_times(D, scenes, W, Hh, level, device, in_flight, only=None, ways=("entered", "entered_parked", "default_flags", "copied")):
     """traceRay's GENERAL case (scene.cl:116-139 enters any 4 x 4 inverse transform, any number of instances) timed, not only tested.
-    320 instances of the two 82 k-triangle meshes (26 M instanced triangles; 2.6 GB as world-space copies: over the library's 2 GB copy budget)
+    432 instances of the two 82 k-triangle meshes (35 M instanced triangles; ~2.5 GB as world-space copies: over the library's 2 GB copy budget)
     under config 4's camera, each turned about the vertical axis and scaled by three different factors; and 208 translated + uniformly scaled
     ones (more than the 95 the fold table holds).  Each scene four ways: every instance entered by the round-6 route (leaf-kind entry steps,
     nothing parked), by the parked route of rounds 2-5 (PT_FLAG_PARKED_INSTANCES), the library's default (copies while the budget lasts), and
     every instance copied to world space with the budget raised (PTAMD_BAKE_BUDGET_GB: what instancing exists to avoid -- the per-ray rate it
     reaches is the yardstick)."""
     res = {}
-    for name, kw, n_inst in (("general_320", dict(nx=20, nz=16, transform="general"), 320), ("uniform_208", dict(nx=16, nz=13, transform="uniform"), 208)):
+    for name, kw, n_inst in (("general_432", dict(nx=24, nz=18, transform="general"), 432), ("uniform_208", dict(nx=16, nz=13, transform="uniform"), 208)):
         if only and name not in only:
             continue
         crowd = scenes.instanced_crowd(W, Hh, level=level, **kw)
@@ -889,7 +889,7 @@ def main():
                                "mesh instances entered at traversal, single-leaf meshes copied (PT_FLAG_TWO_LEVEL_ONLY)" if args.flags & 4 else
                                "instances copied to world space at upload (the library's default while they fit a 2 GB budget; the `two_level` "
                                "object times the same scene with the instances entered instead)"),
-                "scene_flags": args.flags,
+                "scene_flags": args.flags, "csrc_sha256": csrc_sha256(),
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
                 "resident_gb": round(resident_bytes(in_flight, owned) / 1e9, 1),  # queues + accumulator planes of this rank (164 B per entry, 16 B per plane and pixel)
@@ -901,6 +901,8 @@ def main():
             "rays": {"extension": int(ext), "shadow": int(shadow), "primary": int(gen), "shade_hits": int(hits), "deposits": int(deposits)},
             "timed_region_s": round(elapsed, 3),
             "image_mean_radiance": round(image_mean, 5),
+            # the headline is a MIX: camera rays (coherent, bundles of 4 x 64) / bounce rays / shadow rays, with the rate inside the kernel that traces each class
+            "rays_by_class": roofline["rays_by_class"] if roofline else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame": frame,
@@ -913,6 +915,30 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def csrc_sha256():
+    """Fingerprint of the device library's sources + compiler flags (ptamd.build.csrc_fingerprint): goes into config.csrc_sha256 of every line, from where
+    tools/traffic_json.py copies it into the traffic*.json made from the same session's PMC passes."""
+    from ptamd import build as B
+    return B.csrc_fingerprint()
+
+
+def apply_traffic(k, name, tj, stale):
+    """The counter half of a kernel's roofline entry from a committed traffic*.json: HBM bytes per unit always (flagged by the caller when stale), the
+    issue-port figures (valu_*, wave_cycles_*) only when the counters were taken on THIS build -- they describe the instruction stream, and a changed
+    kernel invalidates them."""
+    if tj and name in tj.get("kernels", {}):
+        k["traffic_bytes_per_unit"] = tj["kernels"][name]["bytes_per_unit"]["total"]
+        k["traffic"] = round(k["traffic_bytes_per_unit"] * k["units_per_launch"])
+    if tj and not stale and name in tj.get("issue", {}):
+        k.update(tj["issue"][name])  # valu_issue_frac, active lanes (PMC)
+    return k
+
+
+def traffic_is_stale(tj, fingerprint):
+    """True when the counters in `tj` were not taken on the build with this fingerprint (or do not say which build they were taken on)."""
+    return bool(tj) and tj.get("csrc_sha256") != fingerprint
 
 
 def newest_traffic_json(W, Hh, level, in_flight, world, flags=0):
@@ -943,6 +969,7 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
     batches = spp_step // in_flight
     packets = ps["packet_launches"] > 0  # primary rays went through k_trace_packet
     tj = newest_traffic_json(W, Hh, args.level, in_flight, world, args.flags)
+    stale = traffic_is_stale(tj, csrc_sha256())
     kernels = {}
 
     def add(name, what, ms, launches, units, bytes_per_unit, extra_bytes=0.0):
@@ -953,12 +980,7 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
              "units_per_launch": int(units / launches), "algorithmic_bytes_per_unit": round(bytes_per_unit + extra_bytes / units, 2),
              "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "munits_per_s": round(units / ms / 1e3, 1),
              "traffic": None}
-        if tj and name in tj.get("kernels", {}):
-            k["traffic_bytes_per_unit"] = tj["kernels"][name]["bytes_per_unit"]["total"]
-            k["traffic"] = round(k["traffic_bytes_per_unit"] * units / launches)
-        if tj and name in tj.get("issue", {}):
-            k.update(tj["issue"][name])  # valu_issue_frac, active lanes (PMC)
-        kernels[name] = k
+        kernels[name] = apply_traffic(k, name, tj, stale)
 
     primary = ps["rays_generated"] if packets else 0
     fused = packets and ps["ms_gen"] < 0.05 * batches  # the packet kernel generated (and queued) the primary rays itself: no k_gen launch
@@ -1000,6 +1022,9 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
     return {"bound": "hbm", "kernel": f"{dominant} ({dk['computes']}; largest share of device time)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": dk["traffic"],
+            # the counters (traffic, valu_*, wave_cycles_*) come from the committed PMC passes named in traffic_note; true: they were taken on ANOTHER build of
+            # csrc/ than the one timed here (config.csrc_sha256) -- the HBM bytes are then quoted as an indication, the issue-port figures dropped
+            "traffic_stale": stale if tj else None, "traffic_build": (tj or {}).get("csrc_sha256"),
             "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
             "whole_path_achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2),
             "traffic_note": (f"HBM bytes per launch = bytes per unit from the FETCH_SIZE / WRITE_SIZE PMC passes of this exact configuration "
@@ -1011,7 +1036,8 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
             # waves were doing (SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES), from the committed PMC passes
             "valu_busy": dk.get("valu_busy"), "valu_active_lanes": dk.get("valu_active_lanes"),
             "wave_cycles_issuing": dk.get("wave_cycles_issuing"), "wave_cycles_waiting": dk.get("wave_cycles_waiting"),
-            "mrays_per_s_in_kernel": round(ps["rays_extension"] / ps["ms_intersect"] / 1e3, 1),
+            "mrays_per_s_in_kernel": dk["munits_per_s"],  # of THIS kernel (rounds 1-5 quoted the closest-hit family here: see rays_by_class of the line)
+            "rays_by_class": rays_by_class(ps),
             "kernels": kernels,
             "family_ms": {"gen": round(ps["ms_gen"], 3), "intersect": round(ps["ms_intersect"], 3),
                           "shade": round(ps["ms_shade"], 3), "shadow": round(ps["ms_shadow"], 3)}}

@@ -63,20 +63,60 @@ __device__ inline void bundleBeam(const V3 co, V3 mLo, V3 mHi, bool nx, bool ny,
     ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
 }
 
+// LENS (round 6): bundles of a THIN-LENS camera (camera.cl:54-77).  The R x 64 rays leave from all over the lens and meet -- up to the pixels' footprints -- on the
+// focal plane, which their un-normalised directions put at t = 1: a converging bundle.  Its beam is k_trace_packet's double cone (pt_packet.h): built around the rays'
+// points at t = 1 (the waist) instead of their origins, every distance of the node test measured from there (t' = t - 1).  A lane keeps R origins next to its R
+// directions (3 (R - 1) registers more), a leaf runs the whole Moeller-Trumbore test per ray (no origin half to share).
+// Per lane: the interval of its rays' points at t = 1, each widened by the round-off of the sum that made it
+template <int R>
+__device__ inline void bundleWaist(const V3 (&o)[R], const V3 (&d)[R], V3& pLo, V3& pHi)
+{
+    pLo = mk(INFINITY), pHi = mk(-INFINITY);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const V3 p = mk(o[r].x + d[r].x, o[r].y + d[r].y, o[r].z + d[r].z);
+        const V3 e = mk((fabsf(o[r].x) + fabsf(d[r].x)) * 0x1p-22f, (fabsf(o[r].y) + fabsf(d[r].y)) * 0x1p-22f, (fabsf(o[r].z) + fabsf(d[r].z)) * 0x1p-22f);
+        pLo = mk(fminf(pLo.x, p.x - e.x), fminf(pLo.y, p.y - e.y), fminf(pLo.z, p.z - e.z));
+        pHi = mk(fmaxf(pHi.x, p.x + e.x), fmaxf(pHi.y, p.y + e.y), fmaxf(pHi.z, p.z + e.z));
+    }
+}
+// the constants of the lane's role in the node test for a converging bundle (beamSetup, pt_packet.h, with the lanes' own intervals already folded over their R rays);
+// `corner`: the waist corner the role measures from (kept by the caller: a translated + scaled instance moves it)
+__device__ inline void bundleBeamLens(V3 pLo, V3 pHi, V3 mLo, V3 mHi, bool nx, bool ny, bool nz, uint32_t axis, uint32_t isFar, float& S, float& negSO, float& mulPos,
+    float& mulNeg, uint32_t& ofsQ, float& corner)
+{
+    waveMin3Max3(pLo.x, pLo.y, pLo.z, pHi.x, pHi.y, pHi.z);
+    waveMin3Max3(mLo.x, mLo.y, mLo.z, mHi.x, mHi.y, mHi.z);
+    const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+    const float pLoA = axis == 0u ? pLo.x : (axis == 1u ? pLo.y : pLo.z), pHiA = axis == 0u ? pHi.x : (axis == 1u ? pHi.y : pHi.z);
+    const float mLoA = (axis == 0u ? mLo.x : (axis == 1u ? mLo.y : mLo.z)) * (1.f - 1.f / 262144.f);
+    const float mHiA = (axis == 0u ? mHi.x : (axis == 1u ? mHi.y : mHi.z)) * (1.f + 1.f / 262144.f);
+    S = neg ? -1.f : 1.f;
+    corner = (neg != (isFar != 0u)) ? pLoA : pHiA;
+    negSO = -(S * corner);
+    mulPos = isFar ? -mHiA : mLoA, mulNeg = isFar ? -mLoA : mHiA;
+    ofsQ = 16u + 4u * (2u * axis + ((neg ? 1u : 0u) ^ isFar));
+}
+
 // TWO_LEVEL: the tree holds instance references (k_trace_packet's scheme, pt_packet.h).  Entering an instance is a wave-uniform event: every
 // lane takes its origin and its R directions into the instance's space, the beam is rebuilt from them, a sentinel goes onto the stack;
 // popping it brings the world-space rays and beam back from LDS (8 + 3 R dwords per lane).  Which instance a ray's closest hit lies in
 // is kept in LDS too (written when a hit is accepted -- a few times per ray -- instead of R more registers).  A transform that turns the
 // bundle into more than one octant ends the beam walk: the bundle starts over, sub-packet by sub-packet.
-template <int R, bool TWO_LEVEL>
+template <int R, bool TWO_LEVEL, bool LENS = false>
 #ifndef PT_MULTI_MIN_WAVES_TL
 #define PT_MULTI_MIN_WAVES_TL (PT_MULTI_MIN_WAVES > 4 ? 4 : PT_MULTI_MIN_WAVES) // the instantiation that enters instances: at 5 waves per SIMD (96 VGPRs) it spilled 16 registers
     // inside the node loop -- 44 more vector loads per bundle, all scratch (SQ_INSTS_VMEM_RD +78 % for +9 % vector instructions: profiles/round5/) -- and took
     // 25.4 instead of 17.7 ms per batch; at 4 waves (113 VGPRs, nothing spilled) 20.5
 #endif
-__global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES) k_trace_multi(TraceArgs a)
+#ifndef PT_MULTI_MIN_WAVES_LENS
+#define PT_MULTI_MIN_WAVES_LENS 4 // R origins per lane: 105-120 VGPRs
+#endif
+__global__ void __launch_bounds__(kPacketBlock, LENS ? PT_MULTI_MIN_WAVES_LENS : (TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES)) k_trace_multi(TraceArgs a)
 {
-    constexpr int kSaveRay = 0, kSaveBeam = 3 + 3 * R, kSaveInst = kSaveBeam + 5, kSave = kSaveInst + R;
+    constexpr int RO = LENS ? R : 1; // origins a lane keeps
+    constexpr float tShift = LENS ? 1.0f : 0.0f; // the node test's distances are measured from the bundle's waist (t' = t - tShift)
+    constexpr int kSaveRay = 0, kSaveBeam = 3 * RO + 3 * R, kSaveInst = kSaveBeam + 5, kSave = kSaveInst + R;
     __shared__ uint32_t ldsSave[TWO_LEVEL ? kPacketBlock / 64 : 1][TWO_LEVEL ? kSave : 1][64];
     const uint32_t pwave = threadIdx.x >> 6;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -119,7 +159,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
         spanLeft--;
 
         // ---- the lane's R camera rays (entries base + 64 r + lane: consecutive lanes write consecutive queue entries) -------------
-        V3 co = mk(0.f), cd[R];
+        V3 co[RO], cd[R];
         float tClosest[R], hu[R], hv[R];
         int hprim[R];
         bool whole = true; // wave-uniform: every ray exists, one origin, one octant
@@ -148,14 +188,15 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
             if (o.x == 0.0f) o.x = -FLT_MIN;
             if (o.y == 0.0f) o.y = -FLT_MIN;
             if (o.z == 0.0f) o.z = -FLT_MIN;
-            if (r == 0)
-                co = o;
+            if (LENS || r == 0)
+                co[LENS ? r : 0] = o;
             cd[r] = d;
             tClosest[r] = INFINITY, hu[r] = hv[r] = 0.f, hprim[r] = -1;
             if constexpr (TWO_LEVEL)
                 ldsSave[pwave][kSaveInst + r][lane] = 0xFFFFFFFFu;
-            whole = whole && __builtin_amdgcn_ballot_w64(active) == ~0ull
-                && __builtin_amdgcn_ballot_w64(o.x != asF(uni(asU(co.x))) || o.y != asF(uni(asU(co.y))) || o.z != asF(uni(asU(co.z)))) == 0ull;
+            whole = whole && __builtin_amdgcn_ballot_w64(active) == ~0ull;
+            if constexpr (!LENS) // one origin for the whole bundle
+                whole = whole && __builtin_amdgcn_ballot_w64(o.x != asF(uni(asU(co[0].x))) || o.y != asF(uni(asU(co[0].y))) || o.z != asF(uni(asU(co[0].z)))) == 0ull;
         }
         V3 mLo, mHi;
         bool nx, ny, nz;
@@ -165,16 +206,24 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
             // ---- beam walk (pt_packet.h) for the bundle of R x 64 rays ---------------------------------------------------------------
             const uint32_t role = lane & 7u, child = (lane >> 3) & 3u, axis = min(role >> 1, 2u), isFar = role & 1u;
             const uint32_t ofsO = 4u * axis, ofsE = axis == 0u ? 12u : 36u + 4u * axis, shift = 8u * child; // (the lane's origin component / scale: WideNode, pt_device.h)
-            float S, negSO, mulPos, mulNeg;
+            float S, negSO, mulPos, mulNeg, corner = 0.f;
             uint32_t ofsQ;
-            bundleBeam(co, mLo, mHi, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+            if constexpr (LENS) {
+                V3 pLo, pHi;
+                bundleWaist<R>(co, cd, pLo, pHi);
+                bundleBeamLens(pLo, pHi, mLo, mHi, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ, corner);
+            } else {
+                bundleBeam(co[0], mLo, mHi, nx, ny, nz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+            }
             int curInst = -1; // wave-uniform
             if constexpr (TWO_LEVEL) { // the world-space rays and beam, for the way back out of an instance
-                ldsSave[pwave][kSaveRay + 0][lane] = asU(co.x), ldsSave[pwave][kSaveRay + 1][lane] = asU(co.y), ldsSave[pwave][kSaveRay + 2][lane] = asU(co.z);
+#pragma unroll
+                for (int r = 0; r < RO; r++)
+                    ldsSave[pwave][kSaveRay + 3 * r][lane] = asU(co[r].x), ldsSave[pwave][kSaveRay + 3 * r + 1][lane] = asU(co[r].y), ldsSave[pwave][kSaveRay + 3 * r + 2][lane] = asU(co[r].z);
 #pragma unroll
                 for (int r = 0; r < R; r++)
-                    ldsSave[pwave][kSaveRay + 3 + 3 * r][lane] = asU(cd[r].x), ldsSave[pwave][kSaveRay + 4 + 3 * r][lane] = asU(cd[r].y),
-                                  ldsSave[pwave][kSaveRay + 5 + 3 * r][lane] = asU(cd[r].z);
+                    ldsSave[pwave][kSaveRay + 3 * RO + 3 * r][lane] = asU(cd[r].x), ldsSave[pwave][kSaveRay + 3 * RO + 1 + 3 * r][lane] = asU(cd[r].y),
+                                  ldsSave[pwave][kSaveRay + 3 * RO + 2 + 3 * r][lane] = asU(cd[r].z);
                 ldsSave[pwave][kSaveBeam + 0][lane] = asU(S), ldsSave[pwave][kSaveBeam + 1][lane] = asU(negSO), ldsSave[pwave][kSaveBeam + 2][lane] = asU(mulPos);
                 ldsSave[pwave][kSaveBeam + 3][lane] = asU(mulNeg), ldsSave[pwave][kSaveBeam + 4][lane] = ofsQ;
             }
@@ -206,29 +255,47 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                             // again: one FMA per origin component, one product per direction component (rayIntoInstance's results for such a matrix, bit
                             // for bit, minus its zero-component nudges, as in the per-ray kernels' folded route), two products for the role's multipliers
                             // (1 ulp each against the 2^-18 of slack they carry)
-                            co = mk(fmaf(r0.x, co.x, r0.w), fmaf(r1.y, co.y, r1.w), fmaf(r2.z, co.z, r2.w));
+#pragma unroll
+                            for (int r = 0; r < RO; r++)
+                                co[r] = mk(fmaf(r0.x, co[r].x, r0.w), fmaf(r1.y, co[r].y, r1.w), fmaf(r2.z, co[r].z, r2.w));
 #pragma unroll
                             for (int r = 0; r < R; r++)
                                 cd[r] = mk(r0.x * cd[r].x, r1.y * cd[r].y, r2.z * cd[r].z);
                             const float scl = rcpFast(r0.x);
-                            negSO = -(S * (axis == 0u ? co.x : (axis == 1u ? co.y : co.z)));
+                            if constexpr (LENS) { // the waist moves with the rays (t is shared between the spaces: it stays at t = 1); a little outwards for the round-off of the map
+                                const float wA = axis == 0u ? r0.w : (axis == 1u ? r1.w : r2.w);
+                                const float c = fmaf(r0.x, corner, wA);
+                                const float e = (fabsf(r0.x * corner) + fabsf(wA)) * 0x1p-22f;
+                                negSO = isFar ? -(S * c) + e : -(S * c) - e; // g = S * plane + negSO: entry lanes bound from below (smaller is safe), exit lanes from above
+                            } else {
+                                negSO = -(S * (axis == 0u ? co[0].x : (axis == 1u ? co[0].y : co[0].z)));
+                            }
                             mulPos *= scl, mulNeg *= scl;
                         } else {
-                            V3 to = co, td[R];
+                            V3 to[RO], td[R];
 #pragma unroll
                             for (int r = 0; r < R; r++)
-                                rayIntoInstance(r0, r1, r2, co, cd[r], &to, &td[r]); // (the origin is the same R times: folded by the compiler)
+                                rayIntoInstance(r0, r1, r2, co[LENS ? r : 0], cd[r], &to[LENS ? r : 0], &td[r]); // (a pinhole's origin is the same R times: folded by the compiler)
                             V3 tLo, tHi;
                             bool tnx, tny, tnz;
                             if (!bundleOctant<R>(td, tLo, tHi, tnx, tny, tnz)) {
                                 whole = false; // the bundle no longer points into one octant: start over, sub-packet by sub-packet
                                 break;
                             }
-                            co = to;
+#pragma unroll
+                            for (int r = 0; r < RO; r++)
+                                co[r] = to[r];
 #pragma unroll
                             for (int r = 0; r < R; r++)
                                 cd[r] = td[r];
-                            bundleBeam(co, tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                            if constexpr (LENS) {
+                                V3 pLo, pHi;
+                                float cornerInst; // (`corner` stays the world-space one: the sentinel brings the world-space beam back)
+                                bundleWaist<R>(co, cd, pLo, pHi);
+                                bundleBeamLens(pLo, pHi, tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ, cornerInst);
+                            } else {
+                                bundleBeam(co[0], tLo, tHi, tnx, tny, tnz, axis, isFar, S, negSO, mulPos, mulNeg, ofsQ);
+                            }
                         }
                         curInst = (int)refIndex(cur);
                         stRef = laneWrite(stRef, kRefLeaveInstance, uni(sp));
@@ -237,10 +304,13 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                         continue;
                     }
                     // -------- the sentinel: back to the world-space rays and beam -------------------------------------------------------
-                    co = mk(asF(ldsSave[pwave][kSaveRay + 0][lane]), asF(ldsSave[pwave][kSaveRay + 1][lane]), asF(ldsSave[pwave][kSaveRay + 2][lane]));
+#pragma unroll
+                    for (int r = 0; r < RO; r++)
+                        co[r] = mk(asF(ldsSave[pwave][kSaveRay + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 3 * r + 1][lane]), asF(ldsSave[pwave][kSaveRay + 3 * r + 2][lane]));
 #pragma unroll
                     for (int r = 0; r < R; r++)
-                        cd[r] = mk(asF(ldsSave[pwave][kSaveRay + 3 + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 4 + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 5 + 3 * r][lane]));
+                        cd[r] = mk(asF(ldsSave[pwave][kSaveRay + 3 * RO + 3 * r][lane]), asF(ldsSave[pwave][kSaveRay + 3 * RO + 1 + 3 * r][lane]),
+                            asF(ldsSave[pwave][kSaveRay + 3 * RO + 2 + 3 * r][lane]));
                     S = asF(ldsSave[pwave][kSaveBeam + 0][lane]), negSO = asF(ldsSave[pwave][kSaveBeam + 1][lane]), mulPos = asF(ldsSave[pwave][kSaveBeam + 2][lane]);
                     mulNeg = asF(ldsSave[pwave][kSaveBeam + 3][lane]), ofsQ = ldsSave[pwave][kSaveBeam + 4][lane];
                     curInst = -1;
@@ -257,8 +327,9 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                     v = maxRowShr2(v);
                     v = maxRowShr2(v); // lanes 4 / 5 of the group: max over the axes of the entry bounds / of the negated exit bounds
                     const float tn = rowShr1(v); // lane 5: the entry bound from lane 4
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= 0.f) & __builtin_amdgcn_ballot_w64(tn < tcMax);
-                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn), 0); // bits of max(tn, 0): negative floats are negative integers
+                    // (LENS: exit >= 0 and entry < culling distance in t, i.e. exit' >= -tShift and entry' < tcMax - tShift: pt_packet.h)
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(tn + v <= 0.f) & __builtin_amdgcn_ballot_w64(v <= tShift) & __builtin_amdgcn_ballot_w64(tn < tcMax);
+                    const uint32_t tloBits = (uint32_t)max((int32_t)asU(tn + tShift), 0); // bits of max(entry, 0): negative floats are negative integers
                     uint32_t key[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
@@ -287,13 +358,16 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                         const u4v ta = trisS[(first + k) * 3u + 0u], tb = trisS[(first + k) * 3u + 1u];
                         const uint32_t tcx = trisS[(first + k) * 3u + 2u].x;
                         const V3 v0 = mk(asF(ta.x), asF(ta.y), asF(ta.z)), e1 = mk(asF(ta.w), asF(tb.x), asF(tb.y)), e2 = mk(asF(tb.z), asF(tb.w), asF(tcx));
-                        // the half of Moeller-Trumbore that only knows the origin: once per triangle
+                        // the half of Moeller-Trumbore that only knows the origin: once per triangle (LENS: per ray -- every ray has its own)
                         V3 T, Q;
                         float e2Q;
-                        triOriginHalf(co, v0, e1, e2, &T, &Q, &e2Q);
+                        if constexpr (!LENS)
+                            triOriginHalf(co[0], v0, e1, e2, &T, &Q, &e2Q);
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             float det, u, v, t;
+                            if constexpr (LENS)
+                                triOriginHalf(co[r], v0, e1, e2, &T, &Q, &e2Q);
                             triRayHalf(cd[r], e1, e2, T, Q, e2Q, &det, &u, &v, &t);
                             const bool hit = !(det > -FLT_MIN && det < FLT_MIN) && !(u < 0.f || u > 1.f) && !(v < 0.f || u + v > 1.f) && t > 0.f && t < tClosest[r];
                             if (hit) {
@@ -314,7 +388,7 @@ __global__ void __launch_bounds__(kPacketBlock, TWO_LEVEL ? PT_MULTI_MIN_WAVES_T
                         for (int r = 1; r < R; r++)
                             far = fmaxf(far, tClosest[r]);
                         if (__builtin_amdgcn_ballot_w64(far == INFINITY) == 0ull)
-                            tcMax = asF(uni(asU(waveMax(far))));
+                            tcMax = LENS ? asF(uni(asU(waveMax(far)))) * (1.0f + 0x1p-20f) - tShift : asF(uni(asU(waveMax(far))));
                     }
                 }
                 if (sp == 0u)

@@ -270,6 +270,9 @@ constexpr int kObjPlanes = 9; // origin xyz, 1 / direction xyz, direction xyz
 template <bool ANY_HIT, int LEVELS>
 __global__ void __launch_bounds__(kTraceBlock, LEVELS == 2 ? PT_TRACE_MIN_WAVES_GEN : (LEVELS == 1 ? PT_TRACE_MIN_WAVES_TL : PT_TRACE_MIN_WAVES)) k_trace(TraceArgs a)
 {
+    // (Measured in round 6 and not kept: LEVELS 1 with the table of folded transforms read from GLOBAL memory past 95 entries -- 32 bytes per entry, two more
+    // vector loads per object-space step, no entry step, the staged packet kept: 8 431 against 8 361 Mrays/s for LEVELS 2 on 208 translated + uniformly
+    // scaled instances: one mechanism instead of two.)
     constexpr bool TWO_LEVEL = LEVELS == 1, GENERAL = LEVELS == 2;
     constexpr bool STAGED = !GENERAL; // the next 64 queue entries of the wave copied into LDS ahead of the hand-out
     constexpr int kLdsStack = GENERAL ? PT_LDS_STACK_GEN : (TWO_LEVEL ? kLdsStackTL : ptd::kLdsStack); // (shadows the namespace constant inside this kernel)

@@ -227,7 +227,7 @@ struct pt_ctx {
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks[2] = { 0, 0 };
-    uint32_t multiBlocks[2] = { 0, 0 }; // persistent grid of k_trace_multi [without | with instance references in the tree]
+    uint32_t multiBlocks[4] = { 0, 0, 0, 0 }; // persistent grid of k_trace_multi [without | with instance references in the tree], [2], [3]: the same for a thin-lens camera's converging bundles
     // live entries per pass of the most recent batch whose counters have come back (a HINT for the next batch's k_shade launches:
     // copied to pinned memory by the stream at the end of every batch, never waited for)
     uint32_t* passCountsPinned = nullptr; // kMaxPasses + 1 words
@@ -1192,8 +1192,8 @@ int ensureSpill(pt_ctx* c)
         if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) // diagnostics: a smaller persistent grid leaves wave slots to kernels of other streams / processes
             blocksPerCU = std::max(1, std::min(blocksPerCU, atoi(e)));
         c->traceBlocks[tl] = (uint32_t)(blocksPerCU * c->numCUs);
-        if (tl == 2)
-            break; // (the packet kernels know two kinds of scene)
+        if (tl >= 2)
+            continue; // (the packet kernels know two kinds of scene)
         int pb = 8;
         for (const void* fn : packetVariants[tl]) {
             int b = 0;
@@ -1211,6 +1211,10 @@ int ensureSpill(pt_ctx* c)
         c->multiBlocks[0] = (uint32_t)(std::max(1, b) * c->numCUs);
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, true>, kPacketBlock, 0));
         c->multiBlocks[1] = (uint32_t)(std::max(1, b) * c->numCUs);
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, false, true>, kPacketBlock, 0));
+        c->multiBlocks[2] = (uint32_t)(std::max(1, b) * c->numCUs);
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k_trace_multi<PT_MULTI_RAYS, true, true>, kPacketBlock, 0));
+        c->multiBlocks[3] = (uint32_t)(std::max(1, b) * c->numCUs);
         if (const char* e = getenv("PTAMD_PACKET_BLOCKS_PER_CU")) // the documented knob reaches the bundle kernel too
             for (uint32_t& mb : c->multiBlocks)
                 mb = std::max(1u, std::min(mb, (uint32_t)std::max(1, atoi(e)) * (uint32_t)c->numCUs));
@@ -1410,7 +1414,16 @@ void launchPacket(pt_ctx* c, bool anyHit, const TraceArgs& a)
 }
 
 // first pass of a batch: may the camera rays be generated inside k_trace_multi and walk the tree as bundles (pinhole camera)?
-inline bool primaryBundles(const pt_ctx* c) { return PT_MULTI_RAYS > 1 && !c->camera.thinLens && !(c->packetUse & 8u) && c->dyn[c->active].packetOk && (c->packetUse & 1u); }
+// (thin-lens cameras too since round 6: converging bundles, pt_packet_multi.h LENS; PTAMD_LENS_BUNDLES=0: packets of 64 as in rounds 3-5)
+inline bool lensBundles()
+{
+    static const bool on = !(getenv("PTAMD_LENS_BUNDLES") && atoi(getenv("PTAMD_LENS_BUNDLES")) == 0);
+    return on;
+}
+inline bool primaryBundles(const pt_ctx* c)
+{
+    return PT_MULTI_RAYS > 1 && (!c->camera.thinLens || lensBundles()) && !(c->packetUse & 8u) && c->dyn[c->active].packetOk && (c->packetUse & 1u);
+}
 // are consecutive entries of the first queue of a batch rays of one pixel or of neighbouring pixels?  >= 16 samples of a pixel next to each other, or the
 // pixels of a 1-spp frame in the order of the pixel list (8 x 8 blocks unless the caller chose otherwise) where bundles of 256 serve them
 inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
@@ -1438,7 +1451,13 @@ void launchIntersect(pt_ctx* c, int q, uint32_t pass, bool coherent = false, con
             a.noOrigins = noOrigins ? 1u : 0u;
             c->packetLaunches++;
             c->bundleLaunches++;
-            if (sceneKind(c) != 0)
+            if (c->camera.thinLens) { // converging bundles: every ray its own origin (which stays in the queue: k_shade cannot derive it)
+                a.noOrigins = 0u;
+                if (sceneKind(c) != 0)
+                    hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, true, true>), dim3(c->multiBlocks[3]), dim3(kPacketBlock), 0, c->stream, a);
+                else
+                    hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, false, true>), dim3(c->multiBlocks[2]), dim3(kPacketBlock), 0, c->stream, a);
+            } else if (sceneKind(c) != 0)
                 hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, true>), dim3(c->multiBlocks[1]), dim3(kPacketBlock), 0, c->stream, a);
             else
                 hipLaunchKernelGGL((k_trace_multi<PT_MULTI_RAYS, false>), dim3(c->multiBlocks[0]), dim3(kPacketBlock), 0, c->stream, a);
@@ -1588,7 +1607,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     const bool fused = packetsFirst && PT_FUSED_PRIMARY && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
     // ... and where those are the bundles of a pinhole camera, only (direction, pixel) is queued: k_shade takes the eye as the origin and the sample from the
     // entry index (12 instructions; the full regeneration the paragraph above dismissed is 70) -- 16 B per camera ray less written and 16 B less read
-    const bool derived = fused && primaryBundles(c) && PT_DERIVED_PRIMARIES;
+    const bool derived = fused && primaryBundles(c) && !c->camera.thinLens && PT_DERIVED_PRIMARIES; // (a thin lens: every ray has an origin of its own, which stays in the queue)
     prof.begin(0);
     if (fused)
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, &c->control.p->extCount[0], &c->control.p->generated, entries);
@@ -2544,8 +2563,18 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         if (!(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES)) {
             for (uint32_t k = 0; k < hInst.size(); k++) // single leaves first
                 tryBake(k, false);
-            for (uint32_t k = 0; k < hInst.size(); k++)
-                tryBake(k, true);
+            // Whole trees: ALL of them or none (round 6).  A scene that is partly copied pays for both: every ray runs the kernels that can enter instances,
+            // and the copies' bytes push the shared trees out of the caches (432 instances of the 82 k-triangle meshes, 421 copied + 13 entered: 8 481 Mrays/s
+            // against 9 089 with all of them entered and 9 017 with all of them copied: profiles/round6/).
+            uint64_t allBytes = 0;
+            for (uint32_t k = 0; k < hInst.size(); k++) {
+                const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[k]];
+                if (refCount(root.ref) == 0u)
+                    allBytes += (uint64_t)root.numNodes * sizeof(WideNode) + (uint64_t)root.numRefs * sizeof(TriIsect);
+            }
+            if (allBytes <= budgetBytes)
+                for (uint32_t k = 0; k < hInst.size(); k++)
+                    tryBake(k, true);
         }
         out.bakedNodes = nextNode - (staticNodes + out.topSlots);
         out.bakedTris = nextTri - staticTris;
@@ -2681,9 +2710,12 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial)
                 entered++, enteredGeneral += simple(hInst[k]) ? 0u : 1u;
         out.enteredInstances = entered;
+        // A scene with FEW such instances among many translated + uniformly scaled ones (at most a quarter) that fits the table keeps the folded route
+        // for those -- no entry step at all -- and parks the few.
         static const char* envGeneral = getenv("PTAMD_GENERAL_ROUTE");
         const bool tableHolds = hInst.size() + 1 <= kInstFoldTable;
-        out.generalRoute = !parked && entered > 0u && (envGeneral ? atoi(envGeneral) != 0 : (enteredGeneral > 0u || !tableHolds));
+        const bool mostlySimple = enteredGeneral * 4u <= entered;
+        out.generalRoute = !parked && entered > 0u && (envGeneral ? atoi(envGeneral) != 0 : (!mostlySimple || !tableHolds));
         const bool noFold = parked || out.generalRoute || !tableHolds;
         std::vector<uint8_t> folded(hInst.size(), 0);
         for (size_t k = 0; k < hInst.size() && !noFold; k++)

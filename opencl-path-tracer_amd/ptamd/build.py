@@ -65,6 +65,19 @@ DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"
                 "-Xarch_device", "-fno-slp-vectorize"]
 
 
+def csrc_fingerprint(csrc_dir=None):
+    """sha256 over the device library's sources (csrc/*.hip, *.h: names and bytes, sorted) and its compiler flags: what a set of hardware counters
+    (profiles/roundN/traffic*.json) was taken on, and what bench.py holds them against before it quotes them (roofline.traffic_stale)."""
+    import hashlib
+    d = csrc_dir or CSRC_DIR
+    h = hashlib.sha256(" ".join(DEVICE_FLAGS).encode())
+    for name in sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h"))):
+        h.update(name.encode() + b"\0")
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build_device(force=False):
     out = os.path.join(CSRC_DIR, "libptamd.so")
     deps = _all_files(CSRC_DIR, (".hip", ".h")) + _all_files(os.path.join(ROOT, "..", "include"), (".h",))

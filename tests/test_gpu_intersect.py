@@ -222,18 +222,19 @@ def _rays_leaving_surfaces(ctx, W, Hh, per_pixel, seed, towards=None):
     return p.astype(np.float32), nd.astype(np.float32), (length - 2e-3).astype(np.float32)
 
 
-@pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated", "baked_thin_lens"])
+@pytest.mark.parametrize("kind", ["baked", "two_level", "unbaked_rotated", "baked_thin_lens", "two_level_thin_lens", "unbaked_rotated_thin_lens"])
 @pytest.mark.parametrize("spp", [64, 16])
 def test_first_pass_of_a_batch_finds_the_hits_of_the_per_ray_kernel(gpu, kind, spp):
     """pt_primary_pass runs the first pass of a batch the way pt_render does: the camera rays are generated inside the traversal kernel
-    and -- pinhole camera -- bundles of several packets (the samples of one pixel, or of a few neighbouring ones) walk the tree as ONE
-    bundle (pt_packet_multi.h).  The rays it queues for the shading kernel must be the bits k_gen writes, and every
+    and bundles of several packets (the samples of one pixel, or of a few neighbouring ones) walk the tree as ONE bundle (pt_packet_multi.h) --
+    a pinhole's around their common origin, a thin lens's (*thin_lens, round 6) as a converging bundle around its waist on the focal plane, every
+    lane keeping four origins.  The rays it queues for the shading kernel must be the bits k_gen writes, and every
     hit record the per-ray kernel's for that ray: same triangle and same t / u / v bits, except at exact-t ties."""
     W, Hh = 96, 54
     # two_level / unbaked_rotated: the bundle enters instances as a wave; behind a rotation some bundles point into more than one octant
     # and start over sub-packet by sub-packet
-    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=kind == "baked_thin_lens", sky_size=(16, 8), rotate=kind == "unbaked_rotated")
-    base = {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "unbaked_rotated": gpu.FLAG_NO_BAKED_INSTANCES}.get(kind, 0)
+    b = scenes.instanced_grid(W, Hh, level=4, thin_lens=kind.endswith("thin_lens"), sky_size=(16, 8), rotate=kind.startswith("unbaked_rotated"))
+    base = {"two_level": gpu.FLAG_TWO_LEVEL_ONLY, "unbaked_rotated": gpu.FLAG_NO_BAKED_INSTANCES}.get(kind.replace("_thin_lens", ""), 0)
     first = U.make_ctx(gpu, b, W, Hh, flags=base, samples_in_flight=spp)
     queued = U.make_ctx(gpu, b, W, Hh, flags=base | gpu.FLAG_QUEUE_PRIMARY_RAYS | gpu.FLAG_NO_PACKETS, samples_in_flight=spp)
     n = W * Hh * spp
@@ -253,7 +254,7 @@ def test_first_pass_of_a_batch_finds_the_hits_of_the_per_ray_kernel(gpu, kind, s
             assert np.array_equal(got[k][same].view(np.uint32), want[k][same].view(np.uint32)), k
         assert 0.3 < (got["prim"] >= 0).mean() < 1.0
     assert first.stats()["packet_launches"] == 2 and queued.stats()["packet_launches"] == 0
-    assert first.stats()["bundle_launches"] == (2 if kind != "baked_thin_lens" else 0)  # a thin lens has no common origin: packets of 64
+    assert first.stats()["bundle_launches"] == 2  # (rounds 3-5: a thin lens went through packets of 64)
     first.close()
     queued.close()
 
@@ -320,7 +321,7 @@ def test_thousand_instances_of_a_small_mesh(gpu, mode):
 @pytest.mark.parametrize("n", [60, 200])
 def test_translated_and_scaled_instances_around_the_fold_table(gpu, n):
     """The per-ray kernels walk translated + uniformly scaled instances without parking while the scene's instances fit the LDS table of their transforms
-    (95 entries, pt_trace.h); a scene with more falls back to the parked route for all of them.  Both sides of that limit, every instance entered
+    (95 entries, pt_trace.h); a scene with more takes the general route (round 6: leaf-kind entry steps; rounds 2-5: the parked route for all of them).  Both sides of that limit, every instance entered
     (PT_FLAG_NO_BAKED_INSTANCES): hits equal the oracle's, occlusion verdicts too, with mixed scales and a rotated instance in between (the general
     route and the folded one in one traversal)."""
     mat = L.material_pbr_dielectric((0.7, 0.3, 0.2), 0.6)
@@ -340,7 +341,10 @@ def test_translated_and_scaled_instances_around_the_fold_table(gpu, n):
     assert flat.num_instances == n
     ctx = gpu.Context(64, 36, flags=gpu.FLAG_NO_BAKED_INSTANCES)
     ctx.upload_scene(flat)
-    assert ctx.stats()["folded_instances"] == (n - 1 if n + 1 <= 96 else 0)
+    # 60: the kernels' LDS table holds the transforms, and one turned instance in 60 is few enough for the folded route to stay (that one parks); 200
+    # (round 6; rounds 2-5 parked them all): the general route, every instance entered as a leaf-kind step (pt_trace.h, LEVELS 2)
+    st = ctx.stats()
+    assert (st["folded_instances"], st["general_route"]) == ((n - 1, 0) if n + 1 <= 96 else (0, 1)), st
     sc = O.BoundScene(flat)
     o, d = U.random_rays(40000, n, (-side, 0.05, -side), (side, 3, side))
     got, want = ctx.intersect(o, d), O.intersect_batch(sc, o, d, threads=8)
@@ -557,7 +561,7 @@ def test_general_instance_route_finds_the_parked_routes_hits_bit_for_bit(gpu, sc
     assert 0.05 < occ_g.mean() < 0.95
     sc = U.oracle_scene(b)
     sub = slice(0, 30000)
-    info = U.compare_hits(b.flat, {k: v[sub] for k, v in general.intersect(o, d).items()}, O.intersect_batch(sc, o[sub], d[sub], threads=8))
+    info = U.compare_hits(b.flat, general.intersect(o[sub], d[sub]), O.intersect_batch(sc, o[sub], d[sub], threads=8))
     assert info["n"] > 5000 and info["flips"] == 0
     ref = O.intersect_batch(sc, o[sub], d[sub], tmax=tmax[sub], any_hit=True, threads=8)["prim"]
     assert (occ_g[sub] != ref).sum() <= 3

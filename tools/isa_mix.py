@@ -20,10 +20,10 @@ FULL = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_f
         "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_add_co_u32", "v_addc_co_u32",
         "v_sub_co_u32", "v_subb_co_u32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"}
 QUARTER = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
-# <any hit, two level>: the names without a second argument are the instantiations for scenes that are one world-space tree (the headline)
-KERNELS = {"k_traceILb1ELb0ELb0": "k_trace<true>", "k_traceILb0ELb0ELb0": "k_trace<false>", "k_traceILb1ELb1ELb0": "k_trace<true, two-level>",
-           "k_traceILb0ELb1ELb0": "k_trace<false, two-level>", "k_traceILb1ELb0ELb1": "k_trace<true, start states>", "k_traceILb0ELb0ELb1": "k_trace<false, start states>",
-           "k_descendILb1E": "k_descend<true>", "k_descendILb0E": "k_descend<false>", "k_trace_packetILb0ELb0": "k_trace_packet<false>",
+# <any hit, LEVELS> (round 6; rounds 2-5: <any hit, two level[, start states]>): the names without a second argument are the instantiations for scenes that are one world-space tree (the headline)
+KERNELS = {"k_traceILb1ELi0E": "k_trace<true>", "k_traceILb0ELi0E": "k_trace<false>", "k_traceILb1ELi1E": "k_trace<true, two-level>",
+           "k_traceILb0ELi1E": "k_trace<false, two-level>", "k_traceILb1ELi2E": "k_trace<true, general>", "k_traceILb0ELi2E": "k_trace<false, general>",
+           "k_trace_packetILb0ELb0": "k_trace_packet<false>",
            "k_trace_packetILb0ELb1": "k_trace_packet<false, two-level>", "k_trace_multiILi4ELb0": "k_trace_multi<4>",
            "k_trace_multiILi4ELb1": "k_trace_multi<4, two-level>", "k_shadeILb0ELb0ELb0": "k_shade<false>",
            "k_shadeILb0ELb1ELb0": "k_shade<false, general>", "5k_genE": "k_gen", "k_fold_planes": "k_fold_planes", "k_resolve": "k_resolve"}

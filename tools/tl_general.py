@@ -1,6 +1,6 @@
-"""GPU box: bench.py's `two_level_general` object alone (320 turned + non-uniformly scaled / 208 translated + uniformly scaled instances of the 82 k-triangle
+"""GPU box: bench.py's `two_level_general` object alone (432 turned + non-uniformly scaled / 208 translated + uniformly scaled instances of the 82 k-triangle
 meshes: entered by the general route, by the parked route, the default, all copied), one compact line per way.
-    python tools/tl_general.py [--only general_320] [--ways entered,copied] [--in-flight 256] [--json out.json]      (PTAMD_LIB=... for a variant library)"""
+    python tools/tl_general.py [--only general_432] [--ways entered,copied] [--in-flight 256] [--json out.json]      (PTAMD_LIB=... for a variant library)"""
 import argparse
 import json
 import os

@@ -28,6 +28,12 @@ def table(name):
         # traversal kernels for scenes that are one world-space tree (<., true>: the ones that enter instances)
         for long, short in (("k_shade<false, false, false, false>", "k_shade<false>"), ("k_shade<false, false, false>", "k_shade<false>"), ("k_shade<false, false>", "k_shade<false>"),
                             ("k_trace<true, false, false>", "k_trace<true>"), ("k_trace<false, false, false>", "k_trace<false>"),  # round 4: a third parameter (DESCENT)
+                            # round 6: <any hit, LEVELS> -- 0 one world-space tree, 1 folded / parked instances, 2 the general instance route
+                            ("k_trace<true, 0>", "k_trace<true>"), ("k_trace<false, 0>", "k_trace<false>"),
+                            ("k_trace<true, 1>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,two-level>"),
+                            ("k_trace<false, 1>", "k_trace<false>" if TWO_LEVEL_RUN else "k_trace<false,two-level>"),
+                            ("k_trace<true, 2>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,general>"),
+                            ("k_trace<false, 2>", "k_trace<false>" if TWO_LEVEL_RUN else "k_trace<false,general>"),
                             ("k_trace<true, true, false>", "k_trace<true>" if TWO_LEVEL_RUN else "k_trace<true,two-level>"),
                             ("k_trace<false, true, false>", "k_trace<false>" if TWO_LEVEL_RUN else "k_trace<false,two-level>"),
                             ("k_trace<true, false>", "k_trace<true>"), ("k_trace<false, false>", "k_trace<false>"),
@@ -68,6 +74,8 @@ HALF_COUNTED = {
     "k_gen": (0.0, "writes only"),
 }
 out = {"scene_flags": bench["config"].get("scene_flags", 0),
+       # the build the counters were taken on: bench.py compares it with the tree it runs on (roofline.traffic_stale)
+       "csrc_sha256": bench["config"].get("csrc_sha256"),
        "config": {"width": bench["config"]["width"], "height": bench["config"]["height"], "level": bench["config"]["level"],
                   "samples_in_flight": bench["config"]["samples_in_flight"], "n_gpus": bench["n_gpus"]},
        "calibration": "FETCH_SIZE / WRITE_SIZE in KB, summed over the dispatches of one bench step; FETCH_SIZE counts 16 B/lane coalesced "
