@@ -107,7 +107,11 @@ int main()
         rt.frameTick();
         const std::vector<float> updated = render(rt);
 
-        RayTracer fresh(W, H, makeScene(pos1, nullptr), noTextures, sky);
+        // the yardstick: the same mesh (same tree topology: built on the first frame's positions) deformed BEFORE a RayTracer ever sees it
+        std::shared_ptr<SequenceLikeMesh> seq2;
+        auto scene2 = makeScene(pos0, &seq2);
+        seq2->goToFrame(pos1);
+        RayTracer fresh(W, H, scene2, noTextures, sky);
         const std::vector<float> want = render(fresh);
         const bool staleDiffers = std::memcmp(first.data(), updated.data(), first.size() * sizeof(float)) != 0;
         const bool same = std::memcmp(want.data(), updated.data(), want.size() * sizeof(float)) == 0;
