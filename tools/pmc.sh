@@ -8,6 +8,6 @@ for set in "$@"; do
   i=$((i+1))
   out=gpurun_out/pmc_${tag}_$i
   rm -rf $out
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > $out.log 2>&1 || { echo "pass $i failed"; tail -3 $out.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-roofline --no-frame --no-secondary --rounds 1 --steps 1 --warmup 1 > $out.log 2>&1 || { echo "pass $i failed"; tail -3 $out.log; exit 1; }
   python3 tools/pmc_sum.py $out
 done
