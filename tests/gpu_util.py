@@ -123,3 +123,19 @@ def image_margins(name, got, want, spp, camera, bias_gate, rmse_gate, **extra):
     assert bias < bias_gate, (name, bias)
     assert e < rmse_gate, (name, e)
     return bias, e
+
+
+def fraction_gate(name, close, measured=None, legacy=0.0, slack=0.98):
+    """The fraction of entries / pixels that agree with the oracle within a test's tolerances, on the record (parity_margins.json) and gated at what was
+    MEASURED, not at a round number (`> 0.85` and `>= 0.97` would have hidden a regression of several percent of a stratum).
+    `measured`: {name: fraction} of the test file (the values of the committed profiles/roundN/parity_margins.json); the gate is measured x 0.98 -- the
+    kernels and the counter PRNG are deterministic, what moves a fraction between boxes and builds is a handful of fp32 decision flips -- and never
+    below the `legacy` gate of rounds 1-5; a name without a measurement is held against `legacy` alone and shows up as such in the record."""
+    close = np.asarray(close)
+    n = int(close.size)
+    frac = float(close.mean()) if n else 1.0
+    m = None if measured is None else (measured.get(name) if isinstance(measured, dict) else measured)
+    gate = legacy if m is None else max(legacy, m * slack)
+    record_margin("fraction: " + name, fraction=frac, n=n, measured=m, gate=gate, legacy_gate=legacy)
+    assert frac >= gate, (name, frac, gate)
+    return frac

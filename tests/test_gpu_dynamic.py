@@ -9,6 +9,10 @@ import orclib as O
 from ptamd import host as H, layout as L, scenes
 
 pytestmark = pytest.mark.gpu
+
+# fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
+# every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
+MEASURED = {}
 W, Hh = 96, 54
 
 
@@ -137,7 +141,8 @@ def test_deforming_mesh_through_refit(gpu, builder, route):
         assert info["n"] > 5000
         ref, _ = O.render(sc, room.camera, W, Hh, 16, seed=8, threads=8)
         assert abs(a.mean() - ref[:, :3].mean()) / ref[:, :3].mean() < 1e-3
-        assert np.isclose(a, ref[:, :3], rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1).mean() > 0.97
+        U.fraction_gate(f"deforming mesh ({builder}, {route}), frame {frame}: pixels within 1e-3 of the oracle",
+                        np.isclose(a, ref[:, :3], rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1), MEASURED, legacy=0.97)
         fresh = U.make_ctx(gpu, flat, W, Hh, camera=room.camera, seed=8, samples_in_flight=1)
         fresh.render(16)
         assert np.array_equal(fresh.read_accum()[:, :3], a), f"frame {frame}: refitted context != fresh context on the same arrays"

@@ -9,6 +9,10 @@ import orclib as O
 from ptamd import scenes
 
 pytestmark = pytest.mark.gpu
+
+# fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
+# every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
+MEASURED = {}
 W, H = 1920, 1080
 
 
@@ -43,7 +47,7 @@ def test_full_size_properties(gpu, bundle):
     got, want = b8[px], ref[px, :3]
     U.image_margins("config4 1080p, 8 spp, 6000 pixels", got, want, 8, bundle.camera, 1e-3, 1e-3)
     close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
-    assert close.mean() > 0.97, close.mean()
+    U.fraction_gate("config4 1080p, 8 spp: sampled pixels within 1e-3 of the oracle", close, MEASURED, legacy=0.97)
 
 
 def test_config4_as_a_5x3_grid_against_the_oracle(gpu):
@@ -63,7 +67,7 @@ def test_config4_as_a_5x3_grid_against_the_oracle(gpu):
         ctx.close()
         U.image_margins(f"config4 as a 5x3 grid, 8 spp, {name}", got, want, 8, b.camera, 1e-3, 1e-3)
         close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
-        assert close.mean() > 0.97, (name, close.mean())
+        U.fraction_gate(f"config4 as a 5x3 grid, 8 spp, {name}: sampled pixels within 1e-3 of the oracle", close, MEASURED, legacy=0.97)
 
 
 @pytest.mark.parametrize("flags_name", ["copied", "entered", "thin_lens"])
@@ -101,7 +105,7 @@ def test_the_timed_configuration_against_the_oracle_directly(gpu, bundle, flags_
                     note="" if n == bench.IN_FLIGHT else f"fell back from {bench.IN_FLIGHT} to {n} samples in flight: {free_b / 1e9:.0f} GB of device memory free")
     # path by path most pixels agree to round-off (a pixel holds hundreds of paths here; one fp32 decision flip per pixel is common)
     close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * want.max()).all(axis=1)
-    assert close.mean() > 0.85, close.mean()
+    U.fraction_gate(f"config4 as timed, {flags_name}: sampled pixels within 2e-3 of the oracle", close, MEASURED, legacy=0.85)
 
 
 def test_config5_4k_thin_lens_properties(gpu):
@@ -137,7 +141,7 @@ def test_config5_4k_thin_lens_properties(gpu):
     got, want = whole[px], ref[px, :3]
     U.image_margins("config5 4K thin lens, 2 spp path by path", got, want, 2, b.camera, 1e-3, 1e-3)
     close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
-    assert close.mean() > 0.97, close.mean()
+    U.fraction_gate("config5 4K thin lens, 2 spp: sampled pixels within 1e-3 of the oracle", close, MEASURED, legacy=0.97)
     # the configuration's statistics at a sample count that means something: 64 spp in ONE batch (64 in flight at 4K = the 531 M queue
     # entries of the 1080p benchmark), 4 000 sampled pixels against the oracle
     ctx = U.make_ctx(gpu, b, W4, H4, seed=3, samples_in_flight=64)
@@ -169,7 +173,7 @@ def _config_room_test(gpu, bundle, spp_total, seed, n_pixels=4096, first=8, labe
     got, want = a[px], ref[px, :3]
     U.image_margins(f"{bundle.name} {label}, first {first} spp", got, want, first, bundle.camera, 1e-3, 1e-3)
     close = np.isclose(got, want, rtol=1e-3, atol=1e-3 * want.max()).all(axis=1)
-    assert close.mean() > 0.97, close.mean()
+    U.fraction_gate(f"{bundle.name} {label}, first {first} spp: sampled pixels within 1e-3 of the oracle", close, MEASURED, legacy=0.97)
     # the rest of the configuration's samples on top
     ctx.render(spp_total - first)
     assert ctx.samples_per_pixel == spp_total

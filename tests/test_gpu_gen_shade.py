@@ -11,6 +11,10 @@ import orclib as O
 from ptamd import layout as L, scenes
 
 pytestmark = pytest.mark.gpu
+
+# fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
+# every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
+MEASURED = {}
 F = L.SHADINGFLAGS_HASFINISHED
 
 
@@ -158,18 +162,23 @@ def test_shade_batch_matches_oracle_per_material(gpu, golden, name):
         flips = int((g_o[sl] != o_alive[sl]).sum()), int((g_s[sl] != s_alive[sl]).sum())
         assert max(flips) <= max(1, size // 64), (label, flips)
         both = sl[o_alive[sl] & g_o[sl]]
+        worst = 1.0  # the field of the continuation ray that agrees least in this stratum
         for a, f, c in ray_fields:
             close = np.isclose(got[a][both], out_r[f][slot[both], c], rtol=2e-3, atol=2e-4)
-            assert close.size == 0 or close.mean() >= 0.97, (label, a, close.mean())
+            worst = min(worst, float(close.mean()) if close.size else 1.0)
+        U.fraction_gate(f"shade stratum {name}/{label}: continuation rays, worst field", np.array([worst]), MEASURED, legacy=0.97)
         assert np.array_equal(got["nflags"][both] & 2, out_r["flags"][slot[both]] & 2), label
         sb = sl[s_alive[sl] & g_s[sl]]
+        worst = 1.0
         for a, f, c in sh_fields:
             close = np.isclose(got[a][sb], out_s[f][slot[sb], c], rtol=2e-3, atol=2e-4)
-            assert close.size == 0 or close.mean() >= 0.97, (label, a, close.mean())
-        assert sb.size == 0 or np.isclose(got["slen"][sb], out_s["rayLength"][slot[sb]], rtol=1e-4, atol=1e-5).mean() >= 0.97, label
+            worst = min(worst, float(close.mean()) if close.size else 1.0)
+        if sb.size:
+            worst = min(worst, float(np.isclose(got["slen"][sb], out_s["rayLength"][slot[sb]], rtol=1e-4, atol=1e-5).mean()))
+        U.fraction_gate(f"shade stratum {name}/{label}: shadow rays, worst field", np.array([worst]), MEASURED, legacy=0.97)
         # radiance deposited by shade itself (emissive hits, sky misses), entry by entry
         rad_close = np.isclose(got["radiance"][sl], acc[sl, :3], rtol=2e-3, atol=1e-4).all(axis=1)
-        assert rad_close.mean() >= 0.98, (label, rad_close.mean())
+        U.fraction_gate(f"shade stratum {name}/{label}: radiance deposited by shade", rad_close, MEASURED, legacy=0.98)
         report[label] = (size, len(both), len(sb))
         if label.startswith("miss"):
             assert not g_o[sl].any() and not g_s[sl].any() and (got["radiance"][sl].sum(axis=1) > 0).mean() > 0.9, label

@@ -10,6 +10,10 @@ import orclib as O
 from ptamd import host as H, layout as L, scenes
 
 pytestmark = pytest.mark.gpu
+
+# fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
+# every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
+MEASURED = {}
 W, Hh = 96, 54
 
 CASES = {
@@ -21,13 +25,13 @@ CASES = {
 }
 
 
-def _gates(a, ref, st, cnt, spp, cam, close_frac=0.97):
+def _gates(a, ref, st, cnt, spp, cam, close_frac=0.97, name=""):
     assert st["rays_generated"] == cnt["raysGenerated"] == W * Hh * spp
     for k, ck in (("rays_extension", "raysExtension"), ("rays_shadow", "raysShadow"), ("shade_hits", "shadeHits")):
         assert abs(st[k] - cnt[ck]) <= 1e-3 * cnt[ck] + 2, (k, st[k], cnt[ck])
     assert abs(a.mean() - ref.mean()) / ref.mean() < 1e-3
     close = np.isclose(a, ref, rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1)
-    assert close.mean() > close_frac, close.mean()
+    U.fraction_gate(f"{name}: pixels within 1e-3 of the oracle", close, MEASURED, legacy=close_frac)
     assert U.rmse(U.tonemap(a, spp, cam), U.tonemap(ref, spp, cam)) < 5e-3
 
 
@@ -41,7 +45,7 @@ def test_mis_render_matches_oracle(gpu, case):
     a, st = ctx.read_accum()[:, :3], ctx.stats()
     ctx.close()
     ref, cnt = O.render(U.oracle_scene(b), b.camera, W, Hh, spp, seed=3, threads=8, integrator=O.INTEGRATOR_MIS)
-    _gates(a, ref[:, :3], st, cnt, spp, b.camera)
+    _gates(a, ref[:, :3], st, cnt, spp, b.camera, name=f"MIS integrator vs the oracle, {case}")
     plain, _ = O.render(U.oracle_scene(b), b.camera, W, Hh, spp, seed=3, threads=8)
     if case != "glass" or True:
         assert not np.array_equal(plain[:, :3], ref[:, :3]), "MIS and IS are different estimators"
@@ -69,7 +73,8 @@ def test_compare_shading_halves_agree_in_the_mean(gpu):
     ctx.close()
     ref, _ = O.render(U.oracle_scene(b), b.camera, w, h, 32, seed=5, threads=8, integrator=O.INTEGRATOR_COMPARE)
     close = np.isclose(got, ref[:, :3], rtol=1e-3, atol=1e-3 * ref.max()).all(axis=1)
-    assert close.mean() > 0.97 and abs(got.mean() - ref[:, :3].mean()) / ref[:, :3].mean() < 1e-3
+    U.fraction_gate("COMPARE_SHADING arrangement vs the oracle: pixels within 1e-3", close, MEASURED, legacy=0.97)
+    assert abs(got.mean() - ref[:, :3].mean()) / ref[:, :3].mean() < 1e-3
 
 
 def test_weighted_light_choice_matches_oracle(gpu):
@@ -101,7 +106,7 @@ def test_weighted_light_choice_matches_oracle(gpu):
         ctx.close()
         ref, cnt = O.render(U.oracle_scene(b), b.camera, W, Hh, 16, seed=7, threads=8, integrator=integrator, light_sampling=O.LIGHTS_SOLID_ANGLE)
         # the walk over the light weights ends on a float comparison per light: a few more round-off flips than elsewhere
-        _gates(a, ref[:, :3], st, cnt, 16, b.camera, close_frac=0.95)
+        _gates(a, ref[:, :3], st, cnt, 16, b.camera, close_frac=0.95, name=f"solid-angle light choice vs the oracle, integrator {integrator}")
 
 
 @pytest.mark.parametrize("flag", ["FLAG_INTEGRATOR_MIS", "FLAG_COMPARE_SHADING", "FLAG_SOLID_ANGLE_LIGHTS"])
