@@ -717,6 +717,9 @@ struct ShadeArgs {
     uint32_t* activeFlag;
     uint32_t firstTile; // first 512-entry tile this launch is responsible for
     uint32_t derivedPrimaries; // pass 0 behind k_trace_multi (pinhole): the queue holds (direction, pixel) only -- origin = the eye, sample from the entry index
+    // entries the out queue / the shadow queue hold (round 6: they may be smaller than the batch -- ptamd.hip sizes a batch so that what its first pass emits
+    // fits, from the counts of earlier batches; the guard below and k_clamp_counts turn a wrong guess into a reported error instead of a write past the end)
+    uint32_t outCap, shadowCap;
 };
 
 // shade, kernel.cl:190-301.  PARITY = reference queue semantics: every shaded hit is enqueued in both
@@ -954,13 +957,13 @@ __global__ void __launch_bounds__(kShadeBlock, (PARITY || GENERAL || LOOP) ? 4 :
     __syncthreads();
     const uint32_t baseRay = sBase[0] + sCount[wave][0], baseSh = sBase[1] + sCount[wave][1];
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (emitRay) {
+    if (emitRay && baseRay + (uint32_t)__popcll(mRay & below) < a.outCap) {
         const uint32_t idx = baseRay + (uint32_t)__popcll(mRay & below);
         stQ(&a.out.o[idx], make_float4(r.origin.x, r.origin.y, r.origin.z, asF(pixel)));
         stQ(&a.out.d[idx], make_float4(r.direction.x, r.direction.y, r.direction.z, asF(packState(r.flags, bounce, plane))));
         stQ(&a.out.thr[idx], make_float4(r.throughput.x, r.throughput.y, r.throughput.z, GENERAL ? r.pdf : 0.f));
     }
-    if (emitShadow) {
+    if (emitShadow && baseSh + (uint32_t)__popcll(mSh & below) < a.shadowCap) {
         const uint32_t idx = baseSh + (uint32_t)__popcll(mSh & below);
 #if PT_SHADE_PARK
         const float* pk = &sPark[0][PARITY ? 0 : threadIdx.x];
@@ -1118,6 +1121,21 @@ __global__ void k_set_word(uint32_t* p, uint32_t v)
 // blocking KernelData read-back of raytracer.cpp:381-389).
 // `countsOut` (may be null): pinned host memory that receives the pass counters -- next frame's launch sizes and kernel choices (a copy command on the
 // stream was a blit kernel and two launch gaps on a 1-spp frame's critical path: ~20 us of ~750)
+// Queues smaller than the batch (round 6): what pass `pass` emitted is cut at the queues' sizes -- the kernels behind read the counts, not the sizes -- and a cut is
+// REPORTED (a sticky word in pinned host memory: pt_synchronize and every read of the image fail once it is set).  One thread.
+__global__ void k_clamp_counts(Control* ctl, uint32_t pass, uint32_t outCap, uint32_t shadowCap, uint32_t* overflowPinned)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    bool cut = false;
+    if (ctl->extCount[pass + 1] > outCap)
+        ctl->extCount[pass + 1] = outCap, cut = true;
+    if (ctl->shadowCount[pass] > shadowCap)
+        ctl->shadowCount[pass] = shadowCap, cut = true;
+    if (cut)
+        *overflowPinned = 1u;
+}
+
 __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes, uint32_t* countsOut)
 {
     // one wave: lane p folds and clears the counters of pass p, lane k the k-th deposit slot (17 passes, 64 slots: one round of loads instead of a
@@ -1127,8 +1145,10 @@ __global__ void k_end_sample(Control* ctl, Totals* tot, uint32_t passes, uint32_
         return;
     const uint32_t lane = threadIdx.x;
     unsigned long long ext = 0, sh = 0, hits = 0, slots = 0;
-    if (countsOut && lane <= (uint32_t)kMaxPasses)
+    if (countsOut && lane <= (uint32_t)kMaxPasses) { // [0, kMaxPasses]: rays in the extension queue per pass; behind them the shadow rays per pass
         countsOut[lane] = lane <= passes ? ctl->extCount[lane] : 0u;
+        countsOut[kMaxPasses + 1 + lane] = lane <= passes ? ctl->shadowCount[lane] : 0u;
+    }
     if (lane <= passes && lane <= (uint32_t)kMaxPasses) {
         ext = ctl->extCount[lane];
         sh = ctl->shadowCount[lane];

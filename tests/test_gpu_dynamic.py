@@ -12,7 +12,20 @@ pytestmark = pytest.mark.gpu
 
 # fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
 # every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
-MEASURED = {}
+MEASURED = {
+    'deforming mesh (BVH_BINNED_SAH, device), frame 0: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_BINNED_SAH, device), frame 1: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_BINNED_SAH, device), frame 2: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_BINNED_SAH, host_nodes), frame 0: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_BINNED_SAH, host_nodes), frame 1: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_BINNED_SAH, host_nodes), frame 2: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, device), frame 0: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, device), frame 1: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, device), frame 2: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, host_nodes), frame 0: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, host_nodes), frame 1: pixels within 1e-3 of the oracle': 1.0000,
+    'deforming mesh (BVH_SPATIAL_SPLIT, host_nodes), frame 2: pixels within 1e-3 of the oracle': 1.0000,
+}
 W, Hh = 96, 54
 
 

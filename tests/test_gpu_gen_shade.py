@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 # fractions of pixels / queue entries within tolerance of the oracle as measured on the MI355X (profiles/round6/parity_margins.json): gpu_util.fraction_gate holds
 # every such comparison against 0.98 x its entry here (and never below the round-number gate of rounds 1-5)
-MEASURED = {}
+MEASURED = 1.0  # every stratum, every field: 1.0000 (63 entries of profiles/round6/parity_margins.json) -- the gate lets ONE entry of a 64-entry stratum flip
 F = L.SHADINGFLAGS_HASFINISHED
 
 
