@@ -52,7 +52,13 @@ BYTES_PER_DEPOSIT = 24  # 12 B read + 12 B written per accumulator update (unocc
 IN_FLIGHT = 512  # samples in flight per pixel at 1080p on one rank (x N on 1/N of the pixels)
 MAX_ENTRIES = 1920 * 1080 * IN_FLIGHT  # path segments resident per rank (~200 GB of queues and planes): the 1080p job at any N; caps 4K
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
-BYTES_PER_QUEUE_ENTRY = 164  # resident per queue entry: two extension queues (2 x 48 B), the shadow queue (48 B), the hit record (20 B) -- ensureQueues' accounting
+BYTES_PER_QUEUE_ENTRY = 164  # resident per queue entry with queues as large as the batch (rounds 1-5): two extension queues (2 x 48 B), the shadow queue (48 B), the hit record (20 B)
+# Round 6: the queues that only hold what a batch's FIRST pass emits are sized by what it emits (pt_config.ext_queue_fraction / shadow_queue_fraction): on config 4
+# 23 % of a batch's entries go on after the first hit and 45 % spawn a shadow ray there (measured by the library itself, roofline.first_pass_ratios of the line); with
+# these fractions a camera-ray batch of a pinhole keeps 36 + 80 x 0.30 + 48 x 0.55 = 86 B per entry resident instead of 164 (a thin lens: 68 + 48 x 0.30 + 48 x 0.55 =
+# 109: its camera rays keep their origins).  The library cuts a batch that would emit more to what fits -- never a wrong image, at worst smaller batches.
+EXT_QUEUE_FRACTION = 0.30
+SHADOW_QUEUE_FRACTION = 0.55
 TILE = int(os.environ.get("PTAMD_TILE", "16"))  # edge of the image tiles dealt to the ranks of an N-GPU job.  16 since round 5: every rank's share of the N = 8 job emulated on one
 # GPU (tools/rank_emul.py), slowest rank over fastest: 32 x 32 tiles 1.037 (7.70 x predicted), 16 x 16 1.024 (7.80 x), 8 x 8 1.015 (7.84 x); the variable: diagnostics
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored
@@ -183,9 +189,18 @@ def plan_in_flight(requested, world, owned_pixels, max_entries=MAX_ENTRIES):
     return n
 
 
-def resident_bytes(in_flight, owned_pixels):
+def bytes_per_entry(ext_fraction=1.0, shadow_fraction=1.0, thin_lens=False):
+    """Resident bytes per entry of a batch (ensureQueues' accounting, csrc/ptamd.hip): camera-ray directions 16 + hit record 20 for every entry; the first queue's
+    origin and throughput planes (32) for every entry of a thin lens / for the fraction that goes on with a pinhole's bundles; the second queue (48) for the
+    fraction that goes on; the shadow queue (48) for the fraction that spawns a shadow ray."""
+    fe = ext_fraction if 0.0 < ext_fraction < 1.0 else 1.0
+    fs = shadow_fraction if 0.0 < shadow_fraction < 1.0 else 1.0
+    return 36.0 + 32.0 * (1.0 if thin_lens or fe == 1.0 else fe) + 48.0 * fe + 48.0 * fs
+
+
+def resident_bytes(in_flight, owned_pixels, per_entry=BYTES_PER_QUEUE_ENTRY):
     """HBM the queues and the extra accumulator planes of one context keep resident (what ensureQueues, csrc/ptamd.hip, checks against hipMemGetInfo)."""
-    return owned_pixels * in_flight * BYTES_PER_QUEUE_ENTRY + max(in_flight - 1, 0) * owned_pixels * 16
+    return int(owned_pixels * in_flight * per_entry) + max(in_flight - 1, 0) * owned_pixels * 16
 
 
 def shrink_in_flight(n):
@@ -195,11 +210,11 @@ def shrink_in_flight(n):
     return max(1, n // 2)
 
 
-def fit_in_flight(in_flight, owned_pixels, free_bytes, reserve=6 << 30):
+def fit_in_flight(in_flight, owned_pixels, free_bytes, reserve=6 << 30, per_entry=BYTES_PER_QUEUE_ENTRY):
     """`in_flight`, lowered until its queues and planes fit what the device has free (another tenant on the card, a context that is not
     freed yet, a part with less HBM): the bench line degrades by a percent or two (512 -> 256 in flight: -1.9 %) instead of failing.  `reserve`
     covers the scene, the sky, the spill region and the accumulator."""
-    while in_flight > 1 and resident_bytes(in_flight, owned_pixels) + reserve > free_bytes:
+    while in_flight > 1 and resident_bytes(in_flight, owned_pixels, per_entry) + reserve > free_bytes:
         in_flight = shrink_in_flight(in_flight)
     return in_flight
 
@@ -275,10 +290,10 @@ def frame_times(D, H, scenes, L, device, frames, width=1280, height=720, only=""
             "scenes": out, "reference_published_ms_per_frame": "35.6 - 56.8 (images/*.png overlays, hardware not stated; BASELINE.md 1a)"}
 
 
-def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=1, rounds=1, what=""):
+def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=1, rounds=1, what="", queue_fractions=(0.0, 0.0)):
     """Throughput of one scene / flag set on this GPU, the way the headline is measured (warm-up, clear, K steps between two
     synchronisations), plus the per-kernel-family device times of one extra, profiled step.  Its own context, closed before it returns."""
-    ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=in_flight, flags=flags)
+    ctx = D.Context(W, Hh, seed=1, device=device, samples_in_flight=in_flight, flags=flags, ext_queue_fraction=queue_fractions[0], shadow_queue_fraction=queue_fractions[1])
     try:
         t0 = time.perf_counter()
         ctx.upload_scene(bundle.flat, sky=bundle.sky, material_textures=bundle.material_textures)
@@ -316,6 +331,8 @@ def measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, steps=3, warmup=
                                       "any_hit": round(ps["ms_shadow"], 2)},
                # rays per class and the rate INSIDE the kernels that trace them (device ms of the profiled step): the whole-job figure above is a mix of these
                "rays_by_class": rays_by_class(ps),
+               "batch_samples": ps["batch_samples"],  # samples per pixel of the batches the library cut (< samples_in_flight where the queue fractions made it)
+               "first_pass_ratios": {"ext": round(ps["first_pass_ext_ratio"], 4), "shadow": round(ps["first_pass_shadow_ratio"], 4)},
                "instances": {"entered": ps["entered_instances"], "folded": ps["folded_instances"], "general_route": bool(ps["general_route"])},
                "per_ray_kernels_mrays_per_s": round((pr - primary) / max(per_ray_ms + ps["ms_shadow"], 1e-9) / 1e3, 1),  # bounce + shadow rays over their two kernels' time
                "shade_ns_per_entry": round(ps["ms_shade"] * 1e6 / max(ps["shade_hits"], 1), 3),
@@ -628,6 +645,21 @@ def secondary_measurements(D, H, L, scenes, bundle, args, device, in_flight):
                                                    what="PT_FLAG_TWO_LEVEL_ONLY: the 12 mesh instances are entered; the two quads (single-leaf meshes) "
                                                         "hang off the top level as world-space leaves"),
         "instances_copied_to_world_space": measure_scene(D, bundle, W, Hh, device, in_flight, flags=0, what="the headline's configuration, measured the same way")})
+    def in_flight_curve():
+        # the rate against the footprint.  Samples in flight per pixel x what stays resident for them, with the queues sized by the fractions
+        # of the headline (EXT_QUEUE_FRACTION / SHADOW_QUEUE_FRACTION) and, at the headline's own count, as large as the batch (rounds 1-5: 164 B per entry).
+        pts = {}
+        fe, fs = args.ext_queue_fraction, args.shadow_queue_fraction
+        for n in (32, 128, 256, 512):
+            r = measure_scene(D, bundle, W, Hh, device, n, steps=3, queue_fractions=(fe, fs))
+            pts[str(n)] = {"mrays_per_s": r["mrays_per_s"], "resident_gb": round(resident_bytes(n, W * Hh, bytes_per_entry(fe, fs)) / 1e9, 1), "batch_samples": r["batch_samples"],
+                           "first_pass_ratios": r["first_pass_ratios"]}
+        r = measure_scene(D, bundle, W, Hh, device, in_flight, steps=3)
+        pts[f"{in_flight}_full_queues"] = {"mrays_per_s": r["mrays_per_s"], "resident_gb": round(resident_bytes(in_flight, W * Hh) / 1e9, 1), "batch_samples": r["batch_samples"]}
+        return {"what": f"config 4 as in the headline, samples in flight per pixel -> Mrays/s and resident GB (queues + accumulator planes); queue fractions ext {fe} / shadow {fs} "
+                        f"= {bytes_per_entry(fe, fs):.0f} B per entry; the last point: queues as large as the batch (164 B per entry, rounds 1-5)", "points": pts}
+    guarded("in_flight_curve", in_flight_curve)
+
     guarded("two_level_general", lambda: two_level_general_times(D, scenes, W, Hh, args.level, device, in_flight))
 
     def dynamic():
@@ -701,6 +733,8 @@ def main():
     ap.add_argument("--grid", default="4x3", help="instances of the two meshes, columns x rows (4x3 = 985 012 instanced triangles: the headline since round 1; "
                                                   "5x3 = SURVEY 8(d)'s 15 instances, 1 231 264 with these meshes -- also reported as the `grid_5x3` object of the default line)")
     ap.add_argument("--builder", default="spatial", choices=["spatial", "binned", "fast"], help="BVH builder of the instanced meshes (diagnostic: how much the tree's quality is worth)")
+    ap.add_argument("--ext-queue-fraction", type=float, default=EXT_QUEUE_FRACTION, help="pt_config.ext_queue_fraction of the headline's context (0 or 1: queues as large as the batch)")
+    ap.add_argument("--shadow-queue-fraction", type=float, default=SHADOW_QUEUE_FRACTION, help="pt_config.shadow_queue_fraction of the headline's context")
     ap.add_argument("--flags", type=int, default=0, help="pt_config.flags of the render context (2 = PT_FLAG_NO_BAKED_INSTANCES: two-level traversal)")
     ap.add_argument("--dump-accum", default=None, help="rank 0 saves the (reduced) HDR accumulator as .npy (tests)")
     args = ap.parse_args()
@@ -775,7 +809,9 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(local_rank)
     if args.share_gpu:
         free_b //= world
-    in_flight = fit_in_flight(in_flight, owned, free_b)
+    fe, fs = args.ext_queue_fraction, args.shadow_queue_fraction
+    per_entry = bytes_per_entry(fe, fs, args.thin_lens)
+    in_flight = fit_in_flight(in_flight, owned, free_b, per_entry=per_entry)
 
     def agree(value):  # every rank must use the same batch: the smallest share decides
         if world == 1:
@@ -796,7 +832,7 @@ def main():
             # the context, and ONE batch through it: the queues are set up at the first render, which is where an oversized configuration is refused
             ctx, err = None, ""
             try:
-                ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight, flags=args.flags)
+                ctx = D.Context(W, Hh, seed=1, device=local_rank, samples_in_flight=in_flight, flags=args.flags, ext_queue_fraction=fe, shadow_queue_fraction=fs)
                 ctx.set_stream(stream.cuda_stream)
                 ctx.upload_scene(flat, sky=bundle.sky, material_textures=bundle.material_textures)
                 ctx.set_camera(bundle.camera)
@@ -892,7 +928,10 @@ def main():
                 "scene_flags": args.flags, "csrc_sha256": csrc_sha256(),
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
-                "resident_gb": round(resident_bytes(in_flight, owned) / 1e9, 1),  # queues + accumulator planes of this rank (164 B per entry, 16 B per plane and pixel)
+                "resident_gb": round(resident_bytes(in_flight, owned, per_entry) / 1e9, 1),  # queues + accumulator planes of this rank (bytes_per_entry, 16 B per plane and pixel)
+                "resident_bytes_per_entry": round(per_entry, 1), "queue_fractions": {"ext": fe, "shadow": fs},
+                "batch_samples": st["batch_samples"], "first_pass_ratios": {"ext": round(st["first_pass_ext_ratio"], 4), "shadow": round(st["first_pass_shadow_ratio"], 4)},
+                "probe_batches": st["probe_batches"],
                 "device_memory_gb": {"total": round(total_b / 1e9, 1), "free_before": round(free_b / 1e9, 1), "free_while_rendering": round(free_after / 1e9, 1)},
                 "tiles": "whole frame" if world == 1 else f"{TILE}x{TILE} tiles interleaved over ranks",
                 "pixels_per_rank": owned, "paths_per_step_per_rank": owned * spp_step,

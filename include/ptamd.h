@@ -134,6 +134,16 @@ typedef struct {
                                    Rounded DOWN to a multiple of 256, below 256 to a power of two (only such batches keep
                                    the samples of a pixel next to each other in the queues).
                                    Only with max_active_rays == 0 and PT_RNG_COUNTER. */
+    /* Round 6: queues SMALLER than a batch (0 = 1: one slot per entry, as the reference allocates, src/raytracer.cpp:760-787).  A batch of B entries needs B hit
+     * records and B camera-ray directions, but its second extension queue only holds the paths that go on after the first hit and its shadow queue the shadow
+     * rays of the first hits -- 23 % and 45 % of B on BASELINE config 4.  With fractions f_ext, f_shadow in (0, 1) those queues hold f x (owned pixels x
+     * samples_in_flight) entries: 36 + 80 f_ext + 48 f_shadow bytes per entry instead of 164 (pinhole; a thin lens keeps its camera-ray origins: 68 + 48 f_ext +
+     * 48 f_shadow).  pt_render then sizes every batch so that what its first pass emits fits -- from the counts of earlier batches of the same camera, scene
+     * and tiles; a short probe batch first -- i.e. a scene that emits more than the fractions allow renders in smaller batches, never wrongly; a guess that
+     * turns out wrong all the same is cut at the queue's end on the device and REPORTED: pt_synchronize and the image reads fail (PT_ERR_STATE).
+     * Fixed schedule only (max_active_rays == 0, PT_RNG_COUNTER, samples_in_flight >= 16). */
+    float ext_queue_fraction;
+    float shadow_queue_fraction;
 } pt_config;
 
 #define PT_FLAG_ROWMAJOR_PIXELS 1u /* issue pixels in row-major order (reference order); default is 8x8 blocks */
@@ -186,6 +196,10 @@ typedef struct {
     uint32_t folded_instances; /* instances of the active scene state that the per-ray kernels walk without parking (translation + uniform scale, not copied to world space) */
     uint64_t team_launches; /* traversal launches served by the team kernel (four lanes per ray: launches that do not fill the machine, csrc/pt_team.h) */
     uint32_t entered_instances; /* instances of the active scene state that are entered at traversal (scene.cl:116-139) rather than copied to world space */
+    uint32_t batch_samples; /* samples per pixel of the last batch pt_render cut (samples_in_flight, or fewer where the queue fractions of pt_config made it) */
+    float first_pass_ext_ratio, first_pass_shadow_ratio; /* the largest (rays emitted by a batch's first pass) / (entries of the batch) seen for the current camera, scene
+                                                            state and tiling -- extension rays, shadow rays; 0: not measured (queues as large as the batch) */
+    uint32_t probe_batches; /* short batches rendered to learn what a batch's first pass emits (queue fractions of pt_config; once per camera / scene state / tiling) */
     uint32_t general_route; /* 1: the per-ray kernels enter instances of ANY transform as leaf-kind steps, nothing parked (csrc/pt_trace.h, LEVELS 2: scenes with a rotated /
                                non-uniformly scaled instance, or with more instances than the fold table holds) */
 } pt_stats;

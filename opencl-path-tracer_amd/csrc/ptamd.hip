@@ -224,6 +224,16 @@ struct pt_ctx {
     DevBuf<float4> resolveTmp; // pt_resolve's output staging (allocated at first use)
     uint32_t numOwned = 0;
     uint32_t capacity = 0;
+    // Queues smaller than a batch (pt_config.ext_queue_fraction / shadow_queue_fraction, round 6): entries the second extension queue (and, for batches of a
+    // pinhole's bundles, the origin / throughput planes of the first) and the shadow queue hold; == capacity without fractions.  A batch is sized so that what its
+    // FIRST pass emits fits (every later pass emits at most what it was handed): from the largest ratios seen in this epoch (camera, scene state, tiling).
+    uint32_t capExt = 0, capShadow = 0;
+    bool q0Small = false; // the first queue's origin / throughput planes hold capExt entries (camera rays queued as directions only)
+    bool ratiosKnown = false;
+    double ratioExt = 0, ratioShadow = 0; // (rays emitted by pass 0) / (entries of the batch), the largest of this epoch
+    uint32_t* overflowPinned = nullptr; // set by k_clamp_counts when a batch emitted more than a queue holds after all: sticky, reported by pt_synchronize and the image reads
+    uint32_t batchSamples = 0, probeBatches = 0;
+    uint32_t epoch = 0, passCountsEpoch = 0; // camera / scene state / tiling the ratios belong to; ... the report in flight was launched in
     bool identityPixels = true;
     DevBuf<float4> accumOwn, accumPlanes;
     uint32_t packetBlocks[2] = { 0, 0 };
@@ -232,7 +242,7 @@ struct pt_ctx {
     // copied to pinned memory by the stream at the end of every batch, never waited for)
     uint32_t* passCountsPinned = nullptr; // kMaxPasses + 1 words
     hipEvent_t passCountsCopied = nullptr;
-    uint32_t passCountsHint[kMaxPasses + 1] = {};
+    uint32_t passCountsHint[2 * (kMaxPasses + 1)] = {}; // extension rays per pass, then shadow rays per pass
     uint32_t passCountsEntries = 0; // entries of the batch the hint comes from (0: no hint yet)
     uint32_t passCountsPending = 0; // entries of the batch whose copy is in flight
     uint32_t shadeHeadShift = 0; // diagnostics (PTAMD_SHADE_HEAD_SHIFT): shrinks the head of the split k_shade launches so that tests reach the tile-walking kernel
@@ -1065,6 +1075,49 @@ inline bool splitShadowAccum(const pt_ctx* c, uint64_t cap)
     return PT_SPLIT_SHADOW_ACCUM && c->planes == 1u && !parityMode(c) && c->cfg.max_active_rays == 0 && cap <= (4u << 20) && !(c->packetUse & 2u) && maxBounces(c) <= (uint32_t)kMaxPasses;
 }
 
+bool derivedPrimariesCapable(const pt_ctx* c); // (defined with renderSampleFixed's choice of kernels, below)
+// a new camera, scene state or tiling: what a batch's first pass emits is no longer known
+inline void newEpoch(pt_ctx* c)
+{
+    c->epoch++;
+    c->ratiosKnown = false;
+    c->ratioExt = c->ratioShadow = 0;
+}
+inline bool smallQueues(const pt_ctx* c) { return c->capExt < c->capacity || c->capShadow < c->capacity; }
+inline int checkOverflow(pt_ctx* c)
+{
+    if (c->overflowPinned && *c->overflowPinned)
+        return fail(c, PT_ERR_STATE, "a batch emitted more rays than its queues hold (pt_config.ext_queue_fraction / shadow_queue_fraction; the scene changed under a "
+                                    "running batch?): the rays beyond were dropped, the image since the last pt_clear is incomplete -- pt_clear and render again");
+    return PT_OK;
+}
+// adopt a pass-counter report that has landed (renderSampleFixed); the ratios of this epoch only ever grow
+inline void adoptPassCounts(pt_ctx* c)
+{
+    std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
+    c->passCountsEntries = c->passCountsPending;
+    c->passCountsPending = 0;
+    if (c->passCountsEpoch == c->epoch && c->passCountsEntries) {
+        c->ratioExt = std::max(c->ratioExt, (double)c->passCountsHint[1] / (double)c->passCountsEntries);
+        c->ratioShadow = std::max(c->ratioShadow, (double)c->passCountsHint[kMaxPasses + 1] / (double)c->passCountsEntries);
+        c->ratiosKnown = true;
+    }
+}
+// the largest batch (samples per pixel) whose first pass fits the queues, by the ratios seen so far + 3 % + 64 K entries
+inline uint32_t safeBatch(const pt_ctx* c)
+{
+    auto limit = [&](uint32_t cap, double ratio) -> double {
+        if (!(ratio > 0.0))
+            return (double)c->planes;
+        const double room = cap > 65536u ? (double)(cap - 65536u) : (double)cap * 0.5;
+        return room / (ratio * 1.03 * (double)c->numOwned);
+    };
+    double b = std::min(limit(c->capExt, c->ratioExt), limit(c->capShadow, c->ratioShadow));
+    if (const char* e = getenv("PTAMD_DEBUG_BATCH_SCALE")) // tests: a batch larger than what fits, so that the overflow guard has something to catch
+        b *= atof(e);
+    return (uint32_t)std::max(1.0, std::min((double)c->planes, b));
+}
+
 int ensureQueues(pt_ctx* c)
 {
     if (c->queuesReady)
@@ -1111,11 +1164,25 @@ int ensureQueues(pt_ctx* c)
         // message instead of somewhere in a later hipMalloc: per queue entry two extension queues (3 x 16 B each), the
         // shadow queue (3 x 16 B) and the hit records (20 B); per owned pixel one 16-byte accumulator plane for every
         // extra sample in flight.  (BASELINE config 5 -- 4K, 8 ranks -- at 2 048 samples in flight would be 2.1 G entries.)
-        const uint64_t perEntry = 2ull * 48 + 48 + 20 + (parityMode(c) ? 2ull * 48 + 4 : 0);
         // one sample in flight and a small queue (the 1-spp frames of RayTracer::rayTrace): the shadow rays' own accumulator (16 B per pixel of the
         // image) and a shadow queue per bounce (48 B per entry and bounce), renderSampleFixed -- set aside HERE, not in the first frame
         const bool split = splitShadowAccum(c, cap);
-        const uint64_t need = (uint64_t)cap * perEntry + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4)
+        // queues smaller than the batch (pt_config, round 6): fixed schedule, batches of >= 16 samples (the probe batch must mean something), no per-bounce queues
+        c->capExt = c->capShadow = cap;
+        c->q0Small = false;
+        const float fe = c->cfg.ext_queue_fraction, fs = c->cfg.shadow_queue_fraction;
+        if (!parityMode(c) && c->cfg.max_active_rays == 0 && c->planes >= 16u && !split) {
+            if (fe > 0.f && fe < 1.f)
+                c->capExt = std::min<uint64_t>(cap, (((uint64_t)((double)cap * fe) + 63u) & ~63ull) + 64u);
+            if (fs > 0.f && fs < 1.f)
+                c->capShadow = std::min<uint64_t>(cap, (((uint64_t)((double)cap * fs) + 63u) & ~63ull) + 64u);
+            // camera rays queued as (direction, pixel) only -- a pinhole's bundles, renderSampleFixed `derived` -- leave the first queue's other planes to the later passes
+            c->q0Small = c->capExt < cap && derivedPrimariesCapable(c);
+        }
+        newEpoch(c);
+        const uint64_t q0 = 16ull * cap + 32ull * (c->q0Small ? c->capExt : cap);
+        const uint64_t need = q0 + 48ull * c->capExt + 48ull * c->capShadow + 20ull * cap + (uint64_t)cap * (parityMode(c) ? 2ull * 48 + 4 : 0)
+            + (uint64_t)(c->planes - 1) * c->numOwned * sizeof(float4)
             + (split ? (uint64_t)cap * 48 * maxBounces(c) + (uint64_t)c->cfg.width * c->cfg.height * sizeof(float4) * maxBounces(c) : 0);
         size_t freeB = 0, totalB = 0;
         HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
@@ -1131,14 +1198,15 @@ int ensureQueues(pt_ctx* c)
         HIPCHK(c, hipMemsetAsync(c->accumPlanes.p, 0, n * sizeof(float4), c->stream));
     }
     c->capacity = cap;
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(c, c->rays[k].o.alloc(cap));
-        HIPCHK(c, c->rays[k].d.alloc(cap));
-        HIPCHK(c, c->rays[k].thr.alloc(cap));
-    }
-    HIPCHK(c, c->shadow.o.alloc(cap));
-    HIPCHK(c, c->shadow.d.alloc(cap));
-    HIPCHK(c, c->shadow.c.alloc(cap));
+    HIPCHK(c, c->rays[0].o.alloc(c->q0Small ? c->capExt : cap));
+    HIPCHK(c, c->rays[0].d.alloc(cap));
+    HIPCHK(c, c->rays[0].thr.alloc(c->q0Small ? c->capExt : cap));
+    HIPCHK(c, c->rays[1].o.alloc(c->capExt));
+    HIPCHK(c, c->rays[1].d.alloc(c->capExt));
+    HIPCHK(c, c->rays[1].thr.alloc(c->capExt));
+    HIPCHK(c, c->shadow.o.alloc(c->capShadow));
+    HIPCHK(c, c->shadow.d.alloc(c->capShadow));
+    HIPCHK(c, c->shadow.c.alloc(c->capShadow));
     HIPCHK(c, c->hitH.alloc(cap));
     HIPCHK(c, c->hitInst.alloc(cap));
     if (parityMode(c)) {
@@ -1425,6 +1493,12 @@ inline bool primaryBundles(const pt_ctx* c)
     return PT_MULTI_RAYS > 1 && (!c->camera.thinLens || lensBundles()) && !(c->packetUse & 8u) && c->dyn[c->active].packetOk && (c->packetUse & 1u);
 }
 // are consecutive entries of the first queue of a batch rays of one pixel or of neighbouring pixels?  >= 16 samples of a pixel next to each other, or the
+// can the camera rays of a large batch be queued as (direction, pixel) only?  (renderSampleFixed's `derived`, asked before the batch exists: ensureQueues)
+bool derivedPrimariesCapable(const pt_ctx* c)
+{
+    return c->haveCamera && c->haveDynamic && !c->camera.thinLens && primaryBundles(c) && PT_FUSED_PRIMARY && PT_DERIVED_PRIMARIES && !(c->cfg.flags & PT_FLAG_QUEUE_PRIMARY_RAYS);
+}
+
 // pixels of a 1-spp frame in the order of the pixel list (8 x 8 blocks unless the caller chose otherwise) where bundles of 256 serve them
 inline bool firstPassCoherent(const pt_ctx* c, const FrameParams& fp, uint32_t batch) { return fp.interleave >= 16u || (PT_FRAME_BUNDLES && batch == 1u && primaryBundles(c)); }
 
@@ -1506,6 +1580,9 @@ void launchShade(pt_ctx* c, const FrameParams& fp, int in, int out, uint32_t pas
     a.deposits = parityMode(c) ? &ctl->depositsShade : &ctl->depositSlots[0][0]; // the production kernel spreads its count over the slots (pt_device.h)
     a.streams = c->streams.p;
     a.derivedPrimaries = derivedPrimaries ? 1u : 0u;
+    // what the queues written here hold (pt_shade.h): the second queue capExt; the first queue capacity, or capExt where its origin / throughput planes are small
+    a.outCap = out == 1 ? c->capExt : (c->q0Small ? c->capExt : c->capacity);
+    a.shadowCap = ownShadow ? c->capacity : c->capShadow;
     const uint32_t blocks = (std::max(launchEntries, 1u) + kShadeBlock - 1u) / kShadeBlock; // those beyond the live count leave at once
     if (parityMode(c)) {
         a.out = c->stagedRays.view();
@@ -1583,9 +1660,7 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     FrameParams fp = batchFrameParams(c, sample, batch);
     if (c->passCountsPending) {
         if (hipEventQuery(c->passCountsCopied) == hipSuccess) { // the latest copy has landed: adopt it
-            std::memcpy(c->passCountsHint, c->passCountsPinned, sizeof(c->passCountsHint));
-            c->passCountsEntries = c->passCountsPending;
-            c->passCountsPending = 0;
+            adoptPassCounts(c);
         } else {
             (void)hipGetLastError(); // "not ready" is an answer, not an error: it must not be what the check at the end of the batch finds
         }
@@ -1608,6 +1683,8 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // ... and where those are the bundles of a pinhole camera, only (direction, pixel) is queued: k_shade takes the eye as the origin and the sample from the
     // entry index (12 instructions; the full regeneration the paragraph above dismissed is 70) -- 16 B per camera ray less written and 16 B less read
     const bool derived = fused && primaryBundles(c) && !c->camera.thinLens && PT_DERIVED_PRIMARIES; // (a thin lens: every ray has an origin of its own, which stays in the queue)
+    if (c->q0Small && !derived)
+        return fail(c, PT_ERR_STATE, "the first queue was sized for camera rays queued as directions only, and this batch queues their origins");
     prof.begin(0);
     if (fused)
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, &c->control.p->extCount[0], &c->control.p->generated, entries);
@@ -1641,6 +1718,8 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadowed[b - 1], 0)); // the deposits of bounce b - 1's shadow rays come first
         prof.begin(2);
         launchShade(c, fp, in, out, b, entries, split ? &c->shadowQ[b] : nullptr, derived && b == 0);
+        if (b == 0 && (c->capExt < c->capacity || c->capShadow < c->capacity)) // (later passes emit at most what they were handed: only the first can outgrow a queue)
+            hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, c->stream, c->control.p, 0u, c->capExt, c->capShadow, c->overflowPinned);
         prof.end();
         prof.begin(3);
         if (overlap && b + 1u == bounces && PT_LAST_SHADOW_ON_MAIN) {
@@ -1678,7 +1757,9 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     if (report) {
         HIPCHK(c, hipEventRecord(c->passCountsCopied, c->stream));
         c->passCountsPending = entries;
+        c->passCountsEpoch = c->epoch;
     }
+    c->batchSamples = batch;
     c->batchEntries = 0;
     c->foldPlanes = std::max(c->foldPlanes, batch); // folded once per pt_render (foldPlanesNow)
     HIPCHK(c, hipGetLastError());
@@ -1853,6 +1934,9 @@ int pt_create(const pt_config* cfg, pt_ctx** out)
         || (e = hipEventCreateWithFlags(&c->passCountsCopied, hipEventDisableTiming)) != hipSuccess)
         return bail(e, "pinned counters");
     std::memset(c->passCountsPinned, 0, sizeof(c->passCountsHint));
+    if ((e = hipHostMalloc((void**)&c->overflowPinned, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "pinned overflow word");
+    *c->overflowPinned = 0u;
     if ((e = c->totals.alloc(1)) != hipSuccess || (e = hipMemsetAsync(c->totals.p, 0, sizeof(Totals), c->stream)) != hipSuccess)
         return bail(e, "alloc totals");
     if ((e = c->accumOwn.alloc((size_t)cfg->width * cfg->height)) != hipSuccess
@@ -1923,6 +2007,7 @@ void pt_destroy(pt_ctx* c)
         if (c->evShadowed[k]) (void)hipEventDestroy(c->evShadowed[k]);
     }
     if (c->passCountsPinned) (void)hipHostFree(c->passCountsPinned);
+    if (c->overflowPinned) (void)hipHostFree(c->overflowPinned);
     if (c->passCountsCopied) (void)hipEventDestroy(c->passCountsCopied);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -2980,6 +3065,7 @@ int pt_frame_tick(pt_ctx* c)
     next.used = true;
     HIPCHK(c, hipEventRecord(next.lastUse, c->stream));
     c->active = c->pending;
+    newEpoch(c); // (what a batch's first pass emits belongs to the scene state it was measured on)
     c->pending = -1;
     c->haveDynamic = true;
     if (next.staticIndex != c->statCur) { // the state was built on a rebuilt scene (pt_upload_static_async): that scene is the current one from here on
@@ -3040,6 +3126,7 @@ int pt_set_camera(pt_ctx* c, const pt_camera* cam)
     c->camera.ISO = cam->ISO;
     c->camera.thinLens = cam->thinLensEnabled ? 1u : 0u;
     c->haveCamera = true;
+    newEpoch(c);
     return PT_OK;
 }
 
@@ -3126,6 +3213,10 @@ int pt_clear(pt_ctx* c)
         HIPCHK(c, hipMemsetAsync(c->accumPlanes.p, 0, c->accumPlanes.n * sizeof(float4), c->stream));
     c->foldPlanes = 0;
     c->spp = 0;
+    if (c->overflowPinned && *c->overflowPinned) { // a reported overflow is cleared with the image it spoiled (whatever set it has run: the word is only read after a synchronisation)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *c->overflowPinned = 0u;
+    }
     if (c->accumShadow.p) // (zero between pt_render calls unless one failed half-way)
         HIPCHK(c, hipMemsetAsync(c->accumShadow.p, 0, c->accumShadow.n * sizeof(float4), c->stream));
     c->mergePending = false;
@@ -3147,6 +3238,10 @@ int pt_render(pt_ctx* c, uint32_t spp)
         return fail(c, PT_ERR_STATE, "pt_render: scene (static + dynamic) and camera must be set first");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
+    if ((rc = checkOverflow(c)))
+        return rc;
+    if (c->queuesReady && c->q0Small && !derivedPrimariesCapable(c))
+        c->queuesReady = false; // (the first queue was sized for a pinhole's bundles: this camera / scene state queues whole camera rays)
     if ((rc = ensureQueues(c)) || (rc = ensureSpill(c)))
         return rc;
     Prof prof { c };
@@ -3154,6 +3249,28 @@ int pt_render(pt_ctx* c, uint32_t spp)
     const bool fixedSchedule = !parityMode(c) && c->cfg.max_active_rays == 0;
     for (uint32_t s = 0; s < spp;) {
         uint32_t batch = fixedSchedule ? std::min(c->planes, spp - s) : 1u;
+        bool probe = false;
+        if (fixedSchedule && smallQueues(c)) {
+            // Queues smaller than the batch: how much of a batch goes on after the first hit, and how many shadow rays leave from there, is measured -- a report
+            // of an earlier batch of this epoch, or a short PROBE batch whose report is waited for (16 samples per pixel, fewer where even that might not
+            // fit: its samples count like any others) -- and the batch is cut so that it fits with 3 % to spare.
+            if (c->passCountsPending && hipEventQuery(c->passCountsCopied) == hipSuccess)
+                adoptPassCounts(c);
+            else
+                (void)hipGetLastError();
+            if (!c->ratiosKnown) {
+                probe = true;
+                const uint64_t room = std::min(c->capExt, c->capShadow);
+                batch = std::min<uint32_t>(batch, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, room / std::max(c->numOwned, 1u))));
+                if (c->passCountsPending) { // an older report is still on its way: take it first, the probe needs the slot
+                    HIPCHK(c, hipEventSynchronize(c->passCountsCopied));
+                    adoptPassCounts(c);
+                    probe = !c->ratiosKnown;
+                }
+            }
+            if (!probe)
+                batch = std::min(batch, safeBatch(c));
+        }
         if (fixedSchedule) {
             // Up to kGenInterleave samples of a pixel are queue neighbours only if the batch is a multiple of that power of two (k_gen,
             // primaryEntry): a batch of 2 046 would keep TWO together and lose the bundle kernel and every coherent launch behind it.
@@ -3170,6 +3287,15 @@ int pt_render(pt_ctx* c, uint32_t spp)
         }
         c->spp += batch;
         s += batch;
+        if (probe) { // wait for the probe's counters (a few ms of rendering) and learn the ratios
+            c->probeBatches++;
+            if (c->passCountsPending) {
+                HIPCHK(c, hipEventSynchronize(c->passCountsCopied));
+                adoptPassCounts(c);
+            }
+            if (!c->ratiosKnown) // (no report slot: cannot happen -- the probe took care of it above)
+                return fail(c, PT_ERR_STATE, "the probe batch did not report its counters");
+        }
     }
     foldPlanesNow(c); // the accumulator is complete when pt_render's work on the stream is: callers read it with their own tools
     HIPCHK(c, hipEventRecord(c->evStop, c->stream));
@@ -3192,7 +3318,7 @@ int pt_synchronize(pt_ctx* c)
     if (!c)
         return PT_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PT_OK;
+    return checkOverflow(c);
 }
 
 int pt_resolve(pt_ctx* c, float* rgba_out)
@@ -3210,7 +3336,7 @@ int pt_resolve(pt_ctx* c, float* rgba_out)
         c->camera.relativeAperture, c->camera.shutterTime, c->camera.ISO);
     HIPCHK(c, hipMemcpyAsync(rgba_out, c->resolveTmp.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PT_OK;
+    return checkOverflow(c);
     });
 }
 
@@ -3246,7 +3372,7 @@ int pt_read_accum(pt_ctx* c, float* out)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->accum, (size_t)c->cfg.width * c->cfg.height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PT_OK;
+    return checkOverflow(c);
 }
 
 int pt_write_accum(pt_ctx* c, const float* in, uint32_t spp)
@@ -3297,6 +3423,9 @@ int pt_stats_get(pt_ctx* c, pt_stats* out)
     out->stack_need = c->dyn[c->active].stackNeed;
     out->folded_instances = c->dyn[c->active].foldedInstances;
     out->entered_instances = c->dyn[c->active].enteredInstances;
+    out->batch_samples = c->batchSamples;
+    out->probe_batches = c->probeBatches;
+    out->first_pass_ext_ratio = (float)c->ratioExt, out->first_pass_shadow_ratio = (float)c->ratioShadow;
     out->general_route = c->dyn[c->active].generalRoute ? 1u : 0u;
     out->team_launches = c->teamLaunches;
     return PT_OK;
@@ -3465,7 +3594,7 @@ int pt_gen_rays(pt_ctx* c, uint32_t sample, uint32_t n, float* ox, float* oy, fl
     int rc = ensureQueues(c);
     if (rc)
         return rc;
-    if (n > c->capacity)
+    if (n > (c->q0Small ? c->capExt : c->capacity))
         return fail(c, PT_ERR_INVALID, "pt_gen_rays: n exceeds the queue capacity");
     FrameParams fp = frameParams(c, sample);
     launchGen(c, fp, 0, 0, n, 0, 0);
@@ -3506,6 +3635,8 @@ int pt_primary_pass(pt_ctx* c, uint32_t sample, uint32_t batch, uint32_t n, floa
         return rc;
     if (batch > c->planes || n != c->numOwned * batch)
         return fail(c, PT_ERR_INVALID, "pt_primary_pass: batch exceeds samples_in_flight, or n != owned pixels * batch");
+    if (c->q0Small)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_primary_pass: the hook queues whole camera rays; this context's first queue holds directions only (pt_config.ext_queue_fraction)");
     if (n > (1u << 26)) // every entry comes back to the host (68 B each): a hook for tests, not for 531 M-entry batches
         return fail(c, PT_ERR_INVALID, "pt_primary_pass: %u entries -- the hook reads everything back, use it on small frames (<= 64 M entries)", n);
     FrameParams fp = batchFrameParams(c, sample, batch);

@@ -27,7 +27,7 @@ FLAG_QUEUE_PRIMARY_RAYS = 256  # k_gen writes the primary rays even where the pa
 class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_active_rays", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("rng_mode", C.c_uint32), ("seed", C.c_uint32), ("device", C.c_int32),
-                ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32)]
+                ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32), ("ext_queue_fraction", C.c_float), ("shadow_queue_fraction", C.c_float)]
 
 
 class Rect(C.Structure):
@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("ms_shadow", C.c_double), ("ms_gen", C.c_double), ("packet_launches", C.c_uint64), ("ms_packet", C.c_double),
                 ("deposits_shadow", C.c_uint64), ("gen_launches", C.c_uint64), ("bundle_launches", C.c_uint64),
                 ("stack_need", C.c_uint32), ("folded_instances", C.c_uint32), ("team_launches", C.c_uint64),
-                ("entered_instances", C.c_uint32), ("general_route", C.c_uint32)]
+                ("entered_instances", C.c_uint32), ("batch_samples", C.c_uint32), ("first_pass_ext_ratio", C.c_float), ("first_pass_shadow_ratio", C.c_float), ("probe_batches", C.c_uint32), ("general_route", C.c_uint32)]
 
 
 class RaysSoA(C.Structure):
@@ -141,10 +141,10 @@ class Context:
     """One render context on one GPU (mirrors what RayTracer owns, reference src/raytracer.h:54-106)."""
 
     def __init__(self, width, height, max_active_rays=0, max_bounces=0, rng_mode=RNG_COUNTER, seed=1, device=0,
-                 flags=0, samples_in_flight=0):
+                 flags=0, samples_in_flight=0, ext_queue_fraction=0.0, shadow_queue_fraction=0.0):
         self._h = C.c_void_p()
         self.width, self.height = width, height
-        cfg = Config(width, height, max_active_rays, max_bounces, rng_mode, seed, device, flags, samples_in_flight)
+        cfg = Config(width, height, max_active_rays, max_bounces, rng_mode, seed, device, flags, samples_in_flight, ext_queue_fraction, shadow_queue_fraction)
         rc = lib().pt_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()

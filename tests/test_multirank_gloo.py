@@ -142,3 +142,21 @@ def test_the_bench_line_reads_the_counters_of_the_newest_round():
     for flags, name in ((0, "traffic.json"), (2, "traffic_two_level.json")):
         tj = bench.newest_traffic_json(1920, 1080, 6, bench.IN_FLIGHT, 1, flags)
         assert tj is not None and tj["_path"] == os.path.join("profiles", f"round{rounds[-1]}", name), tj and tj["_path"]
+
+
+def test_resident_bytes_follow_the_queue_fractions():
+    """Round 6: queues smaller than the batch.  bench.bytes_per_entry is ensureQueues' accounting (csrc/ptamd.hip): 164 B per entry with queues
+    as large as the batch; with the headline's fractions the 512-sample batch of the 1080p frame stays under 130 GB, and the fallback planner follows."""
+    sys.path.insert(0, ROOT)
+    import bench
+    px = 1920 * 1080
+    assert bench.bytes_per_entry() == bench.bytes_per_entry(0.0, 0.0) == bench.bytes_per_entry(1.0, 1.0) == bench.BYTES_PER_QUEUE_ENTRY == 164
+    assert abs(bench.bytes_per_entry(0.30, 0.55) - (36 + 80 * 0.30 + 48 * 0.55)) < 1e-9  # a pinhole's bundles: the first queue's origin / throughput planes shrink too
+    assert abs(bench.bytes_per_entry(0.30, 0.55, thin_lens=True) - (68 + 48 * 0.30 + 48 * 0.55)) < 1e-9
+    assert bench.bytes_per_entry(0.5, 1.0) == 36 + 80 * 0.5 + 48
+    per = bench.bytes_per_entry(bench.EXT_QUEUE_FRACTION, bench.SHADOW_QUEUE_FRACTION)
+    assert bench.resident_bytes(512, px, per) < 130e9 < bench.resident_bytes(512, px)  # 109 GB against 191 GB
+    assert bench.resident_bytes(1, px, per) == int(px * per)  # one sample in flight: no extra planes
+    # the planner: what fits 150 GB with the fractions is the whole 512, without them 256
+    assert bench.fit_in_flight(512, px, 150 << 30, per_entry=per) == 512 and bench.fit_in_flight(512, px, 150 << 30) == 256
+    assert bench.fit_in_flight(512, px, 80 << 30, per_entry=per) == 256
