@@ -54,11 +54,11 @@ MAX_ENTRIES = 1920 * 1080 * IN_FLIGHT  # path segments resident per rank (~200 G
 BYTES_PER_SHADED_HIT = 160  # read 28 + 20 + 20, write 48 + 44
 BYTES_PER_QUEUE_ENTRY = 164  # resident per queue entry with queues as large as the batch (rounds 1-5): two extension queues (2 x 48 B), the shadow queue (48 B), the hit record (20 B)
 # Round 6: the queues that only hold what a batch's FIRST pass emits are sized by what it emits (pt_config.ext_queue_fraction / shadow_queue_fraction): on config 4
-# 23 % of a batch's entries go on after the first hit and 45 % spawn a shadow ray there (measured by the library itself, roofline.first_pass_ratios of the line); with
-# these fractions a camera-ray batch of a pinhole keeps 36 + 80 x 0.30 + 48 x 0.55 = 86 B per entry resident instead of 164 (a thin lens: 68 + 48 x 0.30 + 48 x 0.55 =
-# 109: its camera rays keep their origins).  The library cuts a batch that would emit more to what fits -- never a wrong image, at worst smaller batches.
+# 26 % of a batch's entries go on after the first hit and 58 % spawn a shadow ray there (measured by the library itself, roofline.first_pass_ratios of the line); with
+# these fractions a camera-ray batch of a pinhole keeps 36 + 80 x 0.30 + 48 x 0.62 = 90 B per entry resident instead of 164 (a thin lens: 68 + 48 x 0.30 + 48 x 0.62 =
+# 112: its camera rays keep their origins).  The library cuts a batch that would emit more to what fits -- never a wrong image, at worst smaller batches.
 EXT_QUEUE_FRACTION = 0.30
-SHADOW_QUEUE_FRACTION = 0.55
+SHADOW_QUEUE_FRACTION = 0.62
 TILE = int(os.environ.get("PTAMD_TILE", "16"))  # edge of the image tiles dealt to the ranks of an N-GPU job.  16 since round 5: every rank's share of the N = 8 job emulated on one
 # GPU (tools/rank_emul.py), slowest rank over fastest: 32 x 32 tiles 1.037 (7.70 x predicted), 16 x 16 1.024 (7.80 x), 8 x 8 1.015 (7.84 x); the variable: diagnostics
 BYTES_PER_GEN_RAY = 32  # origin + pixel, direction + state; a primary ray's throughput is 1 and is not stored

@@ -136,7 +136,7 @@ typedef struct {
                                    Only with max_active_rays == 0 and PT_RNG_COUNTER. */
     /* Round 6: queues SMALLER than a batch (0 = 1: one slot per entry, as the reference allocates, src/raytracer.cpp:760-787).  A batch of B entries needs B hit
      * records and B camera-ray directions, but its second extension queue only holds the paths that go on after the first hit and its shadow queue the shadow
-     * rays of the first hits -- 23 % and 45 % of B on BASELINE config 4.  With fractions f_ext, f_shadow in (0, 1) those queues hold f x (owned pixels x
+     * rays of the first hits -- 26 % and 58 % of B on BASELINE config 4.  With fractions f_ext, f_shadow in (0, 1) those queues hold f x (owned pixels x
      * samples_in_flight) entries: 36 + 80 f_ext + 48 f_shadow bytes per entry instead of 164 (pinhole; a thin lens keeps its camera-ray origins: 68 + 48 f_ext +
      * 48 f_shadow).  pt_render then sizes every batch so that what its first pass emits fits -- from the counts of earlier batches of the same camera, scene
      * and tiles; a short probe batch first -- i.e. a scene that emits more than the fractions allow renders in smaller batches, never wrongly; a guess that

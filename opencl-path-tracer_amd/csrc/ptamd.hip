@@ -1103,13 +1103,13 @@ inline void adoptPassCounts(pt_ctx* c)
         c->ratiosKnown = true;
     }
 }
-// the largest batch (samples per pixel) whose first pass fits the queues, by the ratios seen so far + 3 % + 64 K entries
+// the largest batch (samples per pixel) whose first pass fits the queues, by the ratios seen so far + 3 % + 64 K entries (a 64th of a small queue)
 inline uint32_t safeBatch(const pt_ctx* c)
 {
     auto limit = [&](uint32_t cap, double ratio) -> double {
         if (!(ratio > 0.0))
             return (double)c->planes;
-        const double room = cap > 65536u ? (double)(cap - 65536u) : (double)cap * 0.5;
+        const double room = (double)cap - std::min(65536.0, (double)cap / 64.0);
         return room / (ratio * 1.03 * (double)c->numOwned);
     };
     double b = std::min(limit(c->capExt, c->ratioExt), limit(c->capShadow, c->ratioShadow));

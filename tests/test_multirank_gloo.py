@@ -151,11 +151,11 @@ def test_resident_bytes_follow_the_queue_fractions():
     import bench
     px = 1920 * 1080
     assert bench.bytes_per_entry() == bench.bytes_per_entry(0.0, 0.0) == bench.bytes_per_entry(1.0, 1.0) == bench.BYTES_PER_QUEUE_ENTRY == 164
-    assert abs(bench.bytes_per_entry(0.30, 0.55) - (36 + 80 * 0.30 + 48 * 0.55)) < 1e-9  # a pinhole's bundles: the first queue's origin / throughput planes shrink too
+    assert abs(bench.bytes_per_entry(0.30, 0.55) - (36 + 80 * 0.30 + 48 * 0.55)) < 1e-9 and 85 < bench.bytes_per_entry(bench.EXT_QUEUE_FRACTION, bench.SHADOW_QUEUE_FRACTION) < 95  # a pinhole's bundles: the first queue's origin / throughput planes shrink too
     assert abs(bench.bytes_per_entry(0.30, 0.55, thin_lens=True) - (68 + 48 * 0.30 + 48 * 0.55)) < 1e-9
     assert bench.bytes_per_entry(0.5, 1.0) == 36 + 80 * 0.5 + 48
     per = bench.bytes_per_entry(bench.EXT_QUEUE_FRACTION, bench.SHADOW_QUEUE_FRACTION)
-    assert bench.resident_bytes(512, px, per) < 130e9 < bench.resident_bytes(512, px)  # 109 GB against 191 GB
+    assert bench.resident_bytes(512, px, per) < 130e9 < bench.resident_bytes(512, px)  # 113 GB against 191 GB
     assert bench.resident_bytes(1, px, per) == int(px * per)  # one sample in flight: no extra planes
     # the planner: what fits 150 GB with the fractions is the whole 512, without them 256
     assert bench.fit_in_flight(512, px, 150 << 30, per_entry=per) == 512 and bench.fit_in_flight(512, px, 150 << 30) == 256
