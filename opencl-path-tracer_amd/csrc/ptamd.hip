@@ -493,10 +493,10 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         return dx * dy + dy * dz + dz * dx;
     };
     {
-        std::vector<uint32_t> stack;
-        for (size_t root = 0; root < N; root++) {
+        // post-order over the subtree below `root` (a stack of its own per caller: subtrees are disjoint, so several can be solved side by side)
+        auto solve = [&](size_t root, std::vector<uint32_t>& stack) {
             if (dp[root].done)
-                continue;
+                return;
             stack.push_back((uint32_t)root);
             while (!stack.empty()) {
                 const uint32_t n = stack.back();
@@ -561,10 +561,47 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
                 d.done = 2;
                 stack.pop_back();
             }
+        };
+        // Round 6 (a rebuilt tree per frame: this pass was 0.67 of the 2.4 ms a 20 k-triangle scene spends in pt_upload_static_async): the subtrees five levels
+        // below the roots of large trees are solved on the host library's worker pool, the tops on the calling thread afterwards.  The recurrence has one
+        // solution per node whatever the order: the same tree, byte for byte.
+        std::vector<uint32_t> tasks;
+        const char* seq = getenv("PTAMD_BUILD_THREADS"); // (1: everything on the calling thread, as the host library's builders read it -- tests compare the two)
+        if (N >= 4096 && !(seq && atoi(seq) == 1)) {
+            std::vector<uint8_t> isChild(N, 0);
+            for (size_t n = 0; n < N; n++)
+                for (uint32_t r : { pair[n].left, pair[n].right })
+                    if (isInner(r))
+                        isChild[refIndex(r)] = 1;
+            std::vector<uint32_t> level, next;
+            for (size_t n = 0; n < N; n++)
+                if (!isChild[n])
+                    level.push_back((uint32_t)n);
+            for (int depth = 0; depth < 5 && !level.empty() && level.size() < 64; depth++) {
+                next.clear();
+                for (uint32_t n : level)
+                    for (uint32_t r : { pair[n].left, pair[n].right })
+                        if (isInner(r) && refIndex(r) != n)
+                            next.push_back(refIndex(r));
+                level.swap(next);
+            }
+            std::sort(level.begin(), level.end());
+            level.erase(std::unique(level.begin(), level.end()), level.end()); // (a shared subtree -- refused by the upload's validation anyway -- is solved once)
+            tasks = level;
         }
+        if (tasks.size() >= 2)
+            raytracer::WorkerPool::get().parallelFor(tasks.size(), 1, [&](size_t t0, size_t t1) {
+                std::vector<uint32_t> stack;
+                for (size_t t = t0; t < t1; t++)
+                    solve(tasks[t], stack);
+            });
+        std::vector<uint32_t> stack;
+        for (size_t root = 0; root < N; root++)
+            solve(root, stack);
     }
 #endif
-    for (size_t i = 0; i < pair.size(); i++) {
+    raytracer::WorkerPool::get().parallelFor(pair.size(), 2048, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
         Child kids[4];
         int n = 0;
 #if PT_COLLAPSE_OPTIMAL
@@ -628,6 +665,7 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         }
         out[i] = wk;
     }
+    });
     return out;
 }
 
