@@ -1042,18 +1042,12 @@ def measure_roofline(ctx, torch, args, W, Hh, in_flight, spp_step, world):
     dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dominant]
     achieved = dk["achieved"]
-    # achievable HBM rate on this box (device stream copy, SURVEY 8d asks for both denominators)
-    src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
-    dst = torch.empty_like(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    dst.copy_(src)
-    e0.record()
-    for _ in range(5):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src, dst
+    # achievable HBM rate on this box: a float4 grid-stride copy of 2 x 2 GiB (pt_debug_copy_bandwidth, csrc/pt_bake.h: 5.5-5.6 TB/s on this pool, the best of
+    # sixty shapes; rounds 1-5 timed torch's Tensor.copy_: 4.7-4.9.  MI355X_MICROARCH.md's 6.29 TB/s was not reproduced: quote `frac`, which is of the 8 TB/s peak)
+    try:
+        copy_gbs = ctx.copy_bandwidth(2 << 30, 5)
+    except Exception:
+        copy_gbs = float("nan")
     # SURVEY 8(d) formula over the whole step
     path_bytes = (48.0 * ps["rays_generated"] + 48.0 * ps["rays_extension"] + 160.0 * ps["shade_hits"] + 44.0 * ps["rays_shadow"]
                   + 24.0 * ps["deposits"])

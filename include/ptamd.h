@@ -340,6 +340,9 @@ int pt_shade_batch(pt_ctx* ctx, pt_shade_batch_io* io);
 
 /* test hook, no device needed: the host side of the routine that quantises up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
  * unused slot) into the 64-byte 4-wide node the traversal kernels read (out64).  Every child box must lie inside its quantised box. */
+/* Diagnostic (bench.py, roofline.peak_measured_copy): GB/s, read + written, of a float4 grid-stride device copy of `bytes` bytes -- what the HBM of the box at hand delivers
+ * to the access shape MI355X_MICROARCH.md measures 6.29 TB/s with (the reference has no counterpart). */
+int pt_debug_copy_bandwidth(pt_ctx* ctx, size_t bytes, uint32_t repeat, float* gbps_out);
 int pt_debug_quantise_node(const float* lo12, const float* hi12, const uint32_t* refs4, const uint8_t* empty4, uint32_t empty_ref, void* out64);
 const char* pt_version(void);
 

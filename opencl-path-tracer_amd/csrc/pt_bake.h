@@ -345,4 +345,15 @@ __global__ void __launch_bounds__(256) k_refit_tris(RefitArgs a)
     a.fat[t] = f;
 }
 
+// What a device copy reaches on the box at hand (bench.py, roofline.peak_measured_copy): a float4 grid-stride copy -- every lane 16 bytes per access, a wave 1 KiB,
+// four workgroups of 256 per CU.  The best of the sixty shapes tools/micro/copy_probe.hip tries on this pool's boxes (1 / 4 / 8 accesses in flight per thread,
+// plain / non-temporal, 4-32 workgroups per CU, 256-1024 threads): 5.5-5.6 TB/s of a 2 x 2 GiB copy; hipMemcpyAsync and torch's Tensor.copy_ (rounds 1-5's
+// probe) reach 4.3-5.1.  MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy: not reproduced here -- the line's `frac` is of the 8 TB/s spec peak either way.
+__global__ void __launch_bounds__(256) k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = src[i];
+}
+
 } // namespace ptd

@@ -159,6 +159,11 @@ int ensureQueues(pt_ctx* c)
                 c->capExt = std::min<uint64_t>(cap, (((uint64_t)((double)cap * fe) + 63u) & ~63ull) + 64u);
             if (fs > 0.f && fs < 1.f)
                 c->capShadow = std::min<uint64_t>(cap, (((uint64_t)((double)cap * fs) + 63u) & ~63ull) + 64u);
+            // ... but never less than the probe batch may emit: 16 samples per pixel, every path going on (16: the smallest batch whose camera rays go through
+            // the bundle kernel, which is what queues them as directions only)
+            const uint64_t floorEntries = std::min<uint64_t>(cap, ((16ull * c->numOwned + 63u) & ~63ull));
+            c->capExt = (uint32_t)std::max<uint64_t>(c->capExt, floorEntries);
+            c->capShadow = (uint32_t)std::max<uint64_t>(c->capShadow, floorEntries);
             // camera rays queued as (direction, pixel) only -- a pinhole's bundles, renderSampleFixed `derived` -- leave the first queue's other planes to the later passes
             c->q0Small = c->capExt < cap && derivedPrimariesCapable(c);
         }
@@ -666,7 +671,9 @@ int renderSampleFixed(pt_ctx* c, uint32_t sample, uint32_t batch, Prof& prof)
     // ... and where those are the bundles of a pinhole camera, only (direction, pixel) is queued: k_shade takes the eye as the origin and the sample from the
     // entry index (12 instructions; the full regeneration the paragraph above dismissed is 70) -- 16 B per camera ray less written and 16 B less read
     const bool derived = fused && primaryBundles(c) && !c->camera.thinLens && PT_DERIVED_PRIMARIES; // (a thin lens: every ray has an origin of its own, which stays in the queue)
-    if (c->q0Small && !derived)
+    // (the first queue's origin / throughput planes hold capExt >= 16 samples' worth of entries: a batch that queues whole camera rays -- fewer than 16 samples
+    // per pixel: no bundles -- fits them; a larger one that does so all the same is a change of camera or scene state pt_render has re-made the queues for)
+    if (c->q0Small && !derived && entries > c->capExt)
         return fail(c, PT_ERR_STATE, "the first queue was sized for camera rays queued as directions only, and this batch queues their origins");
     prof.begin(0);
     if (fused)

@@ -53,6 +53,40 @@ int pt_debug_trace_stats(unsigned long long* out, unsigned int n) // n <= 64 cou
 }
 #endif
 
+// Diagnostic (bench.py): GB/s (read + written) of a float4 grid-stride device copy of `bytes` bytes, the best of `repeat` timed runs after a warm-up.
+int pt_debug_copy_bandwidth(pt_ctx* c, size_t bytes, uint32_t repeat, float* gbps_out)
+{
+    return guarded(c, "pt_debug_copy_bandwidth", [&]() -> int {
+    if (!c || !gbps_out || bytes < (1u << 20))
+        return PT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = bytes / sizeof(float4);
+    DevBuf<float4> src, dst;
+    HIPCHK(c, src.alloc(n));
+    HIPCHK(c, dst.alloc(n));
+    HIPCHK(c, hipMemsetAsync(src.p, 0x3c, n * sizeof(float4), c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    const uint32_t blocks = (uint32_t)c->numCUs * 4u; // 1 024 workgroups of 256 on an MI355X (pt_bake.h: the best of the shapes tried)
+    float best = 0.f;
+    for (uint32_t r = 0; r <= std::max(repeat, 1u); r++) { // (run 0: warm-up)
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k_copy_probe, dim3(blocks), dim3(256), 0, c->stream, src.p, dst.p, n);
+        (void)hipEventRecord(e1, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms > 0.f)
+            best = std::max(best, (float)(2.0 * (double)n * sizeof(float4) / (ms * 1e-3) / 1e9));
+    }
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    src.release(), dst.release();
+    *gbps_out = best;
+    return PT_OK;
+    });
+}
+
 const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
 // Test hook, no device needed: the host side of quantiseWideNode (pt_bake.h) -- up to four child boxes (lo / hi: 4 x 3 floats; empty[k] != 0:
@@ -806,8 +840,8 @@ int pt_render(pt_ctx* c, uint32_t spp)
         bool probe = false;
         if (fixedSchedule && smallQueues(c)) {
             // Queues smaller than the batch: how much of a batch goes on after the first hit, and how many shadow rays leave from there, is measured -- a report
-            // of an earlier batch of this epoch, or a short PROBE batch whose report is waited for (16 samples per pixel, fewer where even that might not
-            // fit: its samples count like any others) -- and the batch is cut so that it fits with 3 % to spare.
+            // of an earlier batch of this epoch, or a short PROBE batch whose report is waited for (16 samples per pixel: the queues hold at least what those
+            // can emit, ensureQueues; its samples count like any others) -- and the batch is cut so that it fits with 3 % to spare.
             if (c->passCountsPending && hipEventQuery(c->passCountsCopied) == hipSuccess)
                 adoptPassCounts(c);
             else
@@ -822,8 +856,8 @@ int pt_render(pt_ctx* c, uint32_t spp)
                     probe = !c->ratiosKnown;
                 }
             }
-            if (!probe)
-                batch = std::min(batch, safeBatch(c));
+            if (!probe) // (16 samples per pixel always fit: ensureQueues' floor)
+                batch = std::min(batch, std::max(safeBatch(c), std::min(16u, c->planes)));
         }
         if (fixedSchedule) {
             // Up to kGenInterleave samples of a pixel are queue neighbours only if the batch is a multiple of that power of two (k_gen,

@@ -67,7 +67,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_uplo
            "pt_upload_texture_array", "pt_set_camera", "pt_set_tiles", "pt_set_accum_buffer", "pt_clear", "pt_render",
            "pt_synchronize", "pt_resolve", "pt_resolve_device", "pt_resolve_device_ptr", "pt_read_accum", "pt_write_accum", "pt_accum_device_ptr",
            "pt_samples_per_pixel", "pt_stats_get", "pt_stats_reset", "pt_profile_kernels", "pt_reduce_accum",
-           "pt_intersect", "pt_gen_rays", "pt_primary_pass", "pt_shade_batch", "pt_debug_quantise_node", "pt_version"]
+           "pt_intersect", "pt_gen_rays", "pt_primary_pass", "pt_shade_batch", "pt_debug_quantise_node", "pt_debug_copy_bandwidth", "pt_version"]
 
 _lib = None
 
@@ -285,6 +285,13 @@ class Context:
         s = Stats()
         self._chk(lib().pt_stats_get(self._h, C.byref(s)), "pt_stats_get")
         return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def copy_bandwidth(self, nbytes=1 << 30, repeat=5):
+        """GB/s (read + written) of a float4 grid-stride device copy: the achievable-HBM yardstick of this box."""
+        lib().pt_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]
+        g = C.c_float(0)
+        self._chk(lib().pt_debug_copy_bandwidth(self._h, nbytes, repeat, C.byref(g)), "pt_debug_copy_bandwidth")
+        return float(g.value)
 
     def reset_stats(self):
         self._chk(lib().pt_stats_reset(self._h), "pt_stats_reset")

@@ -83,3 +83,22 @@ def test_a_batch_that_outgrows_its_queues_is_reported_not_rendered(gpu, monkeypa
     want, _ = _render(gpu, b, W, Hh, 2 * n, n, seed=3)
     assert np.allclose(ctx.read_accum()[:, :3], want, rtol=2e-5, atol=2e-5 * want.max())
     ctx.close()
+
+
+def test_few_samples_in_flight_and_short_renders_with_smaller_queues(gpu):
+    """The corners of the batch sizing: 32 samples in flight (the fractions are floored at what the 16-sample probe batch may emit), renders of fewer than 16
+    samples (no bundles: whole camera rays are queued -- they fit the floor), a render that ends in a short batch."""
+    W, Hh = 160, 90
+    b = scenes.instanced_grid(W, Hh, level=3, sky_size=(32, 16))
+    for n, spps in ((32, (32, 64)), (64, (5, 16 + 64 + 7)), (16, (48,))):
+        want_ctx = U.make_ctx(gpu, b, W, Hh, seed=5, samples_in_flight=n)
+        ctx = U.make_ctx(gpu, b, W, Hh, seed=5, samples_in_flight=n, ext_queue_fraction=0.3, shadow_queue_fraction=0.62)
+        for spp in spps:
+            ctx.render(spp)
+            want_ctx.render(spp)
+        a, w = ctx.read_accum()[:, :3], want_ctx.read_accum()[:, :3]
+        assert np.allclose(a, w, rtol=2e-5, atol=2e-5 * w.max()), n
+        for k in ("rays_generated", "rays_extension", "rays_shadow"):
+            assert ctx.stats()[k] == want_ctx.stats()[k], (n, k)
+        ctx.close()
+        want_ctx.close()
