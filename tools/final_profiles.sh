@@ -22,5 +22,14 @@ timeout -k 10 600 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/fi
 echo "bench done"
 run_set gpurun_out/final_tl --flags 2
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --no-secondary --flags 2 > gpurun_out/final_tl/bench.json 2> gpurun_out/final_tl/bench.log
-# (the rank-by-rank emulation of the N = 1 .. 8 jobs is a session of its own: tools/r4_session.sh)
+# round 6: the same scene, every instance entered through the GENERAL route (pt_trace.h LEVELS 2; PTAMD_GENERAL_ROUTE=1 forces it on a scene the fold table
+# would serve): kernel stats + the instruction and issue counters
+SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_BRANCH" "GRBM_GUI_ACTIVE TA_BUSY_avr SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "FETCH_SIZE")
+export PTAMD_GENERAL_ROUTE=1
+run_set gpurun_out/final_gen --flags 2
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-frame --no-secondary --flags 2 > gpurun_out/final_gen/bench.json 2> gpurun_out/final_gen/bench.log
+unset PTAMD_GENERAL_ROUTE
+# (the rank-by-rank emulation of the N = 1 .. 8 jobs is a session of its own: tools/rank_emul.py)
+rm -rf gpurun_out/final*/stats/*/*_agent_info.csv
+du -sh gpurun_out
 tail -c 1500 gpurun_out/final/bench.json
