@@ -1339,6 +1339,7 @@ int pt_shade_batch(pt_ctx* c, pt_shade_batch_io* io)
         a.shadow = { sh.o.p + i, sh.d.p + i, sh.c.p + i };
         a.accum = AccumView { dAcc.p, nullptr, nullptr, 0u };
         a.inCount = dCtl.p, a.outCount = dCtl.p + 1, a.shadowCount = dCtl.p + 2, a.shadeHits = dCtl.p + 3, a.deposits = dCtl.p + 4;
+        a.outCap = a.shadowCap = 0xFFFFFFFFu; // (the hook's own queues: one slot per entry)
         if (generalShading(c))
             hipLaunchKernelGGL((k_shade<false, true>), dim3(1), dim3(64), 0, c->stream, a);
         else
