@@ -989,7 +989,7 @@ struct DynamicHost {
     uint32_t topSlots = 0; // node slots reserved for the top level (the copies start behind them)
     uint32_t bakedNodes = 0, bakedTris = 0;
     bool packetOk = false, hasInstances = false, generalRoute = false;
-    uint32_t stackNeed = 0, enteredInstances = 0;
+    uint32_t stackNeed = 0, enteredInstances = 0, enteredGeneral = 0; // (... of which not a translation + uniform scale)
 };
 
 int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, const pt_top_bvh_node* topNodes, uint32_t nTop, uint32_t topRoot, DynamicHost& out)
@@ -1251,7 +1251,7 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         for (size_t k = 0; k < hInst.size(); k++)
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial)
                 entered++, enteredGeneral += simple(hInst[k]) ? 0u : 1u;
-        out.enteredInstances = entered;
+        out.enteredInstances = entered, out.enteredGeneral = enteredGeneral;
         // A scene with FEW such instances among many translated + uniformly scaled ones (at most a quarter) that fits the table keeps the folded route
         // for those -- no entry step at all -- and parks the few.
         static const char* envGeneral = getenv("PTAMD_GENERAL_ROUTE");
@@ -1259,6 +1259,19 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         const bool mostlySimple = enteredGeneral * 4u <= entered;
         out.generalRoute = !parked && entered > 0u && (envGeneral ? atoi(envGeneral) != 0 : (!mostlySimple || !tableHolds));
         const bool noFold = parked || out.generalRoute || !tableHolds;
+        if (out.generalRoute) { // the entry records of the general route (pt_trace.h): 32 bytes per instance
+            out.instFold.assign(hInst.size() * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (size_t k = 0; k < hInst.size(); k++) {
+                const Instance& in = hInst[k];
+                const bool sim = simple(in);
+                out.instFold[2 * k] = sim ? make_float4(in.r0.x, in.r0.w, in.r1.w, in.r2.w) : make_float4(1.f, 0.f, 0.f, 0.f);
+                float4 tail = make_float4(0.f, 0.f, sim ? 1.0f / in.r0.x : 1.f, 0.f);
+                std::memcpy(&tail.x, &in.rootRef, 4);
+                const uint32_t flag = sim ? 1u : 0u;
+                std::memcpy(&tail.y, &flag, 4);
+                out.instFold[2 * k + 1] = tail;
+            }
+        }
         std::vector<uint8_t> folded(hInst.size(), 0);
         for (size_t k = 0; k < hInst.size() && !noFold; k++)
             if (refCount(topRef[hInst[k].topNode]) == kRefSpecial && simple(hInst[k]))

@@ -126,6 +126,8 @@ struct TraceArgs {
     uint32_t parityShadow; // any-hit: entries carry a FINISHED flag in rayC.w (reference semantics)
     // k_trace<., true>: the table of folded instance transforms, entry 1 + k = (1/s, w) of instance k (the identity for instances that take the general
     // route), entry 0 = the identity; instFoldCount 0: nothing is folded (more instances than the table holds, parity mode, PT_FLAG_PARKED_INSTANCES)
+    // k_trace<., 2> (the general route): the ENTRY records, two float4 per instance -- (1 / s, w) and (root reference, simple flag, s, -); instFoldCount != 0: some
+    // entered instance is NOT a translation + uniform scale (its 3 x 4 rows are wanted)
     const float4* instFold;
     uint32_t instFoldCount;
 };
@@ -832,15 +834,36 @@ __global__ void __launch_bounds__(kTraceBlock, LEVELS == 2 ? PT_TRACE_MIN_WAVES_
                 if (GENERAL && wantLeaf && kindBits == kRefSpecial) {
                     // -------- enter instance refIndex(cur) (scene.cl:116-139): a leaf-kind step.  The lane's registers keep the world-space ray; the
                     // instance-space ray goes into the lane's LDS slot, where the steps on the instance's nodes and triangles read it
+                    // Two records per instance.  The ENTRY record (32 bytes, a.instFold[2 what]: (1 / s, w), then root reference, "simple" flag, s) serves the common
+                    // transform -- a translation + uniform scale -- with the folded route's arithmetic: three FMAs, six products, no reciprocal, no zero-component
+                    // fix-ups (the world ray has had its own).  A crowd of such instances runs this block in four leaf iterations of five (208 instances: +19 %
+                    // vector instructions per ray against the copied scene with the full transform in it, profiles/round6/r6d_*); the full 3 x 4 transform
+                    // (rayIntoInstance on the 64-byte Instance record: the parked route's arithmetic, bit for bit) runs only where a lane needs it.
                     const uint32_t what = refIndex(cur);
+                    const float4* ep = (const float4*)((const char*)a.instFold + (size_t)(what << 5));
+                    const float4 ef = ep[0], et = ep[1];
+                    // (a scene that holds instances of the other kind -- a.instFoldCount, wave-uniform -- fetches their rows in the same round trip: fetched only once
+                    // the flag has arrived they cost the general scene a second, dependent one -- 0.999 against 1.008 of the copied scene; both forms behind
+                    // branches of their own, the entry record's first half fetched inside: 0.879 against 0.899 on the uniform crowd)
+                    const bool rows = a.instFoldCount != 0u;
                     const Instance* ip = (const Instance*)((const char*)sc.instances + (size_t)(what << 6));
                     static_assert(sizeof(Instance) == 64, "an instance record is addressed by index << 6");
-                    const float4 r0 = ip->r0, r1 = ip->r1, r2 = ip->r2;
-                    const uint32_t root = ip->rootRef;
-                    V3 to, td;
-                    rayIntoInstance(r0, r1, r2, co, cd, &to, &td);
+                    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+                    if (rows)
+                        r0 = ip->r0, r1 = ip->r1, r2 = ip->r2;
+                    const uint32_t root = asU(et.x);
+                    const bool simple = asU(et.y) != 0u;
+                    V3 to = mk(fmaf(co.x, ef.x, ef.y), fmaf(co.y, ef.x, ef.z), fmaf(co.z, ef.x, ef.w));
+                    V3 td = mk(cd.x * ef.x, cd.y * ef.x, cd.z * ef.x);
+                    V3 tid = mk(cid.x * et.z, cid.y * et.z, cid.z * et.z);
+                    if (rows && __ballot(!simple) != 0ull) { // (wave-uniform)
+                        if (!simple) {
+                            rayIntoInstance(r0, r1, r2, co, cd, &to, &td);
+                            tid = mk(rcpSlab(td.x), rcpSlab(td.y), rcpSlab(td.z));
+                        }
+                    }
                     ldsObj[wave][0][lane] = to.x, ldsObj[wave][1][lane] = to.y, ldsObj[wave][2][lane] = to.z;
-                    ldsObj[wave][3][lane] = rcpSlab(td.x), ldsObj[wave][4][lane] = rcpSlab(td.y), ldsObj[wave][5][lane] = rcpSlab(td.z);
+                    ldsObj[wave][3][lane] = tid.x, ldsObj[wave][4][lane] = tid.y, ldsObj[wave][5][lane] = tid.z;
                     ldsObj[wave][6][lane] = td.x, ldsObj[wave][7][lane] = td.y, ldsObj[wave][8][lane] = td.z;
                     curInst = (int)what;
                     cur = root; // nothing pushed: what lies below on the stack are world-space references, which read the world-space ray

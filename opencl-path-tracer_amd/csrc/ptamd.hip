@@ -623,7 +623,7 @@ int pt_upload_dynamic_async(pt_ctx* c, const pt_emissive_triangle* lights, uint3
     d.numTris = c->st->numTris, d.firstWorldNode = (uint32_t)sg.wide.size();
     d.rootRefFolded = h.rootRefFolded;
     d.foldedInstances = h.foldedInstances;
-    d.instRootBase = h.instRootBase, d.numInstRoots = (uint32_t)h.instRoots.size(), d.instFoldCount = (uint32_t)h.instFold.size();
+    d.instRootBase = h.instRootBase, d.numInstRoots = (uint32_t)h.instRoots.size(), d.instFoldCount = h.generalRoute ? h.enteredGeneral : (uint32_t)h.instFold.size(); // (the general route: how many entered instances want their 3 x 4 rows)
     d.packetOk = h.packetOk;
     d.stackNeed = h.stackNeed;
     d.hasInstances = h.hasInstances;
