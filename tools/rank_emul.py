@@ -41,7 +41,7 @@ for world in args.worlds:
     if args.scaling == "strong":
         in_flight = min(in_flight, args.in_flight * args.rounds)
     spp_step = in_flight * args.rounds if args.scaling == "weak" else args.in_flight * args.rounds
-    ctx = D.Context(W, Hh, seed=1, samples_in_flight=in_flight)
+    ctx = D.Context(W, Hh, seed=1, samples_in_flight=in_flight, ext_queue_fraction=bench.EXT_QUEUE_FRACTION, shadow_queue_fraction=bench.SHADOW_QUEUE_FRACTION)  # as bench.py's ranks
     ctx.upload_scene(b.flat, sky=b.sky)
     ctx.set_camera(b.camera)
     times, rays = {}, {}
