@@ -117,10 +117,10 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         return dx * dy + dy * dz + dz * dx;
     };
     {
-        // post-order over the subtree below `root` (a stack of its own per caller: subtrees are disjoint, so several can be solved side by side)
-        auto solve = [&](size_t root, std::vector<uint32_t>& stack) {
+        std::vector<uint32_t> stack;
+        for (size_t root = 0; root < N; root++) {
             if (dp[root].done)
-                return;
+                continue;
             stack.push_back((uint32_t)root);
             while (!stack.empty()) {
                 const uint32_t n = stack.back();
@@ -185,47 +185,13 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
                 d.done = 2;
                 stack.pop_back();
             }
-        };
-        // Round 6 (a rebuilt tree per frame: this pass was 0.67 of the 2.4 ms a 20 k-triangle scene spends in pt_upload_static_async): the subtrees five levels
-        // below the roots of large trees are solved on the host library's worker pool, the tops on the calling thread afterwards.  The recurrence has one
-        // solution per node whatever the order: the same tree, byte for byte.
-        std::vector<uint32_t> tasks;
-        const char* seq = getenv("PTAMD_BUILD_THREADS"); // (1: everything on the calling thread, as the host library's builders read it -- tests compare the two)
-        if (N >= 4096 && !(seq && atoi(seq) == 1)) {
-            std::vector<uint8_t> isChild(N, 0);
-            for (size_t n = 0; n < N; n++)
-                for (uint32_t r : { pair[n].left, pair[n].right })
-                    if (isInner(r))
-                        isChild[refIndex(r)] = 1;
-            std::vector<uint32_t> level, next;
-            for (size_t n = 0; n < N; n++)
-                if (!isChild[n])
-                    level.push_back((uint32_t)n);
-            for (int depth = 0; depth < 5 && !level.empty() && level.size() < 64; depth++) {
-                next.clear();
-                for (uint32_t n : level)
-                    for (uint32_t r : { pair[n].left, pair[n].right })
-                        if (isInner(r) && refIndex(r) != n)
-                            next.push_back(refIndex(r));
-                level.swap(next);
-            }
-            std::sort(level.begin(), level.end());
-            level.erase(std::unique(level.begin(), level.end()), level.end()); // (a shared subtree -- refused by the upload's validation anyway -- is solved once)
-            tasks = level;
         }
-        if (tasks.size() >= 2)
-            raytracer::WorkerPool::get().parallelFor(tasks.size(), 1, [&](size_t t0, size_t t1) {
-                std::vector<uint32_t> stack;
-                for (size_t t = t0; t < t1; t++)
-                    solve(tasks[t], stack);
-            });
-        std::vector<uint32_t> stack;
-        for (size_t root = 0; root < N; root++)
-            solve(root, stack);
+        // (Round 6 solved the subtrees five levels below the roots on the host library's worker pool, and the per-node child lists below in parallel: the pass
+        // went from 0.67 to ~0.45 ms on a 20 k-triangle mesh -- and the NEXT Mesh build on the same pool from 2.55 to 3.43 ms: 7.34 against 6.97 ms per rebuilt-tree
+        // tick, twice, inside bench.py and outside.  Sequential again; EXPERIMENTS.md.)
     }
 #endif
-    raytracer::WorkerPool::get().parallelFor(pair.size(), 2048, [&](size_t i0, size_t i1) {
-    for (size_t i = i0; i < i1; i++) {
+    for (size_t i = 0; i < pair.size(); i++) {
         Child kids[4];
         int n = 0;
 #if PT_COLLAPSE_OPTIMAL
@@ -289,7 +255,6 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         }
         out[i] = wk;
     }
-    });
     return out;
 }
 

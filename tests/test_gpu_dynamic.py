@@ -503,23 +503,3 @@ def test_a_rebuilt_tree_per_frame_is_adopted_at_the_tick_while_the_old_one_rende
     ctx.render(8)
     assert np.array_equal(ctx.read_accum(), fresh(flat_b)[1])
     ctx.close()
-
-
-def test_the_conversion_on_the_worker_pool_makes_the_sequential_tree(gpu, monkeypatch):
-    """pt_upload_static collapses the caller's binary trees to 4-wide nodes by dynamic programming; since round 6 the subtrees of large trees are solved on the
-    host library's worker pool (a rebuilt tree per frame: 0.67 of its 2.4 ms).  The recurrence has one solution per node: hits and images of the two builds of the
-    SAME arrays must agree to the bit (an image bit that differs would mean another tree: another traversal order, another winner of an exact-t tie)."""
-    b = scenes.blob_room(W, Hh, level=5, builder=H.BVH_SPATIAL_SPLIT)  # 20 480 triangles: above the threshold of the parallel path
-    o, d = U.random_rays(40000, 13, (-0.9, 0.1, -0.9), (0.9, 1.9, 0.9))
-    res = []
-    for seq in (False, True):
-        if seq:
-            monkeypatch.setenv("PTAMD_BUILD_THREADS", "1")
-        ctx = U.make_ctx(gpu, b, W, Hh, seed=4, samples_in_flight=1)
-        h = ctx.intersect(o, d)
-        ctx.render(4)
-        res.append((h, ctx.read_accum().copy(), ctx.stats()["stack_need"]))
-        ctx.close()
-    for k in ("t", "u", "v", "prim", "inst"):
-        assert np.array_equal(res[0][0][k], res[1][0][k]), k
-    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
