@@ -44,8 +44,10 @@ def _states(n):
     return b, flats
 
 
-def test_asynchronous_uploads_render_every_state_like_a_fresh_context(gpu):
-    """A frame loop that never waits: render state k (asynchronous), convert + copy state k+1 into the inactive buffers while it
+@pytest.mark.parametrize("instances", ["copied", "entered_general_route"])
+def test_asynchronous_uploads_render_every_state_like_a_fresh_context(gpu, instances):
+    """(entered_general_route, round 6: nothing copied -- the turned instances are entered through the general route, whose entry records are part of the
+    double-buffered dynamic set like the instance table.)  A frame loop that never waits: render state k (asynchronous), convert + copy state k+1 into the inactive buffers while it
     renders, tick, render k+1, ...  Each frame's accumulator is copied out in stream order by a torch op on the same stream.
     Every frame equals the render of a fresh context that only ever saw that state (counter PRNG: bit for bit) -- no frame
     reads a half-written or a too-new set although nothing synchronises with the host in between."""
@@ -55,7 +57,8 @@ def test_asynchronous_uploads_render_every_state_like_a_fresh_context(gpu):
     frames = []
     with torch.cuda.stream(s):
         acc = torch.zeros(W * Hh, 4, device="cuda")
-        ctx = gpu.Context(W, Hh, seed=5)
+        flags = gpu.FLAG_NO_BAKED_INSTANCES if instances == "entered_general_route" else 0
+        ctx = gpu.Context(W, Hh, seed=5, flags=flags)
         ctx.set_stream(s.cuda_stream)
         ctx.set_accum_buffer(acc.data_ptr())
         ctx.upload_scene(flats[0], sky=b.sky)
@@ -68,9 +71,11 @@ def test_asynchronous_uploads_render_every_state_like_a_fresh_context(gpu):
                 ctx.upload_dynamic_async(flats[k + 1])  # host conversion + copy-stream upload overlap the render above
                 ctx.frame_tick()
         got = [f.cpu().numpy() for f in frames]
+        general = ctx.stats()["general_route"]
     ctx.close()
+    assert general == (1 if flags else 0)  # (the last state: four turned instances entered)
     for k, flat in enumerate(flats):
-        fresh = gpu.Context(W, Hh, seed=5)
+        fresh = gpu.Context(W, Hh, seed=5, flags=flags)
         fresh.upload_scene(flat, sky=b.sky)
         fresh.set_camera(b.camera)
         fresh.render(8)
