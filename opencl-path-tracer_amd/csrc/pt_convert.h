@@ -136,15 +136,22 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
                             stack.push_back(refIndex(r));
                     continue;
                 }
-                // children are final (or n sits on a cycle, which upload validation has already excluded): combine
-                auto costSide = [&](int side, int k) {
+                // children are final (or n sits on a cycle, which upload validation has already excluded): combine.  What either side costs with k slots,
+                // looked up once: the child's own table, or one number for every k (a given leaf: what a visit of it costs; nothing where the leaves are given)
+                double flat[2][5];
+                const double* cost[2];
+                for (int side = 0; side < 2; side++) {
                     const uint32_t r = kids[side];
-                    if (isInner(r) && dp[refIndex(r)].done == 2)
-                        return dp[refIndex(r)].atMost[k];
-                    if (leafCosts && r != kRefNone && refCount(r) >= 1u && refCount(r) <= kMaxLeafTris) // a given leaf: what a visit of it costs
-                        return costs.leaf(refCount(r)) * childArea(pair[n], side);
-                    return 0.0;
-                };
+                    if (isInner(r) && dp[refIndex(r)].done == 2) {
+                        cost[side] = dp[refIndex(r)].atMost;
+                        continue;
+                    }
+                    const double v = leafCosts && r != kRefNone && refCount(r) >= 1u && refCount(r) <= kMaxLeafTris ? costs.leaf(refCount(r)) * childArea(pair[n], side) : 0.0;
+                    for (int k = 1; k <= 4; k++)
+                        flat[side][k] = v;
+                    cost[side] = flat[side];
+                }
+                auto costSide = [&](int side, int k) { return cost[side][k]; };
                 Dp& d = dp[n];
                 // the subtree's triangle references as one run?
                 d.asLeaf = 0, d.leafFirst = 0, d.leafCount = 0;
@@ -166,9 +173,10 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
                     if (v < best)
                         best = v, d.rootSplit = (uint8_t)i;
                 }
-                d.atMost[1] = (leafCosts ? costs.inner : 1.0) * nodeArea(n) + best;
+                const double ownArea = nodeArea(n);
+                d.atMost[1] = (leafCosts ? costs.inner : 1.0) * ownArea + best;
                 if (d.leafCount) {
-                    const double asLeaf = costs.leaf(d.leafCount) * nodeArea(n);
+                    const double asLeaf = costs.leaf(d.leafCount) * ownArea;
                     if (asLeaf < d.atMost[1])
                         d.atMost[1] = asLeaf, d.asLeaf = 1;
                 }
@@ -645,6 +653,19 @@ int buildStaticGeom(pt_ctx* c)
     tm.lap("stackNeed");
     buildFat(c);
     tm.lap("buildFat");
+    if (getenv("PTAMD_TREE_HASH")) { // what a conversion made, in one line (tools/tree_hash.py: a change to the conversion's code that is meant to keep its result)
+        auto fnv = [](const void* p, size_t n) {
+            uint64_t h = 1469598103934665603ull;
+            for (size_t i = 0; i < n; i++)
+                h = (h ^ ((const uint8_t*)p)[i]) * 1099511628211ull;
+            return (unsigned long long)h;
+        };
+        fprintf(stderr, "[ptamd] tree hash: wide %zu %016llx boxes %016llx leafOfs %016llx refTri %zu %016llx kidSrc %016llx kidBoxNode %016llx stackNeed %016llx fat %016llx pairs %zu %016llx\n",
+            g.wide.size(), fnv(g.wide.data(), g.wide.size() * sizeof(WideNode)), fnv(g.boxes.data(), g.boxes.size() * sizeof(g.boxes[0])),
+            fnv(g.leafOfs.data(), g.leafOfs.size() * 4), g.refTri.size(), fnv(g.refTri.data(), g.refTri.size() * 4), fnv(g.kidSrc.data(), g.kidSrc.size() * 4),
+            fnv(g.kidBoxNode.data(), g.kidBoxNode.size() * 4), fnv(g.stackNeed.data(), g.stackNeed.size() * 4), fnv(g.fat.data(), g.fat.size() * sizeof(g.fat[0])),
+            c->st->hostBottomNodes.size(), fnv(c->st->hostBottomNodes.data(), c->st->hostBottomNodes.size() * sizeof(PairNode)));
+    }
     g.emptyRef = emptyRef;
     g.version = ++c->staticVersions;
     g.topology = g.version;
@@ -773,7 +794,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
         const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
         return dx * dy + dy * dz + dz * dx;
     };
-    std::function<uint32_t(Range, V3&, V3&)> leafRef = [&](Range r, V3& lo, V3& hi) -> uint32_t {
+    auto leafRefImpl = [&](auto& leafRef, Range r, V3& lo, V3& hi) -> uint32_t {
         lo = mk(FLT_MAX), hi = mk(-FLT_MAX);
         if (r.count <= maxLeaf) {
             for (uint32_t t = 0; t < r.count; t++)
@@ -794,8 +815,8 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
             }
         }
         V3 llo, lhi, rlo, rhi;
-        const uint32_t l = leafRef({ r.first, half }, llo, lhi);
-        const uint32_t rr = leafRef({ r.first + half, r.count - half }, rlo, rhi);
+        const uint32_t l = leafRef(leafRef, { r.first, half }, llo, lhi);
+        const uint32_t rr = leafRef(leafRef, { r.first + half, r.count - half }, rlo, rhi);
         PairNode pn {};
         pn.bx = make_float4(llo.x, lhi.x, rlo.x, rhi.x);
         pn.by = make_float4(llo.y, lhi.y, rlo.y, rhi.y);
@@ -814,7 +835,7 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
                 c->st->nodeRef[i] = makeRef(nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount);
             } else {
                 V3 lo, hi;
-                c->st->nodeRef[i] = leafRef({ nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount }, lo, hi);
+                c->st->nodeRef[i] = leafRefImpl(leafRefImpl, { nodes[i].leftChildOrFirstTriangle, nodes[i].triangleCount }, lo, hi);
             }
         } else if (dense[i] != 0xFFFFFFFFu) {
             c->st->nodeRef[i] = makeRef(dense[i], 0);

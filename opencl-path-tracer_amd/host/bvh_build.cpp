@@ -61,6 +61,8 @@ namespace {
         return env && std::atoi(env) == 1;
     }
 
+    inline float centerOn(const AABB& b, int axis) { return (b.min[axis] + b.max[axis]) / 2.0f; } // AABB::center()[axis], one component computed
+
     inline int binOf(float x, float lo, float invWidth, int numBins)
     {
         int b = (int)((x - lo) * invWidth);
@@ -68,7 +70,9 @@ namespace {
     }
 
     // ---- object split: bin reference-box centroids, sweep 31 planes -----------------------
-    Candidate findObjectSplit(const AABB& nodeBox, const std::vector<PrimRef>& refs, const int* axes, int numAxes)
+    // (the sweeps visit the occupied bins only: a plane behind an empty bin repeats the candidate before it, which the strict comparison never
+    // prefers -- the same choice as a sweep over all 31 planes, at the cost of the bins a small node really fills)
+    Candidate findObjectSplit(const AABB& nodeBox, const PrimRef* refs, size_t numRefs, const int* axes, int numAxes)
     {
         Candidate best;
         vec3 ext = nodeBox.extent();
@@ -82,22 +86,22 @@ namespace {
             auto binRange = [&](size_t begin, size_t end, std::array<AABB, kObjectBins>& bx, std::array<size_t, kObjectBins>& cn) {
                 for (size_t i = begin; i < end; i++) {
                     const PrimRef& r = refs[i];
-                    int b = binOf(r.box.center()[axis], nodeBox.min[axis], invWidth, kObjectBins);
+                    int b = binOf(centerOn(r.box, axis), nodeBox.min[axis], invWidth, kObjectBins);
                     bx[b].fit(r.box);
                     cn[b]++;
                 }
             };
-            if (refs.size() >= kParallelBinning && WorkerPool::get().threads() > 1 && !WorkerPool::insideTask() && !sequentialBuild()) {
+            if (numRefs >= kParallelBinning && WorkerPool::get().threads() > 1 && !WorkerPool::insideTask() && !sequentialBuild()) {
                 // the top of a large tree: every worker bins a range into bins of its own (min / max and counts: the merged bins do not depend on the split)
                 WorkerPool& pool = WorkerPool::get();
-                const size_t parts = pool.threads(), chunk = (refs.size() + parts - 1) / parts;
+                const size_t parts = pool.threads(), chunk = (numRefs + parts - 1) / parts;
                 std::vector<std::array<AABB, kObjectBins>> pbox(parts);
                 std::vector<std::array<size_t, kObjectBins>> pcount(parts);
                 for (auto& c : pcount)
                     c.fill(0);
                 pool.parallelFor(parts, 1, [&](size_t p0, size_t p1) {
                     for (size_t p = p0; p < p1; p++)
-                        binRange(std::min(p * chunk, refs.size()), std::min((p + 1) * chunk, refs.size()), pbox[p], pcount[p]);
+                        binRange(std::min(p * chunk, numRefs), std::min((p + 1) * chunk, numRefs), pbox[p], pcount[p]);
                 });
                 for (size_t p = 0; p < parts; p++)
                     for (int b = 0; b < kObjectBins; b++) {
@@ -105,36 +109,42 @@ namespace {
                         count[b] += pcount[p][b];
                     }
             } else {
-                binRange(0, refs.size(), box, count);
+                binRange(0, numRefs, box, count);
             }
-            // suffix boxes/counts, then a forward sweep
-            std::array<AABB, kObjectBins> rightBox;
-            std::array<size_t, kObjectBins> rightCount {};
+            uint32_t occupied = 0;
+            for (int b = 0; b < kObjectBins; b++)
+                occupied |= count[b] ? 1u << b : 0u;
+            // what lies right of each occupied bin (boxes / counts accumulated from the top down), then a forward sweep
+            std::array<AABB, kObjectBins> rightBox; // [b]: the bins above b
+            std::array<size_t, kObjectBins> rightCount;
             AABB acc;
             size_t n = 0;
-            for (int b = kObjectBins - 1; b >= 1; b--) {
-                acc.fit(box[b]);
-                n += count[b];
+            for (uint32_t m = occupied; m;) {
+                const int b = 31 - __builtin_clz(m);
+                m &= ~(1u << b);
                 rightBox[b] = acc;
                 rightCount[b] = n;
+                acc.fit(box[b]);
+                n += count[b];
             }
             AABB left;
             size_t nl = 0;
-            for (int plane = 1; plane < kObjectBins; plane++) {
-                left.fit(box[plane - 1]);
-                nl += count[plane - 1];
-                if (nl == 0 || rightCount[plane] == 0)
-                    continue;
-                float cost = (float)nl * left.surfaceArea() + (float)rightCount[plane] * rightBox[plane].surfaceArea();
+            for (uint32_t m = occupied; m; m &= m - 1) {
+                const int b = __builtin_ctz(m);
+                left.fit(box[b]);
+                nl += count[b];
+                if (rightCount[b] == 0)
+                    break; // the last occupied bin: nothing on the right
+                float cost = (float)nl * left.surfaceArea() + (float)rightCount[b] * rightBox[b].surfaceArea();
                 if (!best.valid || cost < best.cost) {
                     best.valid = true;
                     best.axis = axis;
-                    best.plane = plane;
+                    best.plane = b + 1;
                     best.cost = cost;
                     best.leftBox = left;
-                    best.rightBox = rightBox[plane];
+                    best.rightBox = rightBox[b];
                     best.leftCount = nl;
-                    best.rightCount = rightCount[plane];
+                    best.rightCount = rightCount[b];
                 }
             }
         }
@@ -382,22 +392,31 @@ namespace {
             uint32_t depth;
             std::vector<PrimRef> refs;
         };
+        // the object-split builders work in place (as the reference's buildBVHInPlace, src/bvh/bvh_build.cpp:195-215): a node is a range of ONE array
+        struct Range {
+            uint32_t node, depth;
+            size_t begin, end;
+        };
+        PrimRef* all = nullptr; // the references, and room of the same size for the right side of a partition (which keeps the order on both sides:
+        PrimRef* spare = nullptr; // the tree is the one the list-based build made, byte for byte)
 
-        void makeLeaf(uint32_t node, const std::vector<PrimRef>& refs)
+        void makeLeaf(uint32_t node, const PrimRef* refs, size_t count)
         {
             nodes[node].leftChildOrFirstTriangle = (uint32_t)leafRefs.size();
-            nodes[node].triangleCount = (uint32_t)refs.size();
-            leafRefs.insert(leafRefs.end(), refs.begin(), refs.end());
+            nodes[node].triangleCount = (uint32_t)count;
+            leafRefs.insert(leafRefs.end(), refs, refs + count);
             if (deferred)
                 topLeaves.push_back({ node, (uint32_t)deferred->size() });
         }
+        void makeLeaf(uint32_t node, const std::vector<PrimRef>& refs) { makeLeaf(node, refs.data(), refs.size()); }
 
         // A subtree set aside by the top phase of a parallel build: the slot of its root (already holding its box), and where the sequential build's arrays
         // stood when it would have been built -- everything it allocates comes right there, ahead of what the top phase allocated afterwards.
         struct Deferred {
             uint32_t slot, depth;
-            std::vector<PrimRef> refs;
+            std::vector<PrimRef> refs; // (spatial splits: a list of its own)
             size_t nodesBefore, leavesBefore; // sizes of the top phase's arrays at that moment
+            size_t begin = 0, end = 0; // (object splits: its range of `all`)
         };
         std::vector<uint32_t> pairEpoch; // per pair of `nodes` (top phase): how many subtrees had been set aside when it was allocated
         std::vector<std::pair<uint32_t, uint32_t>> topLeaves; // (node, epoch) of the leaves the top phase made itself
@@ -433,7 +452,7 @@ namespace {
                     auto sah = [&](const Candidate& c) { return kTraversalCost + c.cost * kIntersectCost / area; };
                     static const int allAxes[3] = { 0, 1, 2 };
                     int one = longestAxis(nodeBox.extent());
-                    Candidate obj = (kind == BvhBuilder::BinnedFast) ? findObjectSplit(nodeBox, w.refs, &one, 1) : findObjectSplit(nodeBox, w.refs, allAxes, 3);
+                    Candidate obj = (kind == BvhBuilder::BinnedFast) ? findObjectSplit(nodeBox, w.refs.data(), n, &one, 1) : findObjectSplit(nodeBox, w.refs.data(), n, allAxes, 3);
                     bool objOk = obj.valid && area > 0.0f && sah(obj) < leafCost;
                     bool done = false;
                     if (kind == BvhBuilder::SpatialSplit && area > 0.0f) {
@@ -477,15 +496,77 @@ namespace {
             }
         }
 
-        void run(std::vector<PrimRef>&& all)
+        // binned object splits only (BinnedSAH, BinnedFast): the same decisions as build(), node by node and in the same order, on ranges
+        void buildRanges(std::vector<Range>& stack)
+        {
+            while (!stack.empty()) {
+                const Range w = stack.back();
+                stack.pop_back();
+                const size_t n = w.end - w.begin;
+                if (deferred && w.depth > 0 && n <= deferBelow && n > kLeafSize) { // a worker thread's share (buildParallel)
+                    deferred->push_back({ w.node, w.depth, {}, nodes.size(), leafRefs.size(), w.begin, w.end });
+                    continue;
+                }
+                maxDepthSeen = std::max(maxDepthSeen, w.depth);
+                const AABB nodeBox = loadBox(nodes[w.node]);
+                PrimRef* refs = all + w.begin;
+                if (n <= kLeafSize || w.depth >= (uint32_t)kMaxBvhDepth) {
+                    makeLeaf(w.node, refs, n);
+                    continue;
+                }
+                AABB leftBox, rightBox;
+                size_t numLeft = 0;
+                if (w.depth >= (uint32_t)kMedianFallbackDepth) {
+                    const int axis = longestAxis(nodeBox.extent());
+                    numLeft = n / 2;
+                    std::nth_element(refs, refs + numLeft, refs + n, [axis](const PrimRef& x, const PrimRef& y) {
+                        return x.box.center()[axis] < y.box.center()[axis];
+                    });
+                    for (size_t i = 0; i < numLeft; i++) leftBox.fit(refs[i].box);
+                    for (size_t i = numLeft; i < n; i++) rightBox.fit(refs[i].box);
+                } else {
+                    const float area = nodeBox.surfaceArea();
+                    static const int allAxes[3] = { 0, 1, 2 };
+                    const int one = longestAxis(nodeBox.extent());
+                    const Candidate obj = (kind == BvhBuilder::BinnedFast) ? findObjectSplit(nodeBox, refs, n, &one, 1) : findObjectSplit(nodeBox, refs, n, allAxes, 3);
+                    if (obj.valid && area > 0.0f && kTraversalCost + obj.cost * kIntersectCost / area < (float)n * kIntersectCost) {
+                        const float invWidth = (float)kObjectBins / nodeBox.extent()[obj.axis], lo = nodeBox.min[obj.axis];
+                        PrimRef* right = spare + w.begin;
+                        size_t numRight = 0;
+                        for (size_t i = 0; i < n; i++) {
+                            if (binOf(centerOn(refs[i].box, obj.axis), lo, invWidth, kObjectBins) < obj.plane)
+                                refs[numLeft++] = refs[i];
+                            else
+                                right[numRight++] = refs[i];
+                        }
+                        std::copy(right, right + numRight, refs + numLeft);
+                        leftBox = obj.leftBox;
+                        rightBox = obj.rightBox;
+                    }
+                }
+                if (numLeft == 0 || numLeft == n) {
+                    makeLeaf(w.node, refs, n);
+                    continue;
+                }
+                const uint32_t pair = allocPair();
+                nodes[w.node].leftChildOrFirstTriangle = pair;
+                nodes[w.node].triangleCount = 0;
+                storeBox(nodes[pair], leftBox);
+                storeBox(nodes[pair + 1], rightBox);
+                stack.push_back({ pair, w.depth + 1, w.begin, w.begin + numLeft });
+                stack.push_back({ pair + 1, w.depth + 1, w.begin + numLeft, w.end });
+            }
+        }
+
+        void run(std::vector<PrimRef>&& refs)
         {
             AABB rootBox;
-            for (auto& r : all) rootBox.fit(r.box);
+            for (auto& r : refs) rootBox.fit(r.box);
             rootArea = rootBox.surfaceArea();
             // Large meshes: the top of the tree here, the subtrees below ~1/12 of the references on the worker threads, each into arrays of its own; the
             // result is put together in the order the sequential build allocates (a subtree's nodes and leaves are contiguous there: the build is depth
             // first), so the arrays are the same bytes whatever the thread count -- PTAMD_BUILD_THREADS=1 builds sequentially (tests compare the two).
-            const size_t n = all.size();
+            const size_t n = refs.size();
             const bool parallel = n >= 8192 && WorkerPool::get().threads() > 1 && !sequentialBuild();
             std::vector<Deferred> subtrees;
             if (parallel) {
@@ -494,10 +575,18 @@ namespace {
             }
             uint32_t root = allocPair();
             storeBox(nodes[root], rootBox);
-            std::vector<Work> stack;
-            stack.push_back({ root, 0, std::move(all) });
             const auto t0 = std::chrono::steady_clock::now();
-            build(stack);
+            std::vector<PrimRef> room;
+            if (kind == BvhBuilder::SpatialSplit) {
+                std::vector<Work> stack;
+                stack.push_back({ root, 0, std::move(refs) });
+                build(stack);
+            } else {
+                room.resize(n);
+                all = refs.data(), spare = room.data();
+                std::vector<Range> stack { { root, 0, 0, n } };
+                buildRanges(stack);
+            }
             const auto t1 = std::chrono::steady_clock::now();
             deferred = nullptr;
             if (!subtrees.empty())
@@ -516,14 +605,22 @@ namespace {
             pool.parallelFor(pool.threads(), 1, [&](size_t, size_t) {
                 for (size_t k; (k = next.fetch_add(1)) < numSub;) {
                     Builder& b = local[k];
+                    Deferred& d = subtrees[k];
+                    const size_t count = kind == BvhBuilder::SpatialSplit ? d.refs.size() : d.end - d.begin;
                     b.rootArea = rootArea;
-                    b.nodes.reserve(subtrees[k].refs.size() + 2);
-                    b.leafRefs.reserve(subtrees[k].refs.size() + subtrees[k].refs.size() / 4);
+                    b.nodes.reserve(count + 2);
+                    b.leafRefs.reserve(count + count / 4);
                     b.allocPair(); // [0]: a copy of the subtree's root slot, [1]: unused
-                    b.nodes[0] = nodes[subtrees[k].slot];
-                    std::vector<Work> stack;
-                    stack.push_back({ 0u, subtrees[k].depth, std::move(subtrees[k].refs) });
-                    b.build(stack);
+                    b.nodes[0] = nodes[d.slot];
+                    if (kind == BvhBuilder::SpatialSplit) {
+                        std::vector<Work> stack;
+                        stack.push_back({ 0u, d.depth, std::move(d.refs) });
+                        b.build(stack);
+                    } else { // (the subtrees' ranges of the two arrays are disjoint)
+                        b.all = all, b.spare = spare;
+                        std::vector<Range> stack { { 0u, d.depth, d.begin, d.end } };
+                        b.buildRanges(stack);
+                    }
                 }
             });
             // where everything goes: a subtree's nodes behind what the top phase had allocated when it set the subtree aside, plus the earlier subtrees

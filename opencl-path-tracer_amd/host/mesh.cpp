@@ -1,6 +1,8 @@
 #include "mesh.h"
 #include "parallel.h"
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -17,6 +19,7 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
 {
     if (materials.empty())
         throw std::invalid_argument("Mesh: at least one material is required");
+    const auto t0 = std::chrono::steady_clock::now();
     m_vertices.resize(numVertices);
     std::memset(m_vertices.data(), 0, numVertices * sizeof(VertexSceneData));
     for (size_t i = 0; i < numVertices; i++) {
@@ -44,13 +47,16 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
             throw std::invalid_argument("Mesh: material index out of range");
         m_inputTriangles[t].materialIndex = mi;
     }
+    const auto t1 = std::chrono::steady_clock::now();
     if (!normals)
         generateSmoothNormals();
+    const auto t2 = std::chrono::steady_clock::now();
     if (bvhCacheFile.empty() || !loadBvh(bvhCacheFile)) {
         m_bvh = buildBVH(m_vertices.data(), m_vertices.size(), m_inputTriangles.data(), m_inputTriangles.size(), builder);
         if (!bvhCacheFile.empty())
             storeBvh(bvhCacheFile);
     }
+    const auto t3 = std::chrono::steady_clock::now();
     // emissive triangles are listed once per INPUT triangle (spatial splits may duplicate references)
     std::vector<uint8_t> listed(numTriangles, 0);
     for (size_t i = 0; i < m_bvh.triangles.size(); i++) {
@@ -59,6 +65,11 @@ Mesh::Mesh(const float* positions, const float* normals, const float* texCoords,
             listed[orig] = 1;
             m_emissive.push_back((uint32_t)i);
         }
+    }
+    if (std::getenv("PTAMD_BUILD_TIMING")) {
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[ptamd_host] Mesh: arrays %.3f ms, smooth normals %.3f, tree %.3f, emissive list %.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
     }
 }
 

@@ -2,10 +2,16 @@
 // reference does this work single-threaded inside Assimp / refit_bvh.cpp, and at 4-6 ms per frame never needed more).  Threads are started at
 // the first use and parked on a condition variable in between; parallelFor splits [0, count) into one contiguous range per thread, the
 // caller takes the first one itself.  Ranges are fixed by (count, thread count) alone: results never depend on timing.
+// A worker that has just finished a range polls for the next loop for ~100 us before it parks, and the caller polls as long for its workers before
+// it blocks: a tree build is half a dozen short loops in a row (bins of the top levels, subtrees, smooth normals), and a futex sleep + wake per loop
+// and per thread cost more than the loops' own work.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdlib>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -42,7 +48,8 @@ public:
         const size_t chunk = (count + parts - 1) / parts;
         {
             std::lock_guard<std::mutex> lock(m_mutex);
-            m_fn = &fn, m_count = count, m_chunk = chunk, m_parts = parts, m_pending = parts - 1, m_generation++;
+            m_fn = &fn, m_count = count, m_chunk = chunk, m_parts = parts, m_pending.store(parts - 1, std::memory_order_relaxed);
+            m_generation.fetch_add(1, std::memory_order_release);
         }
         m_wake.notify_all();
         // An exception out of fn -- on this thread or on a worker (std::bad_alloc from a builder's vectors) -- is kept, every range is still waited
@@ -56,8 +63,9 @@ public:
             mine = std::current_exception();
         }
         insideTask() = false;
+        spinUntil([&] { return m_pending.load(std::memory_order_acquire) == 0; });
         std::unique_lock<std::mutex> lock(m_mutex);
-        m_done.wait(lock, [&] { return m_pending == 0; });
+        m_done.wait(lock, [&] { return m_pending.load(std::memory_order_relaxed) == 0; });
         m_fn = nullptr;
         std::exception_ptr first = mine ? mine : m_error;
         m_error = nullptr;
@@ -73,10 +81,26 @@ public:
     }
 
 private:
+    // polls `ready` for about 100 us (the pause instruction between polls; the clock read every 64th)
+    template <typename F>
+    static bool spinUntil(F ready)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned i = 1;; i++) {
+            if (ready())
+                return true;
+            __builtin_ia32_pause();
+            if ((i & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+                return false;
+        }
+    }
     WorkerPool()
     {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n = std::min(4u, hw) - 1u; // the caller is the first worker; more than four threads buy nothing on loops this small
+        unsigned want = 8u; // the caller is the first worker; a rebuilt tree per frame (16 subtrees of a 20 k-triangle mesh) is the loop that uses them all
+        if (const char* env = std::getenv("PTAMD_HOST_THREADS"))
+            want = (unsigned)std::clamp(std::atoi(env), 1, 64);
+        const unsigned n = std::min(want, hw) - 1u;
         for (unsigned i = 0; i < n; i++)
             m_threads.emplace_back([this, i] { run(i + 1); });
     }
@@ -108,12 +132,14 @@ private:
         for (;;) {
             const std::function<void(size_t, size_t)>* fn;
             size_t begin, end;
+            if (seen != 0)
+                spinUntil([&] { return m_generation.load(std::memory_order_acquire) != seen; }); // (m_quit is only ever set while the workers are parked or will park)
             {
                 std::unique_lock<std::mutex> lock(m_mutex);
-                m_wake.wait(lock, [&] { return m_quit || m_generation != seen; });
+                m_wake.wait(lock, [&] { return m_quit || m_generation.load(std::memory_order_relaxed) != seen; });
                 if (m_quit)
                     return;
-                seen = m_generation;
+                seen = m_generation.load(std::memory_order_relaxed);
                 if (part >= m_parts)
                     continue; // fewer parts than threads this time
                 fn = m_fn, begin = std::min(part * m_chunk, m_count), end = std::min(begin + m_chunk, m_count);
@@ -132,7 +158,7 @@ private:
                 std::lock_guard<std::mutex> lock(m_mutex);
                 if (err && !m_error)
                     m_error = err;
-                if (--m_pending == 0)
+                if (m_pending.fetch_sub(1, std::memory_order_acq_rel) == 1)
                     m_done.notify_one();
             }
         }
@@ -142,7 +168,8 @@ private:
     std::mutex m_mutex, m_callers;
     std::condition_variable m_wake, m_done;
     const std::function<void(size_t, size_t)>* m_fn = nullptr;
-    size_t m_count = 0, m_chunk = 0, m_parts = 0, m_pending = 0, m_generation = 0;
+    size_t m_count = 0, m_chunk = 0, m_parts = 0;
+    std::atomic<size_t> m_pending { 0 }, m_generation { 0 };
     bool m_quit = false;
     std::exception_ptr m_error; // the first exception a worker's range threw in the current loop
 };

@@ -62,7 +62,8 @@ def build_sanitized(force=False):
 # rate and compete with the conversions, compares and selects of the traversal kernels; plain FP32 arithmetic next to one of those is nearly free
 # (profiles/round5/r5r_valu_issue_pairs.md).  Benchmark scene: 11 040 -> 11 660 Mrays/s, k_shade 85 -> 75 VGPRs.
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-                "-Xarch_device", "-fno-slp-vectorize"]
+                "-Xarch_device", "-fno-slp-vectorize",
+                "-Xarch_host", "-msse4.1"]  # (host side: floorf / ceilf of the node quantiser inline -- it is most of a conversion's packing pass)
 
 
 def csrc_fingerprint(csrc_dir=None):

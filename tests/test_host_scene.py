@@ -73,6 +73,19 @@ def test_the_worker_pool_builds_the_sequential_builders_arrays(builder, monkeypa
         assert a.shape == b.shape and a.tobytes() == b.tobytes()
 
 
+def test_the_builders_that_work_in_place_make_the_trees_of_the_list_based_ones():
+    """tests/golden/builder_trees.json: digests of (nodes, triangles, original triangle) written by the builders of commit b2849b6 -- one list of references
+    per node, every one of the 31 planes swept.  The object-split builders now partition ONE array in place (keeping the order on both sides) and sweep the
+    occupied bins only; the spatial-split builder shares the sweep.  Same bytes, whatever the thread count (the reference's in-place builder:
+    src/bvh/bvh_build.cpp:195-215, bins: src/bvh/bvh_object_split.cpp:26-70)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_builder_trees
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "builder_trees.json")) as fh:
+        want = json.load(fh)
+    assert make_builder_trees.trees() == want
+
+
 def test_a_forked_child_builds_without_the_parents_worker_threads():
     """fork() copies the calling thread only: a child of a process whose worker pool has started must not wait for workers that are not there --
     neither in its loops nor at exit (glibc's pthread_cond_destroy waits for the waiters a copied condition variable still counts)."""

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(ROOT, "opencl-path-tracer_amd"))
 from ptamd import device as D, host as H, layout as L, scenes  # noqa: E402
 
 
+OLD_ORDER = "--old-order" in sys.argv
+
+
 def main():
     W, Hh = 1280, 720
     v, f = scenes.icosphere(5)
@@ -36,14 +39,18 @@ def main():
     ctx.set_camera(cam)
     ctx.render(1)
     rows = []
-    for k in range(1, 9):
+    for k in range(1, 14):
         ctx.render(1, sync=False)
         flat, t0, t1, t2 = new_scene(k)
+        if not OLD_ORDER:
+            ctx.render(1, sync=False)
+        t2b = time.perf_counter()
         ctx.upload_static_async(flat)
         t3 = time.perf_counter()
         ctx.upload_dynamic_async(flat)
         t4 = time.perf_counter()
-        ctx.render(1, sync=False)
+        if OLD_ORDER:  # rounds 5-6a: the second frame of the old scene enqueued after the conversion
+            ctx.render(1, sync=False)
         t5 = time.perf_counter()
         ctx.frame_tick()
         t6 = time.perf_counter()
@@ -51,7 +58,7 @@ def main():
         t7 = time.perf_counter()
         ctx.synchronize()
         t8 = time.perf_counter()
-        rows.append([(b - a) * 1e3 for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5), (t5, t6), (t6, t7), (t7, t8), (t0, t8))])
+        rows.append([(b - a) * 1e3 for a, b in ((t0, t1), (t1, t2), (t2b, t3), (t3, t4), (t2, t2b) if not OLD_ORDER else (t4, t5), (t5, t6), (t6, t7), (t7, t8), (t0, t8))])
     names = ["build", "flatten", "static_async", "dynamic_async", "render_enqueue", "tick", "render_enqueue2", "synchronize", "total"]
     med = np.median(np.array(rows[2:]), axis=0)
     print(" ".join(f"{n}={m:.3f}" for n, m in zip(names, med)))
