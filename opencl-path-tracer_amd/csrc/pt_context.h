@@ -68,6 +68,11 @@ struct StaticScene {
         uint32_t emptyRef = 0;
         uint64_t version = 0;
         bool onDevice = false;
+        // pt_upload_static_async (a rebuilt tree per frame): the host makes the topology only -- child references, the slots' box sources, the triangle
+        // references -- and the device makes the records from the caller's own arrays, as after a refit (k_refit_nodes: exact boxes and quantised planes;
+        // k_refit_tris: intersection and shading records).  The host's `wide` planes, `boxes` and `fat` are then not filled in (nothing reads them: a
+        // conversion that runs again makes everything anew, refitWideOnHost / buildFat re-make them from the pair boxes where a host-side refit needs them).
+        bool deviceMakesRecords = false;
         DevBuf<WideNode> dWide;
         DevBuf<WideBoxes> dBoxes;
         DevBuf<uint32_t> dLeafOfs, dRefTri;

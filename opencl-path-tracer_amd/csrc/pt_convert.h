@@ -50,6 +50,8 @@ CollapseCosts collapseCostsFromEnv()
 std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const CollapseCosts costs = CollapseCosts { 0u })
 {
     std::vector<WideKids> out(pair.size());
+    const char* seqEnv = getenv("PTAMD_BUILD_THREADS"); // (1: everything on the calling thread, as the host library's builders read it -- tests compare the two)
+    const bool pooled = pair.size() >= 4096 && !(seqEnv && atoi(seqEnv) == 1);
     struct Child {
         float lo[3], hi[3];
         uint32_t ref;
@@ -117,10 +119,10 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         return dx * dy + dy * dz + dz * dx;
     };
     {
-        std::vector<uint32_t> stack;
-        for (size_t root = 0; root < N; root++) {
+        // post-order over the subtree below `root` (a stack of its own per caller: subtrees are disjoint, so several can be solved side by side)
+        auto solve = [&](size_t root, std::vector<uint32_t>& stack) {
             if (dp[root].done)
-                continue;
+                return;
             stack.push_back((uint32_t)root);
             while (!stack.empty()) {
                 const uint32_t n = stack.back();
@@ -193,13 +195,50 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
                 d.done = 2;
                 stack.pop_back();
             }
+        };
+        // A rebuilt tree per frame: the subtrees five levels below the roots of large trees are solved on the host library's worker pool, the tops on the
+        // calling thread afterwards.  The recurrence has one solution per node whatever the order: the same tree, byte for byte.  (Built once before, on the
+        // pool of four threads that parked between loops, and reverted: the NEXT Mesh build on that pool paid 0.9 ms for the 0.2 this saved -- EXPERIMENTS.md.
+        // The pool of eight that polls before it parks does not show that.)
+        std::vector<uint32_t> tasks;
+        if (pooled) {
+            std::vector<uint8_t> isChild(N, 0);
+            for (size_t n = 0; n < N; n++)
+                for (uint32_t r : { pair[n].left, pair[n].right })
+                    if (isInner(r))
+                        isChild[refIndex(r)] = 1;
+            std::vector<uint32_t> level, next;
+            for (size_t n = 0; n < N; n++)
+                if (!isChild[n])
+                    level.push_back((uint32_t)n);
+            for (int depth = 0; depth < 5 && !level.empty() && level.size() < 64; depth++) {
+                next.clear();
+                for (uint32_t n : level)
+                    for (uint32_t r : { pair[n].left, pair[n].right })
+                        if (isInner(r) && refIndex(r) != n)
+                            next.push_back(refIndex(r));
+                level.swap(next);
+            }
+            std::sort(level.begin(), level.end());
+            level.erase(std::unique(level.begin(), level.end()), level.end()); // (a shared subtree -- refused by the upload's validation anyway -- is solved once)
+            tasks = level;
         }
-        // (Round 6 solved the subtrees five levels below the roots on the host library's worker pool, and the per-node child lists below in parallel: the pass
-        // went from 0.67 to ~0.45 ms on a 20 k-triangle mesh -- and the NEXT Mesh build on the same pool from 2.55 to 3.43 ms: 7.34 against 6.97 ms per rebuilt-tree
-        // tick, twice, inside bench.py and outside.  Sequential again; EXPERIMENTS.md.)
+        if (tasks.size() >= 2) {
+            std::atomic<size_t> nextTask { 0 };
+            raytracer::WorkerPool& pool = raytracer::WorkerPool::get();
+            pool.parallelFor(pool.threads(), 1, [&](size_t, size_t) {
+                std::vector<uint32_t> stack;
+                for (size_t t; (t = nextTask.fetch_add(1)) < tasks.size();)
+                    solve(tasks[t], stack);
+            });
+        }
+        std::vector<uint32_t> stack;
+        for (size_t root = 0; root < N; root++)
+            solve(root, stack);
     }
 #endif
-    for (size_t i = 0; i < pair.size(); i++) {
+    raytracer::WorkerPool::get().parallelFor(pair.size(), pooled ? 2048 : pair.size() + 1, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
         Child kids[4];
         int n = 0;
 #if PT_COLLAPSE_OPTIMAL
@@ -263,6 +302,7 @@ std::vector<WideKids> collapseKids(const std::vector<PairNode>& pair, const Coll
         }
         out[i] = wk;
     }
+    });
     return out;
 }
 
@@ -509,10 +549,11 @@ struct StageTimer {
     }
 };
 
-int buildStaticGeom(pt_ctx* c)
+int buildStaticGeom(pt_ctx* c, bool deviceMakesRecords = false)
 {
     StaticScene::StaticGeom& g = c->st->sg;
     StageTimer tm("buildStaticGeom");
+    g.deviceMakesRecords = deviceMakesRecords;
     refreshHostGeometry(c);
     tm.lap("refreshHostGeometry");
     const uint32_t nN = c->st->numRefNodes, nT = c->st->numTris;
@@ -530,7 +571,7 @@ int buildStaticGeom(pt_ctx* c)
     for (uint32_t i = 0; i < nN; i++)
         if (c->st->nodeRef[i] != kRefNone && (!isChild[i] || std::find(g.extraRoots.begin(), g.extraRoots.end(), i) != g.extraRoots.end()))
             rootNodes.push_back(i);
-    g.wide.clear(), g.boxes.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear(), g.kidBoxNode.clear();
+    g.wide.clear(), g.leafOfs.clear(), g.refTri.clear(), g.roots.clear(), g.kidSrc.clear(), g.kidEmpty.clear(), g.kidBoxNode.clear();
     std::vector<uint32_t> pairLeft(c->st->numDensePairs, 0u); // pair node -> the caller's node that is its left child
     for (uint32_t i = 0; i < nN; i++)
         if (c->st->denseOfNode[i] != 0xFFFFFFFFu)
@@ -576,7 +617,7 @@ int buildStaticGeom(pt_ctx* c)
         }
         // nodes of this run: remapped references, exact boxes, triangle-reference offsets of the leaves
         g.wide.resize(order.size());
-        g.boxes.resize(order.size());
+        g.boxes.resize(order.size()); // (every slot is written below -- or, where the device makes the records, never read)
         g.leafOfs.resize(order.size() * 4, 0u);
         g.kidSrc.resize(order.size() * 4, 0u);
         g.kidEmpty.resize(order.size() * 4, 1u);
@@ -602,10 +643,18 @@ int buildStaticGeom(pt_ctx* c)
                         g.kidBoxNode[q * 4 + k] = pr < c->st->numDensePairs ? pairLeft[pr] + side : (0x80000000u | ((pr - c->st->numDensePairs) * 2u + side));
                     }
                     refs[k] = wk.empty[k] ? emptyRef : (isInner(wk.ref[k]) ? makeRef(newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
-                    for (int a = 0; a < 3; a++)
-                        g.boxes[q].lo[k][a] = wk.lo[k][a], g.boxes[q].hi[k][a] = wk.hi[k][a];
+                    if (!deviceMakesRecords)
+                        for (int a = 0; a < 3; a++)
+                            g.boxes[q].lo[k][a] = wk.lo[k][a], g.boxes[q].hi[k][a] = wk.hi[k][a];
                 }
-                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, emptyRef, &g.wide[q]);
+                if (deviceMakesRecords) { // the references only: k_refit_nodes gathers the boxes and makes the planes (uploadStaticGeom)
+                    WideNode w {};
+                    for (int k = 0; k < 4; k++)
+                        w.child[k] = refs[k];
+                    g.wide[q] = w;
+                } else {
+                    quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, emptyRef, &g.wide[q]);
+                }
             }
         });
         root.numRefs = (uint32_t)g.refTri.size() - root.refBase;
@@ -651,9 +700,12 @@ int buildStaticGeom(pt_ctx* c)
         fprintf(stderr, "\n");
     }
     tm.lap("stackNeed");
-    buildFat(c);
+    if (deviceMakesRecords)
+        g.fat.resize(c->st->hostTriShade.size()); // (its size is what the dynamic sets allocate by)
+    else
+        buildFat(c);
     tm.lap("buildFat");
-    if (getenv("PTAMD_TREE_HASH")) { // what a conversion made, in one line (tools/tree_hash.py: a change to the conversion's code that is meant to keep its result)
+    if (getenv("PTAMD_TREE_HASH") && !deviceMakesRecords) { // what a conversion made, in one line (tools/tree_hash.py: a change to the conversion's code that is meant to keep its result)
         auto fnv = [](const void* p, size_t n) {
             uint64_t h = 1469598103934665603ull;
             for (size_t i = 0; i < n; i++)
@@ -687,9 +739,46 @@ int uploadStaticGeom(pt_ctx* c)
         refreshHostGeometry(c);
         buildFat(c);
     }
+    int rc;
+    if (g.deviceMakesRecords) {
+        // the topology and the caller's arrays as they are; the records on the device (what pt_update_geometry does after a refit: the same kernels from the same
+        // boxes with the same routines -- a context that adopts this scene holds the bytes a fresh one makes on the host, tests/test_gpu_dynamic.py)
+        std::vector<float> extra; // boxes of the pair nodes that cut a leaf of more than two triangles (k_refit_nodes: entry (pair - numDensePairs) * 2 + side)
+        for (size_t j = c->st->numDensePairs; j < c->st->hostBottomNodes.size(); j++) {
+            const PairNode& n = c->st->hostBottomNodes[j];
+            const float b[12] = { n.bx.x, n.by.x, n.bz.x, n.bx.y, n.by.y, n.bz.y, n.bx.z, n.by.z, n.bz.z, n.bx.w, n.by.w, n.bz.w };
+            extra.insert(extra.end(), b, b + 12);
+        }
+        const size_t nT = c->st->numTris;
+        if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs)) || (rc = uploadVec(c, g.dRefTri, g.refTri))
+            || (rc = uploadVec(c, g.dVerts, c->st->rawVerts)) || (rc = uploadVec(c, c->st->triShade, c->st->hostTriShade))
+            || (rc = uploadVec(c, g.dNodes, c->st->hostSubNodes)) || (rc = uploadVec(c, g.dKidBoxNode, g.kidBoxNode)) || (rc = uploadVec(c, g.dExtra, extra)))
+            return rc;
+        if (g.dBoxes.n < std::max<size_t>(g.wide.size(), 1))
+            HIPCHK(c, g.dBoxes.alloc(g.wide.size() + g.wide.size() / 8 + 1));
+        if (g.dTris.n < nT + 1)
+            HIPCHK(c, g.dTris.alloc(nT + nT / 8 + 1));
+        if (g.dFat.n < std::max<size_t>(nT, 1))
+            HIPCHK(c, g.dFat.alloc(nT + nT / 8 + 1));
+        tm.lap("uploads");
+        static_assert(sizeof(VertexIn) == sizeof(pt_vertex) && sizeof(SubNodeIn) == sizeof(pt_sub_bvh_node), "the refit kernels read the caller's records as they are");
+        HIPCHK(c, hipMemsetAsync(g.dTris.p + nT, 0, sizeof(TriIsect), c->copyStream)); // what an unused child slot refers to
+        if (!g.wide.empty()) {
+            RefitNodeArgs rn {};
+            rn.nodes = (const SubNodeIn*)g.dNodes.p, rn.kidBoxNode = g.dKidBoxNode.p, rn.extra = g.dExtra.p, rn.wide = g.dWide.p, rn.boxes = g.dBoxes.p;
+            rn.emptyRef = g.emptyRef, rn.n = (uint32_t)g.wide.size();
+            hipLaunchKernelGGL(k_refit_nodes, dim3((rn.n + 127u) / 128u), dim3(128), 0, c->copyStream, rn);
+        }
+        RefitArgs ra {};
+        ra.verts = (const VertexIn*)g.dVerts.p, ra.tri = c->st->triShade.p, ra.mats = c->st->materials.p, ra.tris = g.dTris.p, ra.fat = g.dFat.p, ra.n = (uint32_t)nT;
+        hipLaunchKernelGGL(k_refit_tris, dim3(((uint32_t)nT + 255u) / 256u), dim3(256), 0, c->copyStream, ra);
+        HIPCHK(c, hipGetLastError());
+        tm.lap("kernels");
+        g.onDevice = true;
+        return PT_OK;
+    }
     std::vector<TriIsect> tris = c->st->hostTris;
     tris.push_back(TriIsect { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) }); // what an unused child slot refers to
-    int rc;
     if ((rc = uploadVec(c, g.dWide, g.wide)) || (rc = uploadVec(c, g.dBoxes, g.boxes)) || (rc = uploadVec(c, g.dLeafOfs, g.leafOfs))
         || (rc = uploadVec(c, g.dRefTri, g.refTri)) || (rc = uploadVec(c, g.dTris, tris)) || (rc = uploadVec(c, g.dFat, g.fat))
         || (rc = uploadVec(c, g.dVerts, c->st->rawVerts)) || (rc = uploadVec(c, c->st->triShade, c->st->hostTriShade))
@@ -875,17 +964,18 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
 
     tm.lap("pairNodes");
     int rc;
-    c->st->hostTris = hTris;
+    c->st->hostTris = std::move(hTris);
     c->st->hostBottomNodes = std::move(hNodes);
     c->st->rawVerts.assign(verts, verts + nV);
     c->st->hostGeomStale = false;
     c->st->sg.latestInStage = false;
-    c->st->denseOfNode = dense;
+    c->st->denseOfNode = std::move(dense);
     c->st->numDensePairs = numInner;
-    if (!async)
+    if (!async) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); // renders in flight read these buffers
-    if ((rc = uploadVec(c, c->st->materials, hMats)))
-        return rc;
+        if ((rc = uploadVec(c, c->st->materials, hMats)))
+            return rc;
+    }
     c->st->hostTriShade = std::move(hShade);
     c->st->hostMaterials.assign(mats, mats + nM);
     c->st->hostSubNodes.assign(nodes, nodes + nN);
@@ -913,9 +1003,14 @@ static int uploadStaticImpl(pt_ctx* c, const pt_vertex* verts, uint32_t nV, cons
     }
     c->st->sg.extraRoots.clear();
     tm.lap("mirrors");
-    if ((rc = buildStaticGeom(c)))
+    if ((rc = buildStaticGeom(c, async && !getenv("PTAMD_HOST_RECORDS")))) // (PTAMD_HOST_RECORDS=1: the records of a rebuilt scene on the host too -- A / B)
         return rc;
     tm.lap("buildStaticGeom");
+    // (pt_upload_static_async: the materials go last.  A blocking copy issued while a frame of the current scene holds every compute unit with its persistent
+    // waves waited for most of that frame -- 0.43 ms of a 1080p frame, tools/rebuild_timing.py --1080p -- and the conversion above is host work the frame can hide)
+    if (async && (rc = uploadVec(c, c->st->materials, hMats)))
+        return rc;
+    tm.lap("materials");
     if (!async)
         refreshSceneView(c);
     return PT_OK;

@@ -35,6 +35,9 @@ namespace {
         float cost = 0.0f; // SA_L*N_L + SA_R*N_R
         AABB leftBox, rightBox;
         size_t leftCount = 0, rightCount = 0;
+        // a node whose bins the workers filled side by side: how many references of each worker's range go left (the partition scatters the ranges side by side too)
+        std::vector<size_t> leftOfPart;
+        size_t partChunk = 0;
     };
 
     inline vec3 position(const pt_vertex& v) { return { v.vertex[0], v.vertex[1], v.vertex[2] }; }
@@ -83,6 +86,8 @@ namespace {
             const float invWidth = (float)kObjectBins / ext[axis];
             std::array<AABB, kObjectBins> box;
             std::array<size_t, kObjectBins> count {};
+            std::vector<std::array<size_t, kObjectBins>> pcount; // (per worker: the top of a large tree)
+            size_t partChunk = 0;
             auto binRange = [&](size_t begin, size_t end, std::array<AABB, kObjectBins>& bx, std::array<size_t, kObjectBins>& cn) {
                 for (size_t i = begin; i < end; i++) {
                     const PrimRef& r = refs[i];
@@ -96,7 +101,8 @@ namespace {
                 WorkerPool& pool = WorkerPool::get();
                 const size_t parts = pool.threads(), chunk = (numRefs + parts - 1) / parts;
                 std::vector<std::array<AABB, kObjectBins>> pbox(parts);
-                std::vector<std::array<size_t, kObjectBins>> pcount(parts);
+                pcount.resize(parts);
+                partChunk = chunk;
                 for (auto& c : pcount)
                     c.fill(0);
                 pool.parallelFor(parts, 1, [&](size_t p0, size_t p1) {
@@ -145,6 +151,11 @@ namespace {
                     best.rightBox = rightBox[b];
                     best.leftCount = nl;
                     best.rightCount = rightCount[b];
+                    best.partChunk = partChunk;
+                    best.leftOfPart.assign(pcount.size(), 0);
+                    for (size_t p = 0; p < pcount.size(); p++)
+                        for (int lb = 0; lb <= b; lb++)
+                            best.leftOfPart[p] += pcount[p][lb];
                 }
             }
         }
@@ -532,14 +543,38 @@ namespace {
                     if (obj.valid && area > 0.0f && kTraversalCost + obj.cost * kIntersectCost / area < (float)n * kIntersectCost) {
                         const float invWidth = (float)kObjectBins / nodeBox.extent()[obj.axis], lo = nodeBox.min[obj.axis];
                         PrimRef* right = spare + w.begin;
-                        size_t numRight = 0;
-                        for (size_t i = 0; i < n; i++) {
-                            if (binOf(centerOn(refs[i].box, obj.axis), lo, invWidth, kObjectBins) < obj.plane)
-                                refs[numLeft++] = refs[i];
-                            else
-                                right[numRight++] = refs[i];
+                        if (!obj.leftOfPart.empty()) {
+                            // the workers' ranges again: each scatters its references to where the ranges before it leave off (left and right side: the
+                            // order inside both sides is the sequential partition's), then copies its share back
+                            const size_t parts = obj.leftOfPart.size(), chunk = obj.partChunk;
+                            std::vector<size_t> leftAt(parts + 1, 0), rightAt(parts + 1, 0);
+                            for (size_t p = 0; p < parts; p++) {
+                                const size_t len = std::min((p + 1) * chunk, n) - std::min(p * chunk, n);
+                                leftAt[p + 1] = leftAt[p] + obj.leftOfPart[p], rightAt[p + 1] = rightAt[p] + (len - obj.leftOfPart[p]);
+                            }
+                            numLeft = leftAt[parts];
+                            WorkerPool& pool = WorkerPool::get();
+                            pool.parallelFor(parts, 1, [&](size_t p0, size_t p1) {
+                                for (size_t p = p0; p < p1; p++) {
+                                    size_t l = leftAt[p], r = numLeft + rightAt[p];
+                                    for (size_t i = std::min(p * chunk, n), e = std::min((p + 1) * chunk, n); i < e; i++)
+                                        right[binOf(centerOn(refs[i].box, obj.axis), lo, invWidth, kObjectBins) < obj.plane ? l++ : r++] = refs[i];
+                                }
+                            });
+                            pool.parallelFor(parts, 1, [&](size_t p0, size_t p1) {
+                                const size_t b = std::min(p0 * chunk, n), e = std::min(p1 * chunk, n);
+                                std::copy(right + b, right + e, refs + b);
+                            });
+                        } else {
+                            size_t numRight = 0;
+                            for (size_t i = 0; i < n; i++) {
+                                if (binOf(centerOn(refs[i].box, obj.axis), lo, invWidth, kObjectBins) < obj.plane)
+                                    refs[numLeft++] = refs[i];
+                                else
+                                    right[numRight++] = refs[i];
+                            }
+                            std::copy(right, right + numRight, refs + numLeft);
                         }
-                        std::copy(right, right + numRight, refs + numLeft);
                         leftBox = obj.leftBox;
                         rightBox = obj.rightBox;
                     }
@@ -648,21 +683,24 @@ namespace {
                     nd.leftChildOrFirstTriangle = topIndex(nd.leftChildOrFirstTriangle);
                 allNodes[topIndex(i)] = nd;
             }
-            for (size_t k = 0; k < numSub; k++) {
-                const Builder& b = local[k];
-                const size_t nodeBase = subtrees[k].nodesBefore + nodesOfEarlier[k], leafBase = subtrees[k].leavesBefore + leavesOfEarlier[k];
-                auto moved = [&](SubBVHNode nd) {
-                    if (nd.triangleCount == 0)
-                        nd.leftChildOrFirstTriangle = (uint32_t)(nodeBase + nd.leftChildOrFirstTriangle - 2);
-                    else
-                        nd.leftChildOrFirstTriangle = (uint32_t)(leafBase + nd.leftChildOrFirstTriangle);
-                    return nd;
-                };
-                allNodes[topIndex(subtrees[k].slot)] = moved(b.nodes[0]);
-                for (size_t i = 2; i < b.nodes.size(); i++)
-                    allNodes[nodeBase + i - 2] = moved(b.nodes[i]);
-                std::copy(b.leafRefs.begin(), b.leafRefs.end(), allLeaves.begin() + leafBase);
-            }
+            next = 0;
+            pool.parallelFor(pool.threads(), 1, [&](size_t, size_t) { // (disjoint ranges of the two arrays)
+                for (size_t k; (k = next.fetch_add(1)) < numSub;) {
+                    const Builder& b = local[k];
+                    const size_t nodeBase = subtrees[k].nodesBefore + nodesOfEarlier[k], leafBase = subtrees[k].leavesBefore + leavesOfEarlier[k];
+                    auto moved = [&](SubBVHNode nd) {
+                        if (nd.triangleCount == 0)
+                            nd.leftChildOrFirstTriangle = (uint32_t)(nodeBase + nd.leftChildOrFirstTriangle - 2);
+                        else
+                            nd.leftChildOrFirstTriangle = (uint32_t)(leafBase + nd.leftChildOrFirstTriangle);
+                        return nd;
+                    };
+                    allNodes[topIndex(subtrees[k].slot)] = moved(b.nodes[0]);
+                    for (size_t i = 2; i < b.nodes.size(); i++)
+                        allNodes[nodeBase + i - 2] = moved(b.nodes[i]);
+                    std::copy(b.leafRefs.begin(), b.leafRefs.end(), allLeaves.begin() + leafBase);
+                }
+            });
             nodes = std::move(allNodes);
             leafRefs = std::move(allLeaves);
         }
@@ -675,14 +713,17 @@ BvhBuildResult buildBVH(const VertexSceneData* vertices, size_t numVertices, con
     if (numTriangles == 0)
         throw std::invalid_argument("buildBVH: empty mesh");
     std::vector<PrimRef> refs(numTriangles);
-    for (size_t i = 0; i < numTriangles; i++) {
-        for (int k = 0; k < 3; k++) {
-            if (triangles[i].indices[k] >= numVertices)
-                throw std::invalid_argument("buildBVH: vertex index out of range");
-            refs[i].box.fit(position(vertices[triangles[i].indices[k]]));
+    const size_t perThread = sequentialBuild() ? numTriangles : 4096; // (small meshes and PTAMD_BUILD_THREADS=1: on the caller)
+    WorkerPool::get().parallelFor(numTriangles, perThread, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            for (int k = 0; k < 3; k++) {
+                if (triangles[i].indices[k] >= numVertices)
+                    throw std::invalid_argument("buildBVH: vertex index out of range");
+                refs[i].box.fit(position(vertices[triangles[i].indices[k]]));
+            }
+            refs[i].prim = (uint32_t)i;
         }
-        refs[i].prim = (uint32_t)i;
-    }
+    });
     Builder b { vertices, triangles, kind };
     b.nodes.reserve(numTriangles);
     b.leafRefs.reserve(numTriangles + numTriangles / 4);
@@ -693,10 +734,12 @@ BvhBuildResult buildBVH(const VertexSceneData* vertices, size_t numVertices, con
     out.nodes = std::move(b.nodes);
     out.triangles.resize(b.leafRefs.size());
     out.originalTriangle.resize(b.leafRefs.size());
-    for (size_t i = 0; i < b.leafRefs.size(); i++) {
-        out.triangles[i] = triangles[b.leafRefs[i].prim];
-        out.originalTriangle[i] = b.leafRefs[i].prim;
-    }
+    WorkerPool::get().parallelFor(b.leafRefs.size(), perThread, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            out.triangles[i] = triangles[b.leafRefs[i].prim];
+            out.originalTriangle[i] = b.leafRefs[i].prim;
+        }
+    });
     return out;
 }
 

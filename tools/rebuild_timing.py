@@ -11,7 +11,7 @@ OLD_ORDER = "--old-order" in sys.argv
 
 
 def main():
-    W, Hh = 1280, 720
+    W, Hh = (1920, 1080) if "--1080p" in sys.argv else (1280, 720)
     v, f = scenes.icosphere(5)
     p0 = (v * 0.5).astype(np.float32)
     f = f.astype(np.uint32)
