@@ -226,7 +226,9 @@ int pt_upload_dynamic(pt_ctx* ctx, const pt_emissive_triangle* lights, uint32_t 
  * instead of a refit), whose arrays transferDynamicData re-uploads every tick (src/raytracer.cpp:510-568).  Same arguments as pt_upload_static;
  * the scene is converted into the context's SECOND static set and copied to the device WITHOUT synchronising the render stream: frames enqueued
  * so far, and any enqueued before the flip, keep rendering the old trees.  Follow with pt_upload_dynamic_async -- lights and top level of the
- * NEW scene (its leaves name the new sub-BVH roots) -- and pt_frame_tick, which adopts both.  (Before anything renders it is pt_upload_static.) */
+ * NEW scene (its leaves name the new sub-BVH roots) -- and pt_frame_tick, which adopts both.  (Before anything renders it is pt_upload_static.)
+ * The host converts the topology; the node boxes, quantised planes and triangle records are made on the device, on the copy stream, from the arrays as
+ * handed in (their bytes are those pt_upload_static makes on the host). */
 int pt_upload_static_async(pt_ctx* ctx, const pt_vertex* verts, uint32_t n_verts, const pt_triangle* tris, uint32_t n_tris,
     const pt_material* mats, uint32_t n_mats, const pt_sub_bvh_node* nodes, uint32_t n_nodes);
 /* transferDynamicData + frameTick as the reference runs them (src/raytracer.cpp:183-189,497-595): the dynamic part of the scene
