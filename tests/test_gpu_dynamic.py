@@ -508,3 +508,46 @@ def test_a_rebuilt_tree_per_frame_is_adopted_at_the_tick_while_the_old_one_rende
     ctx.render(8)
     assert np.array_equal(ctx.read_accum(), fresh(flat_b)[1])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("records", ["device", "host"])
+def test_a_rebuilt_scene_of_every_kind_of_tree_equals_a_fresh_context(gpu, records, monkeypatch):
+    """The records of a rebuilt scene (pt_upload_static_async) are made ON THE DEVICE from the caller's arrays -- k_refit_nodes: exact boxes and quantised planes,
+    k_refit_tris: intersection and shading records -- where pt_upload_static makes them on the host (PTAMD_HOST_RECORDS=1: there too).  Both must be the bytes a
+    fresh context holds: images and hits bit-identical, on the kinds of trees the conversion treats differently -- SBVH meshes with duplicated references and
+    three-triangle leaves (cut into 1 + 2 by appended pair nodes, whose boxes travel as `extra`), single-leaf meshes (the quads), instances copied to world
+    space and entered, textured materials of five types.  Afterwards the adopted scene takes a host-refitted update (pt_update_geometry) like any other."""
+    if records == "host":
+        monkeypatch.setenv("PTAMD_HOST_RECORDS", "1")
+    start = scenes.cornell_box(W, Hh)
+    o, d = U.random_rays(20000, 11, (-3.0, 0.05, -3.0), (3.0, 2.0, 3.0))
+    ctx = U.make_ctx(gpu, start, W, Hh, seed=5, samples_in_flight=1)
+    ctx.render(2)
+    sky = tex = None
+    for name, bundle, flags in (("grid of SBVH meshes, copied", scenes.instanced_grid(W, Hh, nx=3, nz=2, level=3), 0),
+                                ("five material types on one mesh", scenes.mixed_material_room(W, Hh, level=3), 0),
+                                ("crowd, turned instances", scenes.instanced_crowd(W, Hh, nx=3, nz=2, level=2), 0)):
+        ctx.upload_static_async(bundle.flat)
+        ctx.upload_dynamic_async(bundle.flat)
+        ctx.frame_tick()
+        ctx.set_camera(bundle.camera)
+        if bundle.sky is not None:  # (textures belong to the context, not to a scene: the fresh context gets whatever this one holds by now)
+            sky = bundle.sky
+            ctx.upload_texture(1, sky)
+        if bundle.material_textures is not None:
+            tex = bundle.material_textures
+            ctx.upload_texture(0, tex)
+        ctx.clear()
+        ctx.render(4)
+        got_a, got_h = ctx.read_accum().copy(), ctx.intersect(o, d)
+        c2 = gpu.Context(W, Hh, seed=5, samples_in_flight=1, flags=flags)
+        c2.upload_scene(bundle.flat, sky=sky, material_textures=tex)
+        c2.set_camera(bundle.camera)
+        c2.render(4)
+        want_a, want_h = c2.read_accum().copy(), c2.intersect(o, d)
+        c2.close()
+        for key in ("t", "u", "v", "prim", "inst"):
+            assert np.array_equal(got_h[key], want_h[key]), (name, key)
+        assert np.array_equal(got_a, want_a), name
+    ctx.close()
