@@ -81,7 +81,18 @@ public:
     }
 
 private:
-    // polls `ready` for about 100 us (the pause instruction between polls; the clock read every 64th)
+    // PTAMD_HOST_SPIN_US: how long a worker polls for the next loop before it parks (default 100; 0: park at once).  A frame loop whose ticks are a few
+    // milliseconds apart finds its workers asleep at every tick: measured in EXPERIMENTS.md (round 6), not made the default -- seven cores polling for a whole
+    // tick is the application's call, not a library's.
+    static long spinMicroseconds()
+    {
+        static const long us = [] {
+            const char* env = std::getenv("PTAMD_HOST_SPIN_US");
+            return env ? std::clamp(std::atol(env), 0L, 1000000L) : 100L;
+        }();
+        return us;
+    }
+    // polls `ready` for about that long (the pause instruction between polls; the clock read every 64th)
     template <typename F>
     static bool spinUntil(F ready)
     {
@@ -90,7 +101,7 @@ private:
             if (ready())
                 return true;
             __builtin_ia32_pause();
-            if ((i & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+            if ((i & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spinMicroseconds()))
                 return false;
         }
     }
