@@ -211,31 +211,52 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
 
 void flattenStatic(Scene& scene, FlattenedScene& out)
 {
-    out.vertices.clear();
-    out.triangles.clear();
-    out.materials.clear();
-    out.subBvhNodes.clear();
+    size_t numV = 0, numM = 0, numT = 0, numN = 0;
+    for (const MeshBvhPair& pair : scene.getMeshes()) {
+        const IMesh& mesh = *pair.meshPtr;
+        numV += mesh.getVertices().size(), numM += mesh.getMaterials().size(), numT += mesh.getTriangles().size(), numN += mesh.getBvhNodes().size();
+    }
+    out.vertices.resize(numV);
+    out.materials.resize(numM);
+    out.triangles.resize(numT);
+    out.subBvhNodes.resize(numN);
+    uint32_t v0 = 0, m0 = 0, t0 = 0, n0 = 0;
     for (MeshBvhPair& pair : scene.getMeshes()) {
         const IMesh& mesh = *pair.meshPtr;
-        const uint32_t v0 = (uint32_t)out.vertices.size();
-        const uint32_t m0 = (uint32_t)out.materials.size();
-        const uint32_t t0 = (uint32_t)out.triangles.size();
-        const uint32_t n0 = (uint32_t)out.subBvhNodes.size();
-        out.vertices.insert(out.vertices.end(), mesh.getVertices().begin(), mesh.getVertices().end());
+        std::copy(mesh.getVertices().begin(), mesh.getVertices().end(), out.vertices.begin() + v0);
+        size_t i = m0;
         for (const Material& m : mesh.getMaterials())
-            out.materials.push_back(m);
+            out.materials[i++] = m;
+        i = t0;
         for (TriangleSceneData t : mesh.getTriangles()) {
             t.indices[0] += v0, t.indices[1] += v0, t.indices[2] += v0;
             t.materialIndex += m0;
-            out.triangles.push_back(t);
+            out.triangles[i++] = t;
         }
+        i = n0;
         for (SubBVHNode n : mesh.getBvhNodes()) {
             n.leftChildOrFirstTriangle += (n.triangleCount > 0) ? t0 : n0;
-            out.subBvhNodes.push_back(n);
+            out.subBvhNodes[i++] = n;
         }
         pair.bvhIndexOffset = n0;
         pair.vertexIndexOffset = v0;
+        v0 += (uint32_t)mesh.getVertices().size(), m0 += (uint32_t)mesh.getMaterials().size(), t0 += (uint32_t)mesh.getTriangles().size(), n0 += (uint32_t)mesh.getBvhNodes().size();
     }
+    // A mesh whose arrays change under the scene (isDynamic(): the reference's MeshSequence rebuilds or refits its tree in buildBvh, src/model/mesh_sequence.cpp:81-97)
+    // may have moved its root and its bounds since addNode looked at them: the nodes that carry it take the current ones, so that the top level built from
+    // them (flattenDynamic) encloses the frame that is about to be rendered.
+    struct Refresh {
+        static void walk(SceneNode& node, const std::vector<MeshBvhPair>& meshes)
+        {
+            if (node.meshID && meshes[*node.meshID].meshPtr->isDynamic()) {
+                node.bounds = meshes[*node.meshID].meshPtr->getBounds();
+                node.subBvhRootID = meshes[*node.meshID].meshPtr->getBvhRootNode();
+            }
+            for (auto& c : node.children)
+                walk(*c, meshes);
+        }
+    };
+    Refresh::walk(scene.getRootNode(), scene.getMeshes());
 }
 
 void flattenDynamic(const Scene& scene, FlattenedScene& out)

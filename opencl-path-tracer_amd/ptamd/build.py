@@ -109,6 +109,10 @@ def build_raytracer(force=False):
     if force or _newer(exe3, [os.path.join(ex_dir, "untracked_mesh.cpp"), out]):
         subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "untracked_mesh.cpp", "-o", "untracked_mesh", "-L" + HOST_DIR, "-lptamd_raytracer",
                         "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
+    exe4 = os.path.join(ex_dir, "rebuild_loop")
+    if force or _newer(exe4, [os.path.join(ex_dir, "rebuild_loop.cpp"), out]):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "rebuild_loop.cpp", "-o", "rebuild_loop", "-L" + HOST_DIR, "-lptamd_raytracer",
+                        "-lptamd_host", "-L" + CSRC_DIR, "-lptamd", "-Wl,-rpath," + HOST_DIR, "-Wl,-rpath," + CSRC_DIR], cwd=ex_dir, check=True)
     return out, exe
 
 

@@ -57,3 +57,17 @@ def test_a_dynamic_mesh_that_does_not_count_generations_is_uploaded_every_time(g
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "stale_differs=1 same_as_fresh=1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_rebuilt_tree_per_frame_loop(gpu):
+    """examples/rebuild_loop.cpp: the OTHER branch of the reference's MeshSequence::buildBvh (src/model/mesh_sequence.cpp:89-96: a new tree per frame with the
+    fast binned builder) through the kept C++ classes -- a sequence-like IMesh, RayTracer::rebuildGeometry (pt_upload_static_async), RayTracer::frameTick,
+    frames rendered meanwhile.  After the loop the accumulator of four samples equals, bit for bit, that of a RayTracer that only ever saw the last frame
+    (the mesh's bounds and root are re-read when the scene is flattened again).  Timed by the example's own output and bench.py's `rebuild_20k`, not here."""
+    exe = os.path.join(ROOT, "examples", "rebuild_loop")
+    r = subprocess.run([exe, "4", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    fields = dict(kv.split("=") for kv in r.stdout.split() if "=" in kv)
+    assert int(fields["triangles"]) == 5120 and fields["same_as_fresh"] == "1"
+    assert 0 < float(fields["until_first_new_frame_ms"]) < 100.0, fields
