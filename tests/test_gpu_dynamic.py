@@ -525,7 +525,23 @@ def test_a_rebuilt_scene_of_every_kind_of_tree_equals_a_fresh_context(gpu, recor
     ctx = U.make_ctx(gpu, start, W, Hh, seed=5, samples_in_flight=1)
     ctx.render(2)
     sky = tex = None
-    for name, bundle, flags in (("grid of SBVH meshes, copied", scenes.instanced_grid(W, Hh, nx=3, nz=2, level=3), 0),
+
+    class Quads:  # nothing but single-leaf meshes: no packed node at all (k_refit_nodes has nothing to do, the leaves hang off the top level)
+        sky = material_textures = None
+        camera = start.camera
+        mb = scenes._MeshBuilder()
+        mats = scenes._room_materials()
+        scenes._room(mb, mats)
+        _scene = H.Scene()
+        _v = np.array([[-0.5, 0.0, -0.5], [0.5, 0.0, -0.5], [0.5, 0.0, 0.5], [-0.5, 0.0, 0.5]], np.float32)
+        for _k, _y in enumerate((0.4, 0.9, 1.4)):
+            _scene.add_node(H.Mesh(_v * (1.0 - 0.2 * _k), np.array([[0, 1, 2], [0, 2, 3]], np.uint32), [L.material_diffuse((0.8, 0.5 + 0.2 * _k, 0.3))],
+                                   builder=H.BVH_BINNED_SAH), location=(0.0, _y, 0.0))
+        _scene.add_node(H.Mesh(_v * 0.4, np.array([[0, 2, 1], [0, 3, 2]], np.uint32), [L.material_emissive((1.0, 0.9, 0.8), 12.0)], builder=H.BVH_BINNED_SAH),
+                        location=(0.0, 1.9, 0.0))
+        flat = _scene.flatten()
+
+    for name, bundle, flags in (("single-leaf meshes only", Quads, 0), ("grid of SBVH meshes, copied", scenes.instanced_grid(W, Hh, nx=3, nz=2, level=3), 0),
                                 ("five material types on one mesh", scenes.mixed_material_room(W, Hh, level=3), 0),
                                 ("crowd, turned instances", scenes.instanced_crowd(W, Hh, nx=3, nz=2, level=2), 0)):
         ctx.upload_static_async(bundle.flat)
