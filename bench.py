@@ -34,6 +34,8 @@ with the largest share of device time (k_trace<true>, the any-hit traversal of t
 traversal code) on this box's host cores over a bounded sample of the same frame.
 """
 import argparse
+import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -85,6 +87,59 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def _cpu_list(path):
+    cpus = set()
+    for part in open(path).read().strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_one_l3_domain(local_rank=0):
+    """The application's share of thread placement: this process (and every thread it starts from here on -- the host library's worker pool, the HIP
+    runtime's helpers) is restricted to the CPUs that share ONE last-level cache.  On the two-socket, sixteen-domain hosts of this pool the scheduler
+    otherwise spreads a loop's eight threads over domains and sockets: a rebuilt-tree tick took 4.7-5.7 ms unpinned against 3.9-4.2 pinned, `Mesh()`
+    1.6-2.2 against 1.0-1.15 (EXPERIMENTS.md, round 6).  N = 1: the quietest domain of the memory node this process runs on (two /proc/stat samples 50 ms
+    apart); N > 1: domain `local_rank` of that node's list, so that ranks do not share one.  Returns what it did, for the bench line; PTAMD_BENCH_PIN=0: nothing."""
+    if os.environ.get("PTAMD_BENCH_PIN", "1") in ("0", "off") or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False, "why": "disabled"}
+    try:
+        allowed = os.sched_getaffinity(0)
+        here = C.CDLL(None).sched_getcpu()
+        node = next((_cpu_list(os.path.join(d, "cpulist")) for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
+                     if here in _cpu_list(os.path.join(d, "cpulist"))), allowed)
+        domains = {}
+        for c in sorted(allowed & node):
+            d = frozenset(_cpu_list(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list") & allowed)
+            if d:
+                domains.setdefault(min(d), d)
+        if len(domains) < 2:
+            return {"pinned": False, "why": "one last-level cache domain"}
+
+        def busy():
+            out = {}
+            for line in open("/proc/stat"):
+                f = line.split()
+                if f[0].startswith("cpu") and f[0] != "cpu":
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = sum(v) - v[3] - v[4]  # everything but idle and iowait
+            return out
+        keys = sorted(domains)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            pick = keys[local_rank % len(keys)]
+        else:
+            b0 = busy()
+            time.sleep(0.05)
+            b1 = busy()
+            pick = min(keys, key=lambda k: sum(b1.get(c, 0) - b0.get(c, 0) for c in domains[k]))
+        os.sched_setaffinity(0, domains[pick])
+        return {"pinned": True, "cpus": len(domains[pick]), "first_cpu": int(pick), "domains_on_node": len(keys),
+                "what": "process restricted to one last-level cache domain (bench.py pin_to_one_l3_domain); the CPU baseline runs on the original mask"}
+    except Exception as e:  # a host without these files: run where the scheduler puts us
+        return {"pinned": False, "why": str(e)[:120]}
 
 
 def reference_kernels_baseline(O, sc, bundle, width, height, seconds=3.0):
@@ -760,6 +815,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or "
                          f"without a launcher (bench.py then starts the ranks itself)")
 
+    original_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    host_affinity = pin_to_one_l3_domain(local_rank)  # (before torch, HIP and the host library start their threads: they inherit it)
     import torch
     import torch.distributed as dist
     from ptamd import device as D, host as H, layout as L, scenes
@@ -892,7 +949,14 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
+        pinned = os.sched_getaffinity(0) if original_affinity is not None else None
+        if original_affinity is not None:
+            os.sched_setaffinity(0, original_affinity)  # the oracle's threads start here and inherit the mask the process came with
+        try:
+            cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
+        finally:
+            if pinned is not None:
+                os.sched_setaffinity(0, pinned)
     ctx.close()
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
@@ -927,7 +991,7 @@ def main():
                                "mesh instances entered at traversal, single-leaf meshes copied (PT_FLAG_TWO_LEVEL_ONLY)" if args.flags & 4 else
                                "instances copied to world space at upload (the library's default while they fit a 2 GB budget; the `two_level` "
                                "object times the same scene with the instances entered instead)"),
-                "scene_flags": args.flags, "csrc_sha256": csrc_sha256(),
+                "scene_flags": args.flags, "csrc_sha256": csrc_sha256(), "host_affinity": host_affinity,
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
                 "resident_gb": round(resident_bytes(in_flight, owned, per_entry) / 1e9, 1),  # queues + accumulator planes of this rank (bytes_per_entry, 16 B per plane and pixel)

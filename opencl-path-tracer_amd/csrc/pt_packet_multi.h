@@ -105,14 +105,18 @@ __device__ inline void bundleBeamLens(V3 pLo, V3 pHi, V3 mLo, V3 mHi, bool nx, b
 // bundle into more than one octant ends the beam walk: the bundle starts over, sub-packet by sub-packet.
 template <int R, bool TWO_LEVEL, bool LENS = false>
 #ifndef PT_MULTI_MIN_WAVES_TL
-#define PT_MULTI_MIN_WAVES_TL (PT_MULTI_MIN_WAVES > 4 ? 4 : PT_MULTI_MIN_WAVES) // the instantiation that enters instances: at 5 waves per SIMD (96 VGPRs) it spilled 16 registers
-    // inside the node loop -- 44 more vector loads per bundle, all scratch (SQ_INSTS_VMEM_RD +78 % for +9 % vector instructions: profiles/round5/) -- and took
-    // 25.4 instead of 17.7 ms per batch; at 4 waves (113 VGPRs, nothing spilled) 20.5
+#define PT_MULTI_MIN_WAVES_TL PT_MULTI_MIN_WAVES // the instantiation that enters instances.  Round 5 held it at 4 waves per SIMD (at 5 it spilled 16 registers inside the
+    // node loop: 25.4 against 20.5 ms per batch).  Round 6's kernel spills 11 outside it: 5 waves are 8 % faster than 4 (camera rays of the crowds 29.2 -> 26.6 and
+    // 35.3 -> 32.4 ms per batch; config 4 entered 11 593 -> 11 674 Mrays/s, 432 turned instances 9 179 -> 9 311, 208 translated ones 8 676 -> 8 753: A / B / A / B on one box)
 #endif
 #ifndef PT_MULTI_MIN_WAVES_LENS
-#define PT_MULTI_MIN_WAVES_LENS 4 // R origins per lane: 105-120 VGPRs
+#define PT_MULTI_MIN_WAVES_LENS PT_MULTI_MIN_WAVES // R origins per lane (96 VGPRs + 6 spilled at 5 waves; 113 at 4): config 5 on one GPU 11 348 -> 11 451 Mrays/s at 5 ...
 #endif
-__global__ void __launch_bounds__(kPacketBlock, LENS ? PT_MULTI_MIN_WAVES_LENS : (TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES)) k_trace_multi(TraceArgs a)
+#ifndef PT_MULTI_MIN_WAVES_LENS_TL
+#define PT_MULTI_MIN_WAVES_LENS_TL 4 // ... but lens rays INTO instances (128 VGPRs at 4 waves) lose at 5: 10 759 -> 10 488
+#endif
+__global__ void __launch_bounds__(kPacketBlock, LENS ? (TWO_LEVEL ? PT_MULTI_MIN_WAVES_LENS_TL : PT_MULTI_MIN_WAVES_LENS) : (TWO_LEVEL ? PT_MULTI_MIN_WAVES_TL : PT_MULTI_MIN_WAVES))
+    k_trace_multi(TraceArgs a)
 {
     constexpr int RO = LENS ? R : 1; // origins a lane keeps
     constexpr float tShift = LENS ? 1.0f : 0.0f; // the node test's distances are measured from the bundle's waist (t' = t - tShift)

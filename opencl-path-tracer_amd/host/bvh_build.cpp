@@ -99,7 +99,7 @@ namespace {
             if (numRefs >= kParallelBinning && WorkerPool::get().threads() > 1 && !WorkerPool::insideTask() && !sequentialBuild()) {
                 // the top of a large tree: every worker bins a range into bins of its own (min / max and counts: the merged bins do not depend on the split)
                 WorkerPool& pool = WorkerPool::get();
-                const size_t parts = pool.threads(), chunk = (numRefs + parts - 1) / parts;
+                const size_t parts = pool.threads() * 2, chunk = (numRefs + parts - 1) / parts; // (two ranges per thread: whoever is faster takes more)
                 std::vector<std::array<AABB, kObjectBins>> pbox(parts);
                 pcount.resize(parts);
                 partChunk = chunk;
@@ -713,7 +713,7 @@ BvhBuildResult buildBVH(const VertexSceneData* vertices, size_t numVertices, con
     if (numTriangles == 0)
         throw std::invalid_argument("buildBVH: empty mesh");
     std::vector<PrimRef> refs(numTriangles);
-    const size_t perThread = sequentialBuild() ? numTriangles : 4096; // (small meshes and PTAMD_BUILD_THREADS=1: on the caller)
+    const size_t perThread = sequentialBuild() || numTriangles < 8192 ? numTriangles : 1024; // (small meshes and PTAMD_BUILD_THREADS=1: on the caller)
     WorkerPool::get().parallelFor(numTriangles, perThread, [&](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; i++) {
             for (int k = 0; k < 3; k++) {

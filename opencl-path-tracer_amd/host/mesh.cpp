@@ -382,14 +382,14 @@ void Mesh::generateSmoothNormals()
     }
     m_faceNormal.resize(numTriangles);
     WorkerPool& pool = WorkerPool::get();
-    pool.parallelFor(numTriangles, 4096, [&](size_t begin, size_t end) {
+    pool.parallelFor(numTriangles, 1024, [&](size_t begin, size_t end) {
         for (size_t t = begin; t < end; t++) {
             const auto& tri = m_inputTriangles[t];
             auto P = [&](int k) { const float* p = m_vertices[tri.indices[k]].vertex; return vec3(p[0], p[1], p[2]); };
             m_faceNormal[t] = cross(P(1) - P(0), P(2) - P(0));
         }
     });
-    pool.parallelFor(numVertices, 4096, [&](size_t begin, size_t end) {
+    pool.parallelFor(numVertices, 1024, [&](size_t begin, size_t end) {
         for (size_t i = begin; i < end; i++) {
             vec3 acc;
             for (uint32_t c = m_cornerStart[i]; c < m_cornerStart[i + 1]; c++)

@@ -7,7 +7,8 @@ from . import layout as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PTAMD_SANITIZE=1: the AddressSanitizer / UBSan build of the same sources (ptamd/build.py; python needs the sanitizer runtime preloaded)
-HOST_LIB_PATH = os.path.join(_HERE, "..", "host", "libptamd_host_san.so" if os.environ.get("PTAMD_SANITIZE", "") not in ("", "0") else "libptamd_host.so")
+HOST_LIB_PATH = os.environ.get("PTAMD_HOST_LIB") or os.path.join(  # PTAMD_HOST_LIB: another build of the host library (A / B measurements)
+    _HERE, "..", "host", "libptamd_host_san.so" if os.environ.get("PTAMD_SANITIZE", "") not in ("", "0") else "libptamd_host.so")
 
 BVH_BINNED_SAH, BVH_BINNED_FAST, BVH_SPATIAL_SPLIT = 0, 1, 2
 
