@@ -86,6 +86,23 @@ def test_the_builders_that_work_in_place_make_the_trees_of_the_list_based_ones()
     assert make_builder_trees.trees() == want
 
 
+@pytest.mark.parametrize("env", [{"PTAMD_HOST_PIN": "l3all", "PTAMD_HOST_THREADS": "3"}, {"PTAMD_HOST_PIN": "numa", "PTAMD_HOST_SPIN_US": "0"},
+                                 {"PTAMD_HOST_THREADS": "16", "PTAMD_HOST_SPIN_US": "2000"}])
+def test_the_worker_pools_knobs_change_no_tree(env):
+    """PTAMD_HOST_THREADS / PTAMD_HOST_SPIN_US / PTAMD_HOST_PIN (size of the pool, how long an idle worker polls, where its threads may run -- read once, when
+    the pool starts: a fresh process per setting): the same golden digests whatever they say, also where /sys has no cache or node files to pin by."""
+    import subprocess
+    code = ("import sys, json; sys.path.insert(0, %r); import make_builder_trees as m; "
+            "print(json.dumps(m.trees(levels=(4, 5))))" % os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "builder_trees.json")) as fh:
+        want = json.load(fh)
+    assert got and all(want[k] == v for k, v in got.items())
+
+
 def test_a_forked_child_builds_without_the_parents_worker_threads():
     """fork() copies the calling thread only: a child of a process whose worker pool has started must not wait for workers that are not there --
     neither in its loops nor at exit (glibc's pthread_cond_destroy waits for the waiters a copied condition variable still counts)."""
