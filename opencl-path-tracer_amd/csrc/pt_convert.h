@@ -1156,25 +1156,57 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             budgetBytes = (uint64_t)std::max(0.0, atof(e) * (double)(1ull << 30));
         uint64_t usedBytes = 0;
         uint32_t nextNode = staticNodes + out.topSlots, nextTri = staticTris;
+        // Whole trees: ALL of them or none (round 6).  A scene that is partly copied pays for both: every ray runs the kernels that can enter instances,
+        // and the copies' bytes push the shared trees out of the caches (432 instances of the 82 k-triangle meshes, 421 copied + 13 entered: 8 481 Mrays/s
+        // against 9 089 with all of them entered and 9 017 with all of them copied: profiles/round6/).
+        uint64_t allBytes = 0;
+        for (uint32_t k = 0; k < hInst.size(); k++) {
+            const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[k]];
+            if (refCount(root.ref) == 0u)
+                allBytes += (uint64_t)root.numNodes * sizeof(WideNode) + (uint64_t)root.numRefs * sizeof(TriIsect);
+        }
+        const bool copiesAllowed = !(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES), wholeTreesFit = allBytes <= budgetBytes;
+        auto mayBake = [&](uint32_t instIndex) { // by the mesh alone (the byte budget and the index range are the layout's business, below)
+            const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
+            if (refCount(root.ref) != 0u)
+                return true; // the mesh is one leaf
+            return wholeTreesFit && root.bakeable && root.numNodes != 0u && !(c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) && !parityMode(c); // parity mode follows the reference to the letter
+        };
+        // the world transforms of the instances that may be copied: a 4 x 4 inversion in double each -- ten thousand instances moved per tick are ten thousand of
+        // them: on the host library's worker pool
+        struct World {
+            double m[12];
+            bool ok;
+        };
+        std::vector<World> world(copiesAllowed ? hInst.size() : 0);
+        raytracer::WorkerPool::get().parallelFor(world.size(), 256, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++) {
+                world[k].ok = false;
+                if (!mayBake((uint32_t)k))
+                    continue;
+                double w[4][8]; // [r][4..7] = row r of the world transform
+                if (!invertTransform(topNodes[hInst[k].topNode].invTransform, w))
+                    continue; // singular: stays an instance
+                for (int r = 0; r < 3; r++)
+                    for (int col = 0; col < 4; col++)
+                        world[k].m[r * 4 + col] = w[r][4 + col];
+                world[k].ok = true;
+            }
+        });
         auto tryBake = [&](uint32_t instIndex, bool wholeTrees) {
             const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[instIndex]];
             const bool single = refCount(root.ref) != 0u; // the mesh is one leaf
             if (single != !wholeTrees)
                 return;
-            if (!single && (!root.bakeable || root.numNodes == 0u || (c->cfg.flags & PT_FLAG_TWO_LEVEL_ONLY) || parityMode(c))) // parity mode follows the reference to the letter
-                return;
-            double w[4][8]; // [r][4..7] = row r of the world transform
-            if (!invertTransform(topNodes[hInst[instIndex].topNode].invTransform, w))
-                return; // singular: stays an instance
+            if (!world[instIndex].ok)
+                return; // not a mesh that is copied, or a singular transform
             const uint64_t bytes = (uint64_t)root.numNodes * sizeof(WideNode) + (uint64_t)root.numRefs * sizeof(TriIsect);
             if ((!single && usedBytes + bytes > budgetBytes) || (uint64_t)nextNode + root.numNodes >= kRefIndexMask - 4u
                 || (uint64_t)nextTri + root.numRefs >= kRefIndexMask - 4u)
                 return;
             usedBytes += bytes;
             BakeJob j {};
-            for (int r = 0; r < 3; r++)
-                for (int k = 0; k < 4; k++)
-                    j.m[r * 4 + k] = w[r][4 + k];
+            std::memcpy(j.m, world[instIndex].m, sizeof j.m);
             j.srcNode = root.nodeBase, j.numNodes = root.numNodes, j.dstNode = nextNode;
             j.srcRef = root.refBase, j.numRefs = root.numRefs, j.dstTri = nextTri;
             j.instance = instIndex;
@@ -1183,19 +1215,10 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
             nextNode += root.numNodes;
             nextTri += root.numRefs;
         };
-        if (!(c->cfg.flags & PT_FLAG_NO_BAKED_INSTANCES)) {
+        if (copiesAllowed) {
             for (uint32_t k = 0; k < hInst.size(); k++) // single leaves first
                 tryBake(k, false);
-            // Whole trees: ALL of them or none (round 6).  A scene that is partly copied pays for both: every ray runs the kernels that can enter instances,
-            // and the copies' bytes push the shared trees out of the caches (432 instances of the 82 k-triangle meshes, 421 copied + 13 entered: 8 481 Mrays/s
-            // against 9 089 with all of them entered and 9 017 with all of them copied: profiles/round6/).
-            uint64_t allBytes = 0;
-            for (uint32_t k = 0; k < hInst.size(); k++) {
-                const StaticScene::StaticGeom::Root& root = sg.roots[instRoot[k]];
-                if (refCount(root.ref) == 0u)
-                    allBytes += (uint64_t)root.numNodes * sizeof(WideNode) + (uint64_t)root.numRefs * sizeof(TriIsect);
-            }
-            if (allBytes <= budgetBytes)
+            if (wholeTreesFit)
                 for (uint32_t k = 0; k < hInst.size(); k++)
                     tryBake(k, true);
         }
@@ -1264,17 +1287,20 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
         rootRef = makeRef(staticNodes, 0u);
     }
     out.topWide.resize(order.size());
-    out.hasInstances = refCount(rootRef) == kRefSpecial;
-    for (size_t q = 0; q < order.size(); q++) {
-        const WideKids& wk = kids[order[q]];
-        uint32_t refs[4];
-        for (int k = 0; k < 4; k++) {
-            refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(staticNodes + newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
-            if (!wk.empty[k] && refCount(refs[k]) == kRefSpecial)
-                out.hasInstances = true;
+    raytracer::WorkerPool::get().parallelFor(order.size(), 512, [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+            const WideKids& wk = kids[order[q]];
+            uint32_t refs[4];
+            for (int k = 0; k < 4; k++)
+                refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(staticNodes + newIndex[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+            quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[q]);
         }
-        quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[q]);
-    }
+    });
+    out.hasInstances = refCount(rootRef) == kRefSpecial;
+    for (size_t q = 0; q < order.size() && !out.hasInstances; q++)
+        for (uint32_t r : out.topWide[q].child)
+            if (r != sg.emptyRef && refCount(r) == kRefSpecial)
+                out.hasInstances = true;
     // ---- worst-case traversal stack: the top level on top of the deepest thing below it (an entered instance adds its sentinel)
     std::vector<uint32_t> topNeed(order.size(), 0u);
     // the copies' roots are looked up by node index: a map for scenes with many of them
@@ -1380,13 +1406,15 @@ int convertDynamic(pt_ctx* c, const pt_emissive_triangle* lights, uint32_t nL, c
                 rootB = makeRef(foldedBase, 0u);
             }
             out.topWide.resize((size_t)numTopInner + orderB.size()); // (the gap behind the first top level stays zero: never referenced)
-            for (size_t q = 0; q < orderB.size(); q++) {
-                const WideKids& wk = kidsB[orderB[q]];
-                uint32_t refs[4];
-                for (int k = 0; k < 4; k++)
-                    refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(foldedBase + newB[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
-                quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[(size_t)numTopInner + q]);
-            }
+            raytracer::WorkerPool::get().parallelFor(orderB.size(), 512, [&](size_t q0, size_t q1) {
+                for (size_t q = q0; q < q1; q++) {
+                    const WideKids& wk = kidsB[orderB[q]];
+                    uint32_t refs[4];
+                    for (int k = 0; k < 4; k++)
+                        refs[k] = wk.empty[k] ? sg.emptyRef : (isKept(wk.ref[k]) ? makeRef(foldedBase + newB[refIndex(wk.ref[k])], 0u) : wk.ref[k]);
+                    quantiseWideNode(wk.lo, wk.hi, refs, wk.empty, sg.emptyRef, &out.topWide[(size_t)numTopInner + q]);
+                }
+            });
             out.rootRefFolded = rootB;
             // the instances' root copies and the table of their transforms (entry 0: the identity; instances on the general route: the identity too --
             // their lanes hold the instance-space ray in registers)

@@ -1,5 +1,9 @@
 #include "scene.h"
+#include "parallel.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -61,48 +65,97 @@ namespace {
     }
 }
 
-TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>& meshBvhOffsets)
+namespace {
+    // the instances in scene-graph order (the walk carries the world matrices down the graph): made once per flattenDynamic, for the lights and the top level
+    struct Instance {
+        const SceneNode* node;
+        mat4 world;
+    };
+    std::vector<Instance> collectInstances(const SceneNode& root)
+    {
+        std::vector<Instance> instances;
+        walk(root, mat4(), [&](const SceneNode& n, const mat4& world) { instances.push_back({ &n, world }); });
+        return instances;
+    }
+    TopBvhBuildResult buildTopBVHOver(const std::vector<Instance>& instances, const std::vector<uint32_t>& meshBvhOffsets);
+}
+
+TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>& meshBvhOffsets) { return buildTopBVHOver(collectInstances(root), meshBvhOffsets); }
+
+namespace {
+TopBvhBuildResult buildTopBVHOver(const std::vector<Instance>& instances, const std::vector<uint32_t>& meshBvhOffsets)
 {
     TopBvhBuildResult out;
     std::vector<uint32_t> active; // cluster roots still to be merged
-    walk(root, mat4(), [&](const SceneNode& n, const mat4& world) {
-        TopBVHNode leaf;
-        std::memset(&leaf, 0, sizeof(leaf));
-        setBox(leaf, transformedBounds(n.bounds, world));
-        mat4 inv = inverse(world);
-        std::memcpy(leaf.invTransform, inv.data(), sizeof(leaf.invTransform));
-        leaf.a = *n.subBvhRootID + meshBvhOffsets[*n.meshID];
-        leaf.b = 0;
-        leaf.isLeaf = 1;
-        active.push_back((uint32_t)out.nodes.size());
-        out.nodes.push_back(leaf);
+    // every leaf on its own: world bounds, the inverse of the world matrix -- ten thousand instances moved per tick are ten thousand 4 x 4 inversions: on the
+    // worker pool above 512 instances
+    const bool timing = std::getenv("PTAMD_BUILD_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now(), t1 = t0;
+    out.nodes.resize(instances.size());
+    active.resize(instances.size());
+    WorkerPool::get().parallelFor(instances.size(), 256, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            const SceneNode& n = *instances[i].node;
+            TopBVHNode leaf;
+            std::memset(&leaf, 0, sizeof(leaf));
+            setBox(leaf, transformedBounds(n.bounds, instances[i].world));
+            mat4 inv = inverse(instances[i].world);
+            std::memcpy(leaf.invTransform, inv.data(), sizeof(leaf.invTransform));
+            leaf.a = *n.subBvhRootID + meshBvhOffsets[*n.meshID];
+            leaf.b = 0;
+            leaf.isLeaf = 1;
+            active[i] = (uint32_t)i;
+            out.nodes[i] = leaf;
+        }
     });
     if (active.empty())
         throw std::invalid_argument("buildTopBVH: scene has no mesh instances");
+    const auto t2 = std::chrono::steady_clock::now();
+    struct Report {
+        bool on;
+        std::chrono::steady_clock::time_point t0, t1, t2;
+        size_t n;
+        ~Report()
+        {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            if (on)
+                fprintf(stderr, "[ptamd_host] buildTopBVH: %zu instances, leaves %.3f ms, tree %.3f\n", n, ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
+        }
+    } report { timing, t0, t1, t2, instances.size() };
     // The agglomerative clustering below is the reference's (top_bvh_build.cpp:42-93): every merge searches ALL clusters still active
     // for a best partner -- O(n) per search, O(n^2) and worse per tree: 0.03 ms for 14 instances, 16 ms for 1 000, 240 ms for 4 000, every
     // tick.  It is kept where it is cheap (the reference's scenes hold a handful of instances: the identical tree); larger scenes get a
     // top-down build over the instance boxes -- 16-bin SAH on the centroids along the longest axis, median where the bins do not separate
     // -- which is O(n log n).  Either tree is just as valid an input to the traversal (inner nodes after their children, root last).
     if (active.size() > kAgglomerativeMaxInstances) {
-        struct Range {
-            uint32_t first, count;
-        };
         std::vector<uint32_t> order = active;
+        // the leaves' boxes and centroids side by side (a TopBVHNode is 112 bytes, most of it the matrix): what the build reads thirteen times per leaf
+        std::vector<AABB> leafBox(order.size());
+        std::vector<vec3> leafCentre(order.size());
+        for (size_t i = 0; i < order.size(); i++)
+            leafBox[i] = getBox(out.nodes[i]), leafCentre[i] = leafBox[i].center();
         // A SAH split that peels one box off per level (geometrically spaced instances) makes a tree as deep as the instance count, which the
         // device library then refuses for its traversal stack -- a balanced tree over the same boxes would do.  Lop-sided splits (fewer than an
         // eighth on one side) are only taken while the depth stays within 2 log2(n); beyond that the median decides.
         uint32_t depthBudget = 2;
         for (size_t n = order.size(); n > 1; n >>= 1)
             depthBudget += 2;
-        std::function<uint32_t(Range, uint32_t)> build = [&](Range r, uint32_t depth) -> uint32_t {
-            if (r.count == 1)
-                return order[r.first];
+        // A subtree over `count` leaves has count - 1 inner nodes, and the recursion this replaces pushed them in post-order (left subtree, right subtree,
+        // parent): the subtree whose first inner node is `base` owns [base, base + count - 1) and its root is the last of them -- every node's index is
+        // known before anything below it is built, so the subtrees below ~1/32 of the instances are built side by side on the worker pool and the
+        // array is the sequential build's byte for byte.
+        struct Item {
+            uint32_t first, count, depth, base;
+        };
+        const uint32_t numLeaves = (uint32_t)order.size();
+        out.nodes.resize((size_t)numLeaves * 2 - 1);
+        auto rootIndex = [&](const Item& it) { return it.count == 1 ? order[it.first] : it.base + it.count - 2; };
+        auto splitOne = [&](const Item& r, Item& left, Item& right) {
+            const uint32_t depth = r.depth;
             AABB cb, nb;
             for (uint32_t k = 0; k < r.count; k++) {
-                const AABB b = getBox(out.nodes[order[r.first + k]]);
-                cb.fit(b.center());
-                nb.fit(b);
+                cb.fit(leafCentre[order[r.first + k]]);
+                nb.fit(leafBox[order[r.first + k]]);
             }
             const vec3 ext = cb.extent();
             const int axis = ext.x >= ext.y ? (ext.x >= ext.z ? 0 : 2) : (ext.y >= ext.z ? 1 : 2);
@@ -114,10 +167,10 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
                 constexpr int kBins = 16;
                 AABB binBox[kBins];
                 uint32_t binCount[kBins] = {};
-                auto binOf = [&](uint32_t node) { return std::min(kBins - 1, (int)((comp(getBox(out.nodes[node]).center()) - lo) / width * kBins)); };
+                auto binOf = [&](uint32_t node) { return std::min(kBins - 1, (int)((comp(leafCentre[node]) - lo) / width * kBins)); };
                 for (uint32_t k = 0; k < r.count; k++) {
                     const int b = binOf(order[r.first + k]);
-                    binBox[b].fit(getBox(out.nodes[order[r.first + k]]));
+                    binBox[b].fit(leafBox[order[r.first + k]]);
                     binCount[b]++;
                 }
                 float rightArea[kBins];
@@ -150,21 +203,51 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
             if (!split) { // all centroids in one place (or a handful of boxes): the median along the axis
                 mid = r.count / 2;
                 std::nth_element(order.begin() + r.first, order.begin() + r.first + mid, order.begin() + r.first + r.count,
-                    [&](uint32_t x, uint32_t y) { return comp(getBox(out.nodes[x]).center()) < comp(getBox(out.nodes[y]).center()); });
+                    [&](uint32_t x, uint32_t y) { return comp(leafCentre[x]) < comp(leafCentre[y]); });
             }
-            const uint32_t l = build({ r.first, mid }, depth + 1), rr = build({ r.first + mid, r.count - mid }, depth + 1);
+            left = { r.first, mid, depth + 1, r.base };
+            right = { r.first + mid, r.count - mid, depth + 1, r.base + (mid - 1) };
             TopBVHNode inner;
             std::memset(&inner, 0, sizeof(inner));
             setBox(inner, nb);
             mat4 identity;
             std::memcpy(inner.invTransform, identity.data(), sizeof(inner.invTransform));
-            inner.a = l;
-            inner.b = rr;
+            inner.a = rootIndex(left);
+            inner.b = rootIndex(right);
             inner.isLeaf = 0;
-            out.nodes.push_back(inner);
-            return (uint32_t)out.nodes.size() - 1;
+            out.nodes[r.base + r.count - 2] = inner;
         };
-        out.rootNode = build({ 0, (uint32_t)order.size() }, 0);
+        const uint32_t grain = std::max<uint32_t>(256, numLeaves / 32);
+        std::vector<Item> tasks;
+        auto buildBelow = [&](Item top, std::vector<Item>* setAside) {
+            std::vector<Item> stack { top };
+            while (!stack.empty()) {
+                const Item it = stack.back();
+                stack.pop_back();
+                if (it.count == 1)
+                    continue;
+                if (setAside && it.depth > 0 && it.count <= grain) {
+                    setAside->push_back(it);
+                    continue;
+                }
+                Item l, r;
+                splitOne(it, l, r);
+                stack.push_back(r);
+                stack.push_back(l);
+            }
+        };
+        const Item all { 0, numLeaves, 0, numLeaves };
+        WorkerPool& pool = WorkerPool::get();
+        const bool pooled = pool.threads() > 1 && numLeaves >= 2048;
+        buildBelow(all, pooled ? &tasks : nullptr);
+        if (!tasks.empty()) {
+            std::atomic<size_t> next { 0 };
+            pool.parallelFor(pool.threads(), 1, [&](size_t, size_t) {
+                for (size_t t; (t = next.fetch_add(1)) < tasks.size();)
+                    buildBelow(tasks[t], nullptr);
+            });
+        }
+        out.rootNode = rootIndex(all);
         return out;
     }
 
@@ -208,6 +291,8 @@ TopBvhBuildResult buildTopBVH(const SceneNode& root, const std::vector<uint32_t>
     out.rootNode = (uint32_t)out.nodes.size() - 1;
     return out;
 }
+
+} // namespace
 
 void flattenStatic(Scene& scene, FlattenedScene& out)
 {
@@ -262,11 +347,14 @@ void flattenStatic(Scene& scene, FlattenedScene& out)
 void flattenDynamic(const Scene& scene, FlattenedScene& out)
 {
     out.emissiveTriangles.clear();
-    walk(scene.getRootNode(), mat4(), [&](const SceneNode& n, const mat4& world) {
+    const std::vector<Instance> instances = collectInstances(scene.getRootNode());
+    for (const Instance& inst : instances) {
+        const SceneNode& n = *inst.node;
+        const mat4& world = inst.world;
         const IMesh& mesh = *scene.getMeshes()[*n.meshID].meshPtr;
         for (uint32_t ti : mesh.getEmissiveTriangles()) {
             if (out.emissiveTriangles.size() >= kMaxNumLights)
-                return;
+                break;
             const TriangleSceneData& tri = mesh.getTriangles()[ti];
             pt_emissive_triangle e;
             std::memset(&e, 0, sizeof(e));
@@ -278,11 +366,11 @@ void flattenDynamic(const Scene& scene, FlattenedScene& out)
             e.material = mesh.getMaterials()[tri.materialIndex];
             out.emissiveTriangles.push_back(e);
         }
-    });
+    }
     std::vector<uint32_t> offsets;
     for (const MeshBvhPair& p : scene.getMeshes())
         offsets.push_back(p.bvhIndexOffset);
-    TopBvhBuildResult top = buildTopBVH(scene.getRootNode(), offsets);
+    TopBvhBuildResult top = buildTopBVHOver(instances, offsets);
     out.topBvhNodes = std::move(top.nodes);
     out.topBvhRoot = top.rootNode;
 }
