@@ -136,8 +136,9 @@ def pin_to_one_l3_domain(local_rank=0):
             b1 = busy()
             pick = min(keys, key=lambda k: sum(b1.get(c, 0) - b0.get(c, 0) for c in domains[k]))
         os.sched_setaffinity(0, domains[pick])
-        return {"pinned": True, "cpus": len(domains[pick]), "first_cpu": int(pick), "domains_on_node": len(keys),
-                "what": "process restricted to one last-level cache domain (bench.py pin_to_one_l3_domain); the CPU baseline runs on the original mask"}
+        return {"pinned": True, "cpus": len(domains[pick]), "first_cpu": int(pick), "domains_on_node": len(keys), "node_cpus": sorted(allowed & node),
+                "what": "process restricted to one last-level cache domain (bench.py pin_to_one_l3_domain); the CPU baseline's threads run on every CPU of that "
+                        "domain's memory node (where the process allocated the scene)"}
     except Exception as e:  # a host without these files: run where the scheduler puts us
         return {"pinned": False, "why": str(e)[:120]}
 
@@ -179,7 +180,7 @@ def cpu_baseline(bundle, seconds, width, height):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orclib as O  # checker / reported baseline only
     O.build(fast=True, ref=False)  # -O3 -march=native for THIS host
-    cores = usable_cores()
+    cores = int(os.environ.get("PTAMD_BENCH_CPU_THREADS", "0")) or usable_cores()
     sc = O.BoundScene(bundle.flat, sky=bundle.sky, material_textures=bundle.material_textures)
     bx, by = width // 8, height // 8
     order = np.random.default_rng(0).permutation(bx * by)
@@ -951,7 +952,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pinned = os.sched_getaffinity(0) if original_affinity is not None else None
         if original_affinity is not None:
-            os.sched_setaffinity(0, original_affinity)  # the oracle's threads start here and inherit the mask the process came with
+            # the oracle's threads start here and inherit this mask: every CPU of the memory node the pinned process allocated the scene on (threads on the other
+            # socket read it remotely: 14-16 against 27-28 Mrays/s, alternating on one box), or the mask the process came with
+            os.sched_setaffinity(0, set(host_affinity.get("node_cpus") or original_affinity))
         try:
             cpu = cpu_baseline(bundle, args.cpu_seconds, W, Hh)
         finally:
@@ -991,7 +994,7 @@ def main():
                                "mesh instances entered at traversal, single-leaf meshes copied (PT_FLAG_TWO_LEVEL_ONLY)" if args.flags & 4 else
                                "instances copied to world space at upload (the library's default while they fit a 2 GB budget; the `two_level` "
                                "object times the same scene with the instances entered instead)"),
-                "scene_flags": args.flags, "csrc_sha256": csrc_sha256(), "host_affinity": host_affinity,
+                "scene_flags": args.flags, "csrc_sha256": csrc_sha256(), "host_affinity": {k: v for k, v in host_affinity.items() if k != "node_cpus"},
                 "width": W, "height": Hh, "level": args.level, "spp_per_step": spp_step, "samples_in_flight": in_flight, "batches_per_step": args.rounds,
                 "samples_in_flight_planned": planned, "samples_in_flight_fallbacks": fallbacks,
                 "resident_gb": round(resident_bytes(in_flight, owned, per_entry) / 1e9, 1),  # queues + accumulator planes of this rank (bytes_per_entry, 16 B per plane and pixel)
