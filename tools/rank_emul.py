@@ -21,7 +21,7 @@ ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
 ap.add_argument("--all-ranks", action="store_true", help="every rank's share (default: rank 0's only)")
 ap.add_argument("--worlds", type=int, nargs="*", default=[1, 2, 4, 8])
 ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--rounds", type=int, default=1, help="batches per step (bench.py's default is 5)")
+ap.add_argument("--rounds", type=int, default=1, help="batches per step (bench.py: 3)")
 ap.add_argument("--in-flight", type=int, default=bench.IN_FLIGHT)
 ap.add_argument("--json", default=None)
 args = ap.parse_args()
