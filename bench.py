@@ -103,7 +103,7 @@ def pin_to_one_l3_domain(local_rank=0):
     runtime's helpers) is restricted to the CPUs that share ONE last-level cache.  On the two-socket, sixteen-domain hosts of this pool the scheduler
     otherwise spreads a loop's eight threads over domains and sockets: a rebuilt-tree tick took 4.7-5.7 ms unpinned against 3.9-4.2 pinned, `Mesh()`
     1.6-2.2 against 1.0-1.15 (EXPERIMENTS.md, round 6).  N = 1: the quietest domain of the memory node this process runs on (two /proc/stat samples 50 ms
-    apart); N > 1: domain `local_rank` of that node's list, so that ranks do not share one.  Returns what it did, for the bench line; PTAMD_BENCH_PIN=0: nothing."""
+    apart); N > 1: the ranks of a node spread evenly over all its domains in order, so that no two share one.  Returns what it did, for the bench line; PTAMD_BENCH_PIN=0: nothing."""
     if os.environ.get("PTAMD_BENCH_PIN", "1") in ("0", "off") or not hasattr(os, "sched_setaffinity"):
         return {"pinned": False, "why": "disabled"}
     try:
@@ -128,8 +128,17 @@ def pin_to_one_l3_domain(local_rank=0):
                     out[int(f[0][3:])] = sum(v) - v[3] - v[4]  # everything but idle and iowait
             return out
         keys = sorted(domains)
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            pick = keys[local_rank % len(keys)]
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        if local_world > 1:
+            # the ranks of a node spread evenly over ALL its domains, in order (8 ranks on 16 domains: every second one -- ranks 0-3 on the first socket,
+            # 4-7 on the second, as the GPUs usually are)
+            every = {}
+            for c in sorted(allowed):
+                d = frozenset(_cpu_list(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list") & allowed)
+                if d:
+                    every.setdefault(min(d), d)
+            domains, keys = every, sorted(every)
+            pick = keys[(local_rank * max(1, len(keys) // local_world)) % len(keys)]
         else:
             b0 = busy()
             time.sleep(0.05)
