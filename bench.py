@@ -98,19 +98,48 @@ def _cpu_list(path):
     return cpus
 
 
+def gpu_memory_node(local_rank=0):
+    """The memory node the rank's GPU hangs off, from the KFD topology (the compute nodes this process may open, in order; location_id = bus << 8 | devfn)
+    and the PCI device's numa_node; None where that cannot be read.  No HIP call: this runs before anything touches the GPU."""
+    try:
+        gpus = []
+        for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/[0-9]*"), key=lambda p: int(os.path.basename(p))):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(d, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        if not gpus:
+            return None
+        g = gpus[local_rank] if local_rank < len(gpus) else gpus[0]
+        loc, dom = int(g["location_id"]), int(g.get("domain", "0"))
+        node = int(open(f"/sys/bus/pci/devices/{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7}/numa_node").read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
 def pin_to_one_l3_domain(local_rank=0):
     """The application's share of thread placement: this process (and every thread it starts from here on -- the host library's worker pool, the HIP
     runtime's helpers) is restricted to the CPUs that share ONE last-level cache.  On the two-socket, sixteen-domain hosts of this pool the scheduler
     otherwise spreads a loop's eight threads over domains and sockets: a rebuilt-tree tick took 4.7-5.7 ms unpinned against 3.9-4.2 pinned, `Mesh()`
-    1.6-2.2 against 1.0-1.15 (EXPERIMENTS.md, round 6).  N = 1: the quietest domain of the memory node this process runs on (two /proc/stat samples 50 ms
+    1.6-2.2 against 1.0-1.15 (EXPERIMENTS.md, round 6).  N = 1: the quietest domain of the memory node the GPU hangs off (else: this process runs on; two /proc/stat samples 50 ms
     apart); N > 1: the ranks of a node spread evenly over all its domains in order, so that no two share one.  Returns what it did, for the bench line; PTAMD_BENCH_PIN=0: nothing."""
     if os.environ.get("PTAMD_BENCH_PIN", "1") in ("0", "off") or not hasattr(os, "sched_setaffinity"):
         return {"pinned": False, "why": "disabled"}
     try:
         allowed = os.sched_getaffinity(0)
         here = C.CDLL(None).sched_getcpu()
-        node = next((_cpu_list(os.path.join(d, "cpulist")) for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
-                     if here in _cpu_list(os.path.join(d, "cpulist"))), allowed)
+        gpu_node = gpu_memory_node(local_rank)  # (the GPU's side of the machine: 1-spp frames are 1.5-2 % faster from there than from the other socket)
+        node = None
+        if gpu_node is not None and os.path.exists(f"/sys/devices/system/node/node{gpu_node}/cpulist"):
+            node = _cpu_list(f"/sys/devices/system/node/node{gpu_node}/cpulist")
+            if not (node & allowed):
+                node = None
+        if node is None:
+            node = next((_cpu_list(os.path.join(d, "cpulist")) for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
+                         if here in _cpu_list(os.path.join(d, "cpulist"))), allowed)
         domains = {}
         for c in sorted(allowed & node):
             d = frozenset(_cpu_list(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list") & allowed)
@@ -129,7 +158,9 @@ def pin_to_one_l3_domain(local_rank=0):
             return out
         keys = sorted(domains)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        if local_world > 1:
+        if local_world > 1 and gpu_node is not None:
+            pick = keys[local_rank % len(keys)]  # a domain of the rank's GPU's memory node: ranks whose GPUs share a node take different ones
+        elif local_world > 1:
             # the ranks of a node spread evenly over ALL its domains, in order (8 ranks on 16 domains: every second one -- ranks 0-3 on the first socket,
             # 4-7 on the second, as the GPUs usually are)
             every = {}
@@ -145,7 +176,7 @@ def pin_to_one_l3_domain(local_rank=0):
             b1 = busy()
             pick = min(keys, key=lambda k: sum(b1.get(c, 0) - b0.get(c, 0) for c in domains[k]))
         os.sched_setaffinity(0, domains[pick])
-        return {"pinned": True, "cpus": len(domains[pick]), "first_cpu": int(pick), "domains_on_node": len(keys), "node_cpus": sorted(allowed & node),
+        return {"pinned": True, "cpus": len(domains[pick]), "first_cpu": int(pick), "domains_on_node": len(keys), "gpu_memory_node": gpu_node, "node_cpus": sorted(allowed & node),
                 "what": "process restricted to one last-level cache domain (bench.py pin_to_one_l3_domain); the CPU baseline's threads run on every CPU of that "
                         "domain's memory node (where the process allocated the scene)"}
     except Exception as e:  # a host without these files: run where the scheduler puts us
